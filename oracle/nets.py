@@ -1,0 +1,57 @@
+"""Layer tables of the four BASELINE nets, restated as data.
+
+Follows /root/reference/isprs_dilated_random.py:
+  dilated_icpr_original      (Dilated6)         :761-788
+  dilated_icpr_rate6_densely (DenseDilated6)    :914-959
+  dilated_grsl               (Dilated6Pooling)  :962-993
+  dilated_grsl_rate8         (Dilated8Pooling)  :996-1033   (net_type 'dilated8_grsl' at :1672)
+
+Each conv entry is (scope, k, c_in, c_out, rate); c_in == -1 means "input channels".
+"""
+
+NETS = {
+    "dilated_icpr_original": dict(
+        act="relu", pool=False, dense=False,
+        convs=[("main_conv1", 5, -1, 64, 1), ("main_conv2", 5, 64, 64, 1),
+               ("main_conv3", 4, 64, 128, 2), ("main_conv4", 4, 128, 128, 2),
+               ("main_conv5", 3, 128, 256, 4), ("main_conv6", 3, 256, 256, 4)],
+        c_last=256),
+    "dilated_grsl": dict(
+        act="lrelu", pool=True, dense=False,
+        convs=[("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2),
+               ("conv3", 4, 64, 128, 3), ("conv4", 4, 128, 128, 4),
+               ("conv5", 3, 128, 256, 5), ("conv6", 3, 256, 256, 6)],
+        c_last=256),
+    "dilated_grsl_rate8": dict(
+        act="lrelu", pool=True, dense=False,
+        convs=[("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2),
+               ("conv3", 4, 64, 128, 3), ("conv4", 4, 128, 128, 4),
+               ("conv5", 3, 128, 192, 5), ("conv6", 3, 192, 192, 6),
+               ("conv7", 3, 192, 256, 7), ("conv8", 3, 256, 256, 8)],
+        c_last=256),
+    "dilated_icpr_rate6_densely": dict(
+        act="relu", pool=False, dense=True,
+        convs=[("conv1", 5, -1, 32, 1), ("conv2", 5, 32, 32, 2),
+               ("conv3", 4, 64, 64, 3), ("conv4", 4, 128, 64, 4),
+               ("conv5", 3, 192, 128, 5), ("conv6", 3, 320, 128, 6)],
+        c_last=448),
+}
+# isprs:1672 spells Dilated8Pooling 'dilated8_grsl'; coffee/contest/README spell it 'dilated_grsl_rate8'
+ALIASES = {"dilated8_grsl": "dilated_grsl_rate8"}
+
+
+def resolve(net_type):
+    return ALIASES.get(net_type, net_type)
+
+
+def conv_specs(net_type, channels):
+    spec = NETS[resolve(net_type)]
+    return [(n, k, channels if ci < 0 else ci, co, r) for (n, k, ci, co, r) in spec["convs"]]
+
+
+def same_pad(k, rate):
+    """tf.nn.atrous_conv2d / conv2d SAME padding, stride 1 (isprs:710-712)."""
+    k_eff = k + (k - 1) * (rate - 1)
+    total = k_eff - 1
+    before = total // 2
+    return before, total - before

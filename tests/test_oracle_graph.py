@@ -1,0 +1,127 @@
+"""oracle/tf_ops.py (numpy, hand-derived backward) vs oracle/torch_ref.py (PyTorch-CPU
+autograd): two independent restatements of the reference graph must agree.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tf_ops as T
+from oracle.torch_ref import TorchNet
+from oracle import nets
+
+CASES = [("dilated_icpr_original", 3, 6, 2, 9), ("dilated_grsl", 5, 6, 2, 10),
+         ("dilated8_grsl", 5, 6, 2, 11), ("dilated_icpr_rate6_densely", 4, 2, 3, 8)]
+
+
+def test_same_pad_table():
+    assert nets.same_pad(4, 3) == (4, 5)       # asymmetric
+    assert nets.same_pad(4, 4) == (6, 6)
+    assert nets.same_pad(5, 2) == (4, 4)
+    assert nets.same_pad(3, 8) == (8, 8)
+    assert nets.same_pad(5, 1) == (2, 2)
+    assert nets.same_pad(4, 2) == (3, 3)
+
+
+def test_mac_per_pixel_matches_baseline_md():
+    def mac(net, c, k):
+        return sum(kk * kk * ci * co for (_, kk, ci, co, _) in nets.conv_specs(net, c)) + nets.NETS[nets.resolve(net)]["c_last"] * k
+    assert mac("dilated_grsl_rate8", 5, 6) == 2090304
+    assert mac("dilated_grsl", 5, 6) == 1389888
+    assert mac("dilated_icpr_original", 3, 6) == 1386688
+    assert mac("dilated_icpr_rate6_densely", 4, 2) == 816128
+
+
+@pytest.mark.parametrize("net,ch,K,B,s", CASES)
+def test_forward_and_grads_agree(net, ch, K, B, s):
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(B, s, s, ch))
+    y = rng.integers(0, K, size=(B, s, s))
+    o = T.OracleNet(net, ch, K, dtype=np.float64, seed=1)
+    # perturb biases / moving stats so that nothing cancels by accident
+    for n in o.p:
+        if n.endswith("biases"):
+            o.p[n] = o.p[n] + rng.normal(size=o.p[n].shape) * 0.05
+        if n.endswith("moving_mean"):
+            o.p[n] = rng.normal(size=o.p[n].shape) * 0.1
+        if n.endswith("moving_variance"):
+            o.p[n] = rng.uniform(0.5, 1.5, size=o.p[n].shape)
+    t = TorchNet(net, ch, K, params=o.p, dtype=torch.float64)
+    # eval-mode logits
+    np.testing.assert_allclose(o.forward(x, False), t.forward(x, False).detach().numpy(), rtol=1e-9, atol=1e-10)
+    # train-mode loss, logits and every gradient
+    wd = 0.005
+    loss_o, pred_o, g_o, logits_o = o.loss_and_grads(x, y, wd)
+    loss_t, logits_t, g_t = t.grads(x, y, wd)
+    assert abs(loss_o - loss_t) < 1e-10
+    np.testing.assert_allclose(logits_o, logits_t, rtol=1e-8, atol=1e-9)
+    for n in g_t:
+        np.testing.assert_allclose(g_o[n], g_t[n], rtol=1e-6, atol=1e-9, err_msg=n)
+    # moving statistics after one training forward
+    tp = t.get_params()
+    for n in o.p:
+        if "moving" in n:
+            np.testing.assert_allclose(o.p[n], tp[n], rtol=1e-9, atol=1e-12, err_msg=n)
+
+
+def test_masked_loss_agrees():
+    rng = np.random.default_rng(2)
+    net, ch, K, B, s = "dilated_grsl", 3, 7, 2, 9
+    x = rng.normal(size=(B, s, s, ch))
+    y = rng.integers(0, K, size=(B, s, s))
+    m = rng.integers(0, 2, size=(B, s, s)).astype(bool)
+    o = T.OracleNet(net, ch, K, seed=3)
+    t = TorchNet(net, ch, K, params=o.p, dtype=torch.float64)
+    loss_o, _, g_o, _ = o.loss_and_grads(x, y, 0.001, mask=m)
+    loss_t, _, g_t = t.grads(x, y, 0.001, mask=m)
+    assert abs(loss_o - loss_t) < 1e-10
+    for n in g_t:
+        np.testing.assert_allclose(g_o[n], g_t[n], rtol=1e-6, atol=1e-9, err_msg=n)
+
+
+def test_three_training_steps_agree():
+    rng = np.random.default_rng(4)
+    net, ch, K, B, s = "dilated8_grsl", 5, 6, 2, 9
+    o = T.OracleNet(net, ch, K, seed=5)
+    t = TorchNet(net, ch, K, params=o.p, dtype=torch.float64)
+    for step in range(3):
+        x = rng.normal(size=(B, s, s, ch))
+        y = rng.integers(0, K, size=(B, s, s))
+        lo, po = o.train_step(x, y, 0.01, 0.005)
+        lt, pt = t.train_step(x, y, 0.01, 0.005)
+        assert abs(lo - lt) < 1e-9
+        np.testing.assert_array_equal(po, pt)
+    tp = t.get_params()
+    for n in o.p:
+        np.testing.assert_allclose(o.p[n], tp[n], rtol=1e-7, atol=1e-10, err_msg=n)
+
+
+def test_finite_difference_of_conv_weight():
+    rng = np.random.default_rng(6)
+    net, ch, K, B, s = "dilated_grsl", 3, 6, 1, 7
+    o = T.OracleNet(net, ch, K, seed=7)
+    x = rng.normal(size=(B, s, s, ch))
+    y = rng.integers(0, K, size=(B, s, s))
+    _, _, g, _ = o.loss_and_grads(x, y, 0.0)
+    name = "conv3/weights"
+    idx = (1, 2, 5, 9)
+    eps = 1e-6
+    base = o.p[name][idx]
+    mm = {n: v.copy() for n, v in o.p.items() if "moving" in n}
+    vals = []
+    for d in (+eps, -eps):
+        o.p[name][idx] = base + d
+        l, _, _, _ = o.loss_and_grads(x, y, 0.0)
+        vals.append(l)
+    o.p[name][idx] = base
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(fd - g[name][idx]) < 1e-6 * max(1.0, abs(fd))
+
+
+def test_lr_schedule_and_pool_ties():
+    assert T.learning_rate(0.01, 49999, 0.5) == 0.01
+    assert T.learning_rate(0.01, 50000, 0.5) == 0.005
+    assert abs(T.learning_rate(0.01, 100001, 0.1) - 0.0001) < 1e-18
+    x = np.zeros((1, 3, 3, 1))
+    out, idx = T.max_pool_3x3(x)          # all ties: first in-bounds window element wins
+    assert idx[0, 0, 0, 0] == 4 and idx[0, 1, 1, 0] == 0 and idx[0, 2, 2, 0] == 0 and idx[0, 0, 2, 0] == 3
+    g = T.max_pool_3x3_bwd(idx, np.ones_like(x))
+    assert g.sum() == 9 and g[0, 0, 0, 0] == 4
