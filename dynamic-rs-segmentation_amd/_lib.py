@@ -1,0 +1,78 @@
+"""ctypes binding of libdrs_hip.so (include/drs.h).  There is no CPU fallback: if the HIP
+library is missing or a symbol is absent this module raises, and so does everything above it."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdrs_hip.so")
+
+_p, _i, _f, _d = C.c_void_p, C.c_int, C.c_float, C.c_double
+_sz, _u64 = C.c_size_t, C.c_ulonglong
+
+# name -> (restype, argtypes); mirrors include/drs.h declaration by declaration
+SIGNATURES = {
+    "drs_conv_mtile": (_i, [_i]),
+    "drs_conv_forward": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p]),
+    "drs_conv_wgrad_splits": (_i, [_i, _i, _i, _i, _i]),
+    "drs_conv_wgrad": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "drs_filter_flip_transpose": (_i, [_p, _p, _i, _i, _i, _p]),
+    "drs_filter_pad_cin": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "drs_stats_reduce": (_i, [_p, _i, _i, _p, _p]),
+    "drs_bn_finish": (_i, [_p, _d, _i, _p, _p, _p, _f, _i, _p]),
+    "drs_bn_eval_coeffs": (_i, [_p, _p, _i, _p, _p]),
+    "drs_bn_act_pool_forward": (_i, [_p, _i, _i, _i, _p, _f, _i, _p, _i, _i, _i, _p, _p]),
+    "drs_bn_backward_rows": (_i, [_i, _i]),
+    "drs_bn_backward_reduce": (_i, [_p, _i, _i, _p, _p, _i, _i, _i, _p, _f, _i, _p, _p, _p]),
+    "drs_bn_backward_apply": (_i, [_p, _p, _i, _i, _i, _p, _p, _d, _p, _i, _i, _i, _p]),
+    "drs_classifier_rows": (_i, [_i, _i]),
+    "drs_classifier_loss": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _p, _p, _p,
+                                 _p, _p]),
+    "drs_rows_reduce_f32": (_i, [_p, _i, _i, _p, _p]),
+    "drs_sum_f64": (_i, [_p, _i, _p, _p]),
+    "drs_l2_loss": (_i, [_p, _sz, _p, _p, _p]),
+    "drs_momentum_update": (_i, [_p, _p, _p, _sz, _sz, _f, _f, _f, _f, _p]),
+    "drs_confusion": (_i, [_p, _p, _p, _sz, _i, _i, _p, _p]),
+    "drs_crop_normalize": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _u64, _p, _p, _i, _i, _i, _i, _p, _p,
+                                _p, _p]),
+    "drs_stitch_accumulate": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "drs_stitch_finalize": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+}
+
+
+class DrsError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """dlopen the library once and type every symbol of include/drs.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise DrsError("HIP library not built: %s is missing (run dynamic-rs-segmentation_amd/csrc/build.sh "
+                       "or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+_STATUS = {1: "DRS_ERR_ARG (rejected argument)", 2: "DRS_ERR_HIP (launch failed)"}
+
+
+def call(name, *args):
+    """Call an int-status entry point; raise on a non-zero status."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise DrsError("%s -> %s" % (name, _STATUS.get(rc, rc)))
+
+
+def query(name, *args):
+    """Call a pure size query (returns its int)."""
+    return getattr(load(), name)(*args)

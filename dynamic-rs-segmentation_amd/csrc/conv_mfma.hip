@@ -1,0 +1,454 @@
+// Dilated stride-1 SAME convolution on gfx950 as an fp32 implicit GEMM on the MFMA pipe.
+//
+// Replaces the TensorFlow ops behind /root/reference/isprs_dilated_random.py:710-713
+// (tf.nn.atrous_conv2d / tf.nn.conv2d + bias_add) and their gradients.
+//
+//   forward : z[p, o]  = sum_{u,v,c} X[p + (u,v)*rate - pad, c] * W[u,v,c,o] + bias[o]
+//   dgrad   : the same kernel run on the (zero-haloed) output gradient with the filter flipped in
+//             (u,v) and transposed in (c,o), and pad_before := pad_after
+//   wgrad   : dW[u,v,c,o] = sum_p X[p + (u,v)*rate - pad, c] * G[p, o]   (split over pixels, slabs, ordered reduce)
+//
+// Data layout in HBM: activations are channels-last with an explicit zero halo ("padded NHWC"), so a filter tap is a
+// wave-uniform address offset and the inner loop has no bounds checks; filters are HWIO = a row-major [k*k*Cin][Cout]
+// GEMM B operand as they stand.  GEMM view: M = B*S*S pixels, N = Cout, K = k*k*Cin.
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 64 FLOP/clk/SIMD = the fp32 roof of the chip).  One
+// workgroup = 4 waves (one per SIMD); every wave owns 64x64 (or 64x32) of the output tile = 2x2 MFMA tiles = 64
+// accumulator VGPRs; A tile [BM][32] and B tile [32][BN] are staged through LDS (register prefetch of the next
+// K-step while the current one is multiplied).
+#include "drs_common.hpp"
+
+namespace {
+
+constexpr int BK = 32;        // channels per K-step (every Cin on this path is a multiple of 32; conv1 is zero-padded)
+constexpr int LDA = BK + 4;   // LDS row stride of the A tile: 36 floats -> ds_read_b128 of 16 rows hit 16 distinct slots
+
+struct ConvArgs {
+  const float* in; int S, P, ld_in, coff_in;
+  int M;
+  const float* w;       // [k*k*Cin][Cout]
+  const float* bias;    // [Cout] or null
+  float* out; int ld_out, coff_out;
+  float* stats;         // [mtiles][Cout][2] partial (sum, sumsq) of the output rows of each M tile, or null
+  int k, rate, pad, Cin, Cout;
+  int accumulate;
+  float rcpS, rcpSS;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int LDB = BN + 4;
+  constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
+  constexpr int TM = WTM / 32, TN = WTN / 32;   // MFMA tiles per wave
+  constexpr int NA = BM / 32;                   // float4 A loads per thread per K-step
+  constexpr int NB = BN / 32;                   // float4 B loads per thread per K-step
+  constexpr int BROWS = 256 / (BN / 4);         // B rows covered by one pass of the 256 threads
+
+  __shared__ __attribute__((aligned(16))) float lds[BM * LDA + BK * LDB];
+  float* As = lds;
+  float* Bs = lds + BM * LDA;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int ntn = a.Cout / BN;
+  const int nblk = gridDim.x;
+  const int tile = xcd_remap(blockIdx.x, nblk);
+  const int m0 = (tile / ntn) * BM;
+  const int n0 = (tile % ntn) * BN;
+
+  const int Sp = a.S + 2 * a.P;
+  // per-thread A source offsets (element units, < 2^32): pixel part + slice + this thread's 4-channel column
+  uint32_t offA[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    int p = m0 + (t >> 3) + 32 * i;
+    p = p < a.M ? p : a.M - 1;
+    offA[i] = padded_pixel_off(p, a.S, a.P, a.ld_in, a.rcpS, a.rcpSS, -a.pad, -a.pad) + (uint32_t)(a.coff_in + (t & 7) * 4);
+  }
+  const int brow = t / (BN / 4), bcol = (t % (BN / 4)) * 4;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int cpt = a.Cin / BK;                 // K-steps per filter tap
+  const int nks = a.k * a.k * cpt;
+  f32x4 ra[NA], rb[NB];
+  int lu = 0, lv = 0, lc = 0;                 // (tap row, tap col, channel chunk) of the next K-step to fetch
+
+  auto gload = [&](int ks) {
+    const uint32_t soff = (uint32_t)((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a.in + offA[i] + soff);
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      rb[i] = *reinterpret_cast<const f32x4*>(a.w + (size_t)(ks * BK + brow + BROWS * i) * a.Cout + n0 + bcol);
+    if (++lc == cpt) { lc = 0; if (++lv == a.k) { lv = 0; ++lu; } }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(&As[((t >> 3) + 32 * i) * LDA + (t & 7) * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(&Bs[(brow + BROWS * i) * LDB + bcol]) = rb[i];
+  };
+
+  gload(0);
+  lstore();
+  __syncthreads();
+  const int arow = wm * WTM + li, bcolw = wn * WTN + li;
+  for (int ks = 0; ks < nks; ++ks) {
+    if (ks + 1 < nks) gload(ks + 1);
+    // K is consumed in the order the wide LDS reads deliver it: lane-half h of read q supplies k = 8q+4h+e at step e
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+      f32x4 af[TM];
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) af[mi] = *reinterpret_cast<const f32x4*>(&As[(arow + mi * 32) * LDA + q * 8 + h * 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float bf[TN];
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) bf[ni] = Bs[(q * 8 + h * 4 + e) * LDB + bcolw + ni * 32];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][e], bf[ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (ks + 1 < nks) { lstore(); __syncthreads(); }
+  }
+
+  // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  float s1[TN], s2[TN];
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni) { s1[ni] = 0.f; s2[ni] = 0.f; }
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni) {
+    const int col = n0 + wn * WTN + ni * 32 + li;
+    const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < a.M) {
+          float v = acc[mi][ni][r] + bv;
+          float* dst = a.out + (size_t)row * a.ld_out + a.coff_out + col;
+          if (a.accumulate) v += *dst;
+          *dst = v;
+          s1[ni] += v;
+          s2[ni] += v * v;
+        }
+      }
+    }
+  }
+  if (a.stats) {
+    // fixed-order reduction: lane halves, then the WM waves that share these columns; one slab row per M tile
+    float* red = lds;   // [WM][BN][2], aliases the (finished) A tile
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      s1[ni] += __shfl_xor(s1[ni], 32);
+      s2[ni] += __shfl_xor(s2[ni], 32);
+      if (h == 0) {
+        const int c = wn * WTN + ni * 32 + li;
+        red[(wm * BN + c) * 2 + 0] = s1[ni];
+        red[(wm * BN + c) * 2 + 1] = s2[ni];
+      }
+    }
+    __syncthreads();
+    if (t < BN) {
+      float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { u1 += red[(w * BN + t) * 2]; u2 += red[(w * BN + t) * 2 + 1]; }
+      float* dst = a.stats + ((size_t)(m0 / BM) * a.Cout + n0 + t) * 2;
+      dst[0] = u1;
+      dst[1] = u2;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ wgrad
+struct WgradArgs {
+  const float* x; int S, Px, ld_x, coff_x;
+  const float* g; int Pg, ld_g, coff_g;
+  int M;
+  int k, rate, pad, Cin, Cout;
+  float* slab;               // [nsplit][k*k*Cin][Cout]
+  int chunks_per_split;      // 32-pixel chunks per split
+  int ntr, nto;
+  float rcpS, rcpSS;
+};
+
+template <int TR, int TO>
+__global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1)) void wgrad_kernel(const WgradArgs a) {
+  constexpr int WR = TR >= 64 ? 2 : 1, WC = TO >= 64 ? 2 : 1;
+  constexpr int NT = 64 * WR * WC;
+  constexpr int WTR = TR / WR, WTO = TO / WC;
+  constexpr int TMr = WTR / 32, TNo = WTO / 32;
+  constexpr int BP = 32;                      // pixels per K-step
+  constexpr int LDX = TR + 4, LDG = TO + 4;
+  constexpr int XQ = TR / 4, GQ = TO / 4;     // float4 per pixel row
+  constexpr int NX = BP * XQ / NT, NG = BP * GQ / NT;
+  constexpr int XPS = NT / XQ, GPS = NT / GQ; // pixel stride between a thread's successive loads
+
+  __shared__ __attribute__((aligned(16))) float lds[BP * LDX + BP * LDG];
+  float* Xs = lds;
+  float* Gs = lds + BP * LDX;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int wr = wave / WC, wc = wave % WC;
+
+  const int ntile = a.ntr * a.nto;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = id / ntile;
+  const int tile = id % ntile;
+  const int R0 = (tile / a.nto) * TR;         // first row of the [k*k*Cin] dimension (a tile never straddles a tap)
+  const int o0 = (tile % a.nto) * TO;
+  const int tap = R0 / a.Cin, c0 = R0 % a.Cin;
+  const int u = tap / a.k, v = tap % a.k;
+  const int Sxp = a.S + 2 * a.Px;
+  // constant part of this thread's X source: tap shift, slice, channel column
+  const uint32_t xconst = (uint32_t)((u * a.rate * Sxp + v * a.rate) * a.ld_x + a.coff_x + c0 + (t % XQ) * 4);
+  const uint32_t gconst = (uint32_t)(a.coff_g + o0 + (t % GQ) * 4);
+  const int xpix = t / XQ, gpix = t / GQ;
+
+  f32x16 acc[TMr][TNo];
+#pragma unroll
+  for (int mi = 0; mi < TMr; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TNo; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int nchunks_total = (a.M + BP - 1) / BP;
+  const int cbeg = split * a.chunks_per_split;
+  int cend = cbeg + a.chunks_per_split;
+  cend = cend < nchunks_total ? cend : nchunks_total;
+
+  f32x4 rx[NX], rg[NG];
+  auto gload = [&](int chunk) {
+    const int pb = chunk * BP;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      int p = pb + xpix + XPS * i;
+      p = p < a.M ? p : a.M - 1;               // clamped rows meet a zero G row
+      const uint32_t off = padded_pixel_off(p, a.S, a.Px, a.ld_x, a.rcpS, a.rcpSS, -a.pad, -a.pad);
+      rx[i] = *reinterpret_cast<const f32x4*>(a.x + off + xconst);
+    }
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const int p = pb + gpix + GPS * i;
+      if (p < a.M) {
+        const uint32_t off = padded_pixel_off(p, a.S, a.Pg, a.ld_g, a.rcpS, a.rcpSS, 0, 0);
+        rg[i] = *reinterpret_cast<const f32x4*>(a.g + off + gconst);
+      } else {
+        rg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) *reinterpret_cast<f32x4*>(&Xs[(xpix + XPS * i) * LDX + (t % XQ) * 4]) = rx[i];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) *reinterpret_cast<f32x4*>(&Gs[(gpix + GPS * i) * LDG + (t % GQ) * 4]) = rg[i];
+  };
+
+  if (cbeg < cend) {
+    gload(cbeg);
+    lstore();
+    __syncthreads();
+    const int xr = wr * WTR + li, gc = wc * WTO + li;
+    for (int ch = cbeg; ch < cend; ++ch) {
+      if (ch + 1 < cend) gload(ch + 1);
+#pragma unroll
+      for (int s = 0; s < BP / 2; ++s) {
+        float af[TMr], bf[TNo];
+#pragma unroll
+        for (int mi = 0; mi < TMr; ++mi) af[mi] = Xs[(2 * s + h) * LDX + xr + mi * 32];
+#pragma unroll
+        for (int ni = 0; ni < TNo; ++ni) bf[ni] = Gs[(2 * s + h) * LDG + gc + ni * 32];
+#pragma unroll
+        for (int mi = 0; mi < TMr; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TNo; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+      }
+      __syncthreads();
+      if (ch + 1 < cend) { lstore(); __syncthreads(); }
+    }
+  }
+  const size_t rows_total = (size_t)a.k * a.k * a.Cin;
+  float* dst = a.slab + ((size_t)split * rows_total + R0) * a.Cout + o0;
+#pragma unroll
+  for (int mi = 0; mi < TMr; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TNo; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wr * WTR + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int col = wc * WTO + ni * 32 + li;
+        dst[(size_t)row * a.Cout + col] = acc[mi][ni][r];
+      }
+}
+
+// grad[tap][c][o] = sum over splits (fixed order) of slab[split][tap][c (of cin_pad)][o], c < cin_real
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, int nsplit, int taps,
+                                    int cin_pad, int cin_real, int cout) {
+  const int n = taps * cin_real * cout;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int o = i % cout;
+    const int rc = i / cout;
+    const int c = rc % cin_real, tap = rc / cin_real;
+    const size_t src = ((size_t)tap * cin_pad + c) * cout + o;
+    const size_t stride = (size_t)taps * cin_pad * cout;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slab[k * stride + src];
+    grad[i] = s;
+  }
+}
+
+// Wt[k-1-u][k-1-v][o][c] = W[u][v][c][o]      (filter for the input-gradient pass)
+__global__ void flip_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int k, int cin, int cout) {
+  const int n = k * k * cin * cout;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int c = i % cin;
+    int rest = i / cin;
+    const int o = rest % cout;
+    rest /= cout;
+    const int v = rest % k, u = rest / k;
+    wt[i] = w[(((k - 1 - u) * k + (k - 1 - v)) * cin + c) * cout + o];
+  }
+}
+
+// Wp[tap][c < cin_pad][o] = c < cin ? W[tap][c][o] : 0
+__global__ void pad_cin_kernel(const float* __restrict__ w, float* __restrict__ wp, int taps, int cin, int cin_pad, int cout) {
+  const int n = taps * cin_pad * cout;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int o = i % cout;
+    const int rc = i / cout;
+    const int c = rc % cin_pad, tap = rc / cin_pad;
+    wp[i] = c < cin ? w[((size_t)tap * cin + c) * cout + o] : 0.f;
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_conv(const ConvArgs& a, hipStream_t st) {
+  const int mt = (a.M + BM - 1) / BM, nt = a.Cout / BN;
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(mt * nt), dim3(256), 0, st, a);
+  return DRS_LAUNCH_CHECK();
+}
+
+template <int TR, int TO>
+int launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t st) {
+  constexpr int NT = 64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1);
+  hipLaunchKernelGGL((wgrad_kernel<TR, TO>), dim3(nsplit * a.ntr * a.nto), dim3(NT), 0, st, a);
+  return DRS_LAUNCH_CHECK();
+}
+
+int pick_tile(int c) { return c % 128 == 0 ? 128 : (c % 64 == 0 ? 64 : 32); }
+
+}  // namespace
+
+extern "C" {
+
+// M-tile height the forward/dgrad kernel uses for this Cout (= rows per BN-statistics slab row)
+int drs_conv_mtile(int cout) { return pick_tile(cout) == 128 ? 128 : 256; }
+
+int drs_conv_forward(const float* in, int B, int S, int P, int ld_in, int coff_in, const float* w, const float* bias,
+                     int k, int rate, int pad_before, int cin, int cout, float* out, int ld_out, int coff_out,
+                     int accumulate, float* stats_partial, void* stream) {
+  if (!in || !w || !out || cin % 32 || cout % 32 || k < 1 || rate < 1 || P < pad_before) return DRS_ERR_ARG;
+  if (P < (k - 1) * rate - pad_before) return DRS_ERR_ARG;          // halo must cover pad_after too
+  const long long M = (long long)B * S * S;
+  if (M <= 0 || M >= (1 << 24)) return DRS_ERR_ARG;
+  ConvArgs a;
+  a.in = in; a.S = S; a.P = P; a.ld_in = ld_in; a.coff_in = coff_in; a.M = (int)M;
+  a.w = w; a.bias = bias; a.out = out; a.ld_out = ld_out; a.coff_out = coff_out; a.stats = stats_partial;
+  a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout; a.accumulate = accumulate;
+  a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
+  hipStream_t st = (hipStream_t)stream;
+  switch (pick_tile(cout)) {
+    case 128: return launch_conv<128, 128, 2, 2>(a, st);
+    case 64:  return launch_conv<256, 64, 4, 1>(a, st);
+    default:  return launch_conv<256, 32, 4, 1>(a, st);
+  }
+}
+
+// number of pixel splits (= slab count) drs_conv_wgrad will use; workspace = nsplit * k*k*cin * cout floats
+int drs_conv_wgrad_splits(int B, int S, int k, int cin, int cout) {
+  const long long M = (long long)B * S * S;
+  const int tr = pick_tile(cin), to = pick_tile(cout);
+  const int ntile = (k * k * cin / tr) * (cout / to);
+  const int nchunks = (int)((M + 31) / 32);
+  int want = (1536 + ntile - 1) / ntile;            // ~6 workgroups per CU in flight
+  int maxs = (nchunks + 31) / 32;                   // at least 32 chunks (1024 pixels) per split
+  if (maxs < 1) maxs = 1;
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  const int cps = (nchunks + want - 1) / want;
+  return (nchunks + cps - 1) / cps;
+}
+
+int drs_conv_wgrad(const float* x, int B, int S, int Px, int ld_x, int coff_x, const float* g, int Pg, int ld_g,
+                   int coff_g, int k, int rate, int pad_before, int cin, int cin_real, int cout, float* slab,
+                   float* grad, void* stream) {
+  if (!x || !g || !slab || !grad || cin % 32 || cout % 32 || cin_real > cin) return DRS_ERR_ARG;
+  const long long M = (long long)B * S * S;
+  if (M <= 0 || M >= (1 << 24)) return DRS_ERR_ARG;
+  WgradArgs a;
+  a.x = x; a.S = S; a.Px = Px; a.ld_x = ld_x; a.coff_x = coff_x;
+  a.g = g; a.Pg = Pg; a.ld_g = ld_g; a.coff_g = coff_g; a.M = (int)M;
+  a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout; a.slab = slab;
+  const int tr = pick_tile(cin), to = pick_tile(cout);
+  a.ntr = k * k * cin / tr; a.nto = cout / to;
+  const int nsplit = drs_conv_wgrad_splits(B, S, k, cin, cout);
+  const int nchunks = (int)((M + 31) / 32);
+  a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
+  a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (tr == 128 && to == 128) rc = launch_wgrad<128, 128>(a, nsplit, st);
+  else if (tr == 128 && to == 64) rc = launch_wgrad<128, 64>(a, nsplit, st);
+  else if (tr == 128 && to == 32) rc = launch_wgrad<128, 32>(a, nsplit, st);
+  else if (tr == 64 && to == 128) rc = launch_wgrad<64, 128>(a, nsplit, st);
+  else if (tr == 64 && to == 64) rc = launch_wgrad<64, 64>(a, nsplit, st);
+  else if (tr == 64 && to == 32) rc = launch_wgrad<64, 32>(a, nsplit, st);
+  else if (tr == 32 && to == 128) rc = launch_wgrad<32, 128>(a, nsplit, st);
+  else if (tr == 32 && to == 64) rc = launch_wgrad<32, 64>(a, nsplit, st);
+  else rc = launch_wgrad<32, 32>(a, nsplit, st);
+  if (rc) return rc;
+  const int n = k * k * cin_real * cout;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), dim3(256), 0, st, slab,
+                     grad, nsplit, k * k, cin, cin_real, cout);
+  return DRS_LAUNCH_CHECK();
+}
+
+int drs_filter_flip_transpose(const float* w, float* wt, int k, int cin, int cout, void* stream) {
+  if (!w || !wt) return DRS_ERR_ARG;
+  const int n = k * k * cin * cout;
+  hipLaunchKernelGGL(flip_transpose_kernel, dim3((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), dim3(256), 0,
+                     (hipStream_t)stream, w, wt, k, cin, cout);
+  return DRS_LAUNCH_CHECK();
+}
+
+int drs_filter_pad_cin(const float* w, float* wp, int k, int cin, int cin_pad, int cout, void* stream) {
+  if (!w || !wp || cin_pad < cin) return DRS_ERR_ARG;
+  const int n = k * k * cin_pad * cout;
+  hipLaunchKernelGGL(pad_cin_kernel, dim3((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), dim3(256), 0,
+                     (hipStream_t)stream, w, wp, k * k, cin, cin_pad, cout);
+  return DRS_LAUNCH_CHECK();
+}
+
+}  // extern "C"

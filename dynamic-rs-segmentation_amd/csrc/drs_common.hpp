@@ -1,0 +1,50 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the dilated-CNN patch path.
+// Written for wave64 / MFMA / 160 KiB LDS only; there is no other target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DRS_OK 0
+#define DRS_ERR_ARG 1
+#define DRS_ERR_HIP 2
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// A view of a spatially padded NHWC activation slab [B][S+2P][S+2P][ld]; the slice starts at channel `coff`.
+// `base` addresses the padded element (b=0, y=-P, x=-P, ch=0).
+struct ActView {
+  float* base;
+  int S;     // patch side (interior)
+  int P;     // halo width (zeros)
+  int ld;    // floats per pixel
+  int coff;  // first channel of the slice
+};
+
+// q = n / d, r = n % d for 0 <= n < 2^24 (exact in f32), d >= 1; rcp = 1.0f/d.
+__device__ __forceinline__ void divmod24(int n, int d, float rcp, int& q, int& r) {
+  q = (int)((float)n * rcp);
+  r = n - q * d;
+  if (r < 0) { q -= 1; r += d; }
+  else if (r >= d) { q += 1; r -= d; }
+}
+
+// flat interior pixel p = (b*S + y)*S + x  ->  element offset of padded pixel (b, y+dy, x+dx), channel 0 of the buffer
+__device__ __forceinline__ uint32_t padded_pixel_off(int p, int S, int P, int ld, float rcpS, float rcpSS, int dy, int dx) {
+  int b, rem, y, x;
+  divmod24(p, S * S, rcpSS, b, rem);
+  divmod24(rem, S, rcpS, y, x);
+  const int Sp = S + 2 * P;
+  return (uint32_t)(((b * Sp + y + P + dy) * Sp + (x + P + dx))) * (uint32_t)ld;
+}
+
+// Bijective XCD-aware remap of a 1-D grid: blocks b and b+8 share an XCD (round-robin dispatch), so give every
+// XCD one contiguous chunk of the logical tile order (neighbouring tiles then share that XCD's 4 MiB L2).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+  const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + (bid >> 3);
+}
+
+static inline int drs_check(hipError_t e) { return e == hipSuccess ? DRS_OK : DRS_ERR_HIP; }
+#define DRS_LAUNCH_CHECK() drs_check(hipGetLastError())

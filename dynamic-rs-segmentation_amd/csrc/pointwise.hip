@@ -1,0 +1,574 @@
+// HBM-bound kernels of the dilated-CNN patch path on gfx950: batch-norm statistics and normalisation fused with the
+// (leaky) ReLU and the 3x3/stride-1 max-pool (forward and backward), the 1x1 classifier fused with the per-pixel
+// softmax cross-entropy, arg-max, confusion matrix and their gradients, and the momentum update.
+//
+// Reference call sites (/root/reference/isprs_dilated_random.py): _batch_norm :655-663, activation :717-721 and
+// leaky_relu :620-621, _max_pool :745-746, classifier :1024-1031, loss_def :1089-1099 (masked form:
+// contest_dilated_random.py:881-901), MomentumOptimizer :1685-1687, tf.argmax :1690, calc_accuracy_by_crop :510-531.
+//
+// All cross-workgroup reductions go through per-workgroup slabs that are summed in a fixed order (no float atomics),
+// so a step is bitwise reproducible.  Everything is channels-last; a thread owns 4 consecutive channels (16-B
+// accesses), consecutive lanes own consecutive channel quads, so every wave access is a run of full cache lines.
+#include "drs_common.hpp"
+
+namespace {
+
+constexpr float BN_EPS = 0.001f;
+
+__device__ __forceinline__ float act(float x, float alpha) { return fmaxf(alpha * x, x); }   // alpha = 0 -> ReLU
+
+// ------------------------------------------------------------------------------------------------ BN statistics
+// partial[row][c][2] (fp32, one row per conv M tile / per reduce workgroup) -> sums[c][2] in fp64, fixed order
+__global__ void stats_reduce_kernel(const float* __restrict__ partial, int nrows, int C, double* __restrict__ sums) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < nrows; ++r) {
+    const float2 v = *reinterpret_cast<const float2*>(partial + ((size_t)r * C + c) * 2);
+    s1 += (double)v.x;
+    s2 += (double)v.y;
+  }
+  sums[2 * c] = s1;
+  sums[2 * c + 1] = s2;
+}
+
+// sums (global over the batch, all ranks) -> mean, rstd; moving averages updated as
+// moving -= (moving - value) * (1 - decay)  (tf assign_moving_average); the moving variance takes the
+// Bessel-corrected batch variance (TF fused batch norm), the normalisation the biased one.
+__global__ void bn_finish_kernel(const double* __restrict__ sums, double count, int C, float* __restrict__ mean_rstd,
+                                 float* __restrict__ moving_mean, float* __restrict__ moving_var, float one_minus_decay,
+                                 int bessel) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double m = sums[2 * c] / count;
+  double var = sums[2 * c + 1] / count - m * m;
+  if (var < 0.0) var = 0.0;
+  const float mf = (float)m, vf = (float)var;
+  mean_rstd[2 * c] = mf;
+  mean_rstd[2 * c + 1] = 1.0f / sqrtf(vf + BN_EPS);
+  if (moving_mean) {
+    const float vu = bessel && count > 1.0 ? (float)(var * (count / (count - 1.0))) : vf;
+    moving_mean[c] = moving_mean[c] - (moving_mean[c] - mf) * one_minus_decay;
+    moving_var[c] = moving_var[c] - (moving_var[c] - vu) * one_minus_decay;
+  }
+}
+
+// eval mode: (mean, rstd) from the moving statistics
+__global__ void bn_eval_coeffs_kernel(const float* __restrict__ moving_mean, const float* __restrict__ moving_var, int C,
+                                      float* __restrict__ mean_rstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean_rstd[2 * c] = moving_mean[c];
+  mean_rstd[2 * c + 1] = 1.0f / sqrtf(moving_var[c] + BN_EPS);
+}
+
+// ------------------------------------------------------------------------------------------------ BN + act + pool, forward
+// z [B*S*S][C] (raw conv output) -> out view (zero halo written here), optional arg-max code per element.
+// grid.y = padded rows (b, yy), grid.x * block covers (xx, channel quad) of one padded row.
+template <bool POOL>
+__global__ void bn_act_pool_fwd_kernel(const float* __restrict__ z, int B, int S, int C, const float* __restrict__ mean_rstd,
+                                       float alpha, ActView out, unsigned char* __restrict__ idx) {
+  const int CQ = C >> 2;
+  const int Sp = S + 2 * out.P;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= Sp * CQ) return;
+  const int xx = e / CQ, cq = e - xx * CQ;
+  const int b = blockIdx.y / Sp, yy = blockIdx.y - b * Sp;
+  float* dst = out.base + ((size_t)(b * Sp + yy) * Sp + xx) * out.ld + out.coff + cq * 4;
+  const int y = yy - out.P, x = xx - out.P;
+  if (y < 0 || y >= S || x < 0 || x >= S) {
+    *reinterpret_cast<f32x4*>(dst) = f32x4{0.f, 0.f, 0.f, 0.f};
+    return;
+  }
+  const f32x4 mr0 = *reinterpret_cast<const f32x4*>(mean_rstd + cq * 8);        // (m0, r0, m1, r1)
+  const f32x4 mr1 = *reinterpret_cast<const f32x4*>(mean_rstd + cq * 8 + 4);    // (m2, r2, m3, r3)
+  const float mu[4] = {mr0[0], mr0[2], mr1[0], mr1[2]};
+  const float rs[4] = {mr0[1], mr0[3], mr1[1], mr1[3]};
+  const size_t pix = ((size_t)b * S + y) * S + x;
+  f32x4 best;
+  unsigned code[4] = {4u, 4u, 4u, 4u};
+  if (!POOL) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(z + pix * C + cq * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) best[j] = act((v[j] - mu[j]) * rs[j], alpha);
+  } else {
+    bool first = true;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int ny = y + dy, nx = x + dx;
+        if (ny < 0 || ny >= S || nx < 0 || nx >= S) continue;       // SAME padding never wins
+        const f32x4 v = *reinterpret_cast<const f32x4*>(z + (((size_t)b * S + ny) * S + nx) * C + cq * 4);
+        const unsigned cd = (unsigned)((dy + 1) * 3 + (dx + 1));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = act((v[j] - mu[j]) * rs[j], alpha);
+          if (first || a > best[j]) { best[j] = a; code[j] = cd; }   // first maximum in scan order wins
+        }
+        first = false;
+      }
+    }
+  }
+  *reinterpret_cast<f32x4*>(dst) = best;
+  if (POOL && idx) {
+    const unsigned packed = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
+    *reinterpret_cast<unsigned*>(idx + pix * C + cq * 4) = packed;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ BN + act + pool, backward
+// pass A: route the incoming gradient back through the pool (gather form over the saved arg-max codes) and the
+// activation; write g_xhat and per-workgroup partial sums of (g_xhat, g_xhat * xhat) per channel.
+// block = (C/4) x PT threads; a workgroup walks `rows_per_block` pixels.
+template <bool POOL>
+__global__ void bn_bwd_reduce_kernel(const float* __restrict__ ga, int ld_ga, int coff_ga, const float* __restrict__ z,
+                                     const unsigned char* __restrict__ idx, int B, int S, int C,
+                                     const float* __restrict__ mean_rstd, float alpha, float* __restrict__ gxh,
+                                     float* __restrict__ partial, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [PT][C][2]
+  const int CQ = C >> 2;
+  const int cq = threadIdx.x % CQ, tp = threadIdx.x / CQ, PT = blockDim.x / CQ;
+  const int M = B * S * S;
+  const f32x4 mr0 = *reinterpret_cast<const f32x4*>(mean_rstd + cq * 8);
+  const f32x4 mr1 = *reinterpret_cast<const f32x4*>(mean_rstd + cq * 8 + 4);
+  const float mu[4] = {mr0[0], mr0[2], mr1[0], mr1[2]};
+  const float rs[4] = {mr0[1], mr0[3], mr1[1], mr1[3]};
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  const int p0 = blockIdx.x * rows_per_block;
+  int pend = p0 + rows_per_block;
+  pend = pend < M ? pend : M;
+  const float rcpS = 1.0f / (float)S, rcpSS = 1.0f / (float)(S * S);
+  for (int p = p0 + tp; p < pend; p += PT) {
+    f32x4 g;
+    if (!POOL) {
+      g = *reinterpret_cast<const f32x4*>(ga + (size_t)p * ld_ga + coff_ga + cq * 4);
+    } else {
+      int b, rem, y, x;
+      divmod24(p, S * S, rcpSS, b, rem);
+      divmod24(rem, S, rcpS, y, x);
+      g = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy) {
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int qy = y + dy, qx = x + dx;
+          if (qy < 0 || qy >= S || qx < 0 || qx >= S) continue;
+          const size_t q = ((size_t)b * S + qy) * S + qx;
+          const unsigned packed = *reinterpret_cast<const unsigned*>(idx + q * C + cq * 4);
+          const unsigned want = (unsigned)((1 - dy) * 3 + (1 - dx));   // where p sits in q's window
+          const f32x4 gq = *reinterpret_cast<const f32x4*>(ga + q * ld_ga + coff_ga + cq * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (((packed >> (8 * j)) & 0xffu) == want) g[j] += gq[j];
+        }
+      }
+    }
+    const f32x4 zv = *reinterpret_cast<const f32x4*>(z + (size_t)p * C + cq * 4);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (zv[j] - mu[j]) * rs[j];
+      const float gx = xh > 0.f ? g[j] : g[j] * alpha;
+      o[j] = gx;
+      s1[j] += gx;
+      s2[j] += gx * xh;
+    }
+    *reinterpret_cast<f32x4*>(gxh + (size_t)p * C + cq * 4) = o;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    red[((size_t)tp * C + cq * 4 + j) * 2] = s1[j];
+    red[((size_t)tp * C + cq * 4 + j) * 2 + 1] = s2[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float u1 = 0.f, u2 = 0.f;
+    for (int r = 0; r < PT; ++r) { u1 += red[((size_t)r * C + c) * 2]; u2 += red[((size_t)r * C + c) * 2 + 1]; }
+    partial[((size_t)blockIdx.x * C + c) * 2] = u1;
+    partial[((size_t)blockIdx.x * C + c) * 2 + 1] = u2;
+  }
+}
+
+// pass B: g_z = rstd * (g_xhat - mean(g_xhat) - xhat * mean(g_xhat * xhat)), written into a zero-haloed view
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ gxh, const float* __restrict__ z, int B, int S, int C,
+                                    const float* __restrict__ mean_rstd, const double* __restrict__ sums, double count,
+                                    ActView out) {
+  const int CQ = C >> 2;
+  const int Sp = S + 2 * out.P;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= Sp * CQ) return;
+  const int xx = e / CQ, cq = e - xx * CQ;
+  const int b = blockIdx.y / Sp, yy = blockIdx.y - b * Sp;
+  float* dst = out.base + ((size_t)(b * Sp + yy) * Sp + xx) * out.ld + out.coff + cq * 4;
+  const int y = yy - out.P, x = xx - out.P;
+  if (y < 0 || y >= S || x < 0 || x >= S) {
+    *reinterpret_cast<f32x4*>(dst) = f32x4{0.f, 0.f, 0.f, 0.f};
+    return;
+  }
+  const size_t pix = ((size_t)b * S + y) * S + x;
+  const f32x4 gv = *reinterpret_cast<const f32x4*>(gxh + pix * C + cq * 4);
+  const f32x4 zv = *reinterpret_cast<const f32x4*>(z + pix * C + cq * 4);
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = cq * 4 + j;
+    const float mu = mean_rstd[2 * c], rs = mean_rstd[2 * c + 1];
+    const float m1 = (float)(sums[2 * c] / count), m2 = (float)(sums[2 * c + 1] / count);
+    const float xh = (zv[j] - mu) * rs;
+    o[j] = rs * (gv[j] - m1 - xh * m2);
+  }
+  *reinterpret_cast<f32x4*>(dst) = o;
+}
+
+// ------------------------------------------------------------------------------------------------ classifier + loss
+// One wave walks pixels; lane l owns channels l, l+64, ... of the feature vector.  K <= 8 classes.
+struct ClsArgs {
+  ActView feat; int C, K, M;
+  const float* w;            // [C][K]
+  const float* bias;         // [K]
+  const unsigned char* labels;   // [M] or null (inference)
+  const unsigned char* loss_mask;  // [M] or null: pixels that enter the loss (contest void mask)
+  const unsigned char* acc_mask;   // [M] or null: pixels that enter the confusion matrix (augmentation validity)
+  float inv_n;               // 1 / (number of pixels the loss averages over, all ranks)
+  float* logits;             // [M][K] or null
+  unsigned char* pred;       // [M] or null
+  float* gfeat; int ld_g, coff_g;   // gradient wrt features [M][ld_g] or null
+  float* dw_partial;         // [nblk][C][K] or null
+  float* db_partial;         // [nblk][K]
+  double* loss_partial;      // [nblk]
+  unsigned int* conf;        // [K][K] counts (integer atomics) or null
+  int rows_per_block;
+  float rcpS, rcpSS;
+};
+
+template <int CI>   // CI = C / 64
+__global__ __launch_bounds__(256) void classifier_loss_kernel(const ClsArgs a) {
+  constexpr int KM = 8;
+  __shared__ float red[4][CI * 64 * KM];
+  __shared__ float redb[4][KM];
+  __shared__ double redl[4];
+  __shared__ unsigned int confs[KM * KM];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int K = a.K;
+  if (threadIdx.x < KM * KM) confs[threadIdx.x] = 0u;
+  float wr[CI][KM], dw[CI][KM];
+#pragma unroll
+  for (int i = 0; i < CI; ++i)
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      wr[i][k] = k < K ? a.w[(size_t)(lane + 64 * i) * K + k] : 0.f;
+      dw[i][k] = 0.f;
+    }
+  float bk[KM], db[KM];
+#pragma unroll
+  for (int k = 0; k < KM; ++k) { bk[k] = k < K ? a.bias[k] : 0.f; db[k] = 0.f; }
+  double lsum = 0.0;
+  __syncthreads();
+  const int p0 = blockIdx.x * a.rows_per_block;
+  int pend = p0 + a.rows_per_block;
+  pend = pend < a.M ? pend : a.M;
+  for (int p = p0 + wave; p < pend; p += 4) {
+    const uint32_t off = padded_pixel_off(p, a.feat.S, a.feat.P, a.feat.ld, a.rcpS, a.rcpSS, 0, 0) + a.feat.coff;
+    float f[CI];
+#pragma unroll
+    for (int i = 0; i < CI; ++i) f[i] = a.feat.base[off + lane + 64 * i];
+    float lg[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < CI; ++i) s += f[i] * wr[i][k];
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+      lg[k] = s + bk[k];
+    }
+    // arg-max (first maximum) and softmax over the K live classes; every lane holds the same values
+    int am = 0;
+    float mx = lg[0];
+#pragma unroll
+    for (int k = 1; k < KM; ++k)
+      if (k < K && lg[k] > mx) { mx = lg[k]; am = k; }
+    if (lane == 0) {
+      if (a.logits)
+        for (int k = 0; k < K; ++k) a.logits[(size_t)p * K + k] = lg[k];
+      if (a.pred) a.pred[p] = (unsigned char)am;
+    }
+    if (!a.labels) continue;
+    const int y = a.labels[p];
+    if (lane == 0 && a.conf && (!a.acc_mask || a.acc_mask[p]) && y < K) atomicAdd(&confs[y * KM + am], 1u);
+    const bool in_loss = !a.loss_mask || a.loss_mask[p];
+    float ex[KM], se = 0.f;
+#pragma unroll
+    for (int k = 0; k < KM; ++k) { ex[k] = k < K ? expf(lg[k] - mx) : 0.f; se += ex[k]; }
+    const float inv = 1.0f / se;
+    float ly = 0.f;
+    float dl[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      const float pk = ex[k] * inv;
+      dl[k] = in_loss && k < K ? (pk - (k == y ? 1.f : 0.f)) * a.inv_n : 0.f;
+      if (k == y) ly = lg[k];
+    }
+    if (in_loss) lsum += (double)(logf(se) + mx - ly);
+    if (a.gfeat) {
+#pragma unroll
+      for (int i = 0; i < CI; ++i) {
+        float g = 0.f;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) g += dl[k] * wr[i][k];
+        a.gfeat[(size_t)p * a.ld_g + a.coff_g + lane + 64 * i] = g;
+#pragma unroll
+        for (int k = 0; k < KM; ++k) dw[i][k] += f[i] * dl[k];
+      }
+#pragma unroll
+      for (int k = 0; k < KM; ++k) db[k] += dl[k];
+    }
+  }
+  if (!a.labels) return;
+  // workgroup reduction in wave order, then one slab row per workgroup
+#pragma unroll
+  for (int i = 0; i < CI; ++i)
+#pragma unroll
+    for (int k = 0; k < KM; ++k) red[wave][(i * 64 + lane) * KM + k] = dw[i][k];
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < KM; ++k) redb[wave][k] = db[k];
+    redl[wave] = lsum;
+  }
+  __syncthreads();
+  if (a.dw_partial) {
+    for (int e = threadIdx.x; e < a.C * K; e += 256) {
+      const int c = e / K, k = e - c * K;
+      const float s = ((red[0][c * KM + k] + red[1][c * KM + k]) + red[2][c * KM + k]) + red[3][c * KM + k];
+      a.dw_partial[(size_t)blockIdx.x * a.C * K + e] = s;
+    }
+    if (threadIdx.x < K)
+      a.db_partial[(size_t)blockIdx.x * K + threadIdx.x] =
+          ((redb[0][threadIdx.x] + redb[1][threadIdx.x]) + redb[2][threadIdx.x]) + redb[3][threadIdx.x];
+  }
+  if (threadIdx.x == 0) a.loss_partial[blockIdx.x] = ((redl[0] + redl[1]) + redl[2]) + redl[3];
+  if (a.conf && threadIdx.x < K * K) {
+    const int r = threadIdx.x / K, c = threadIdx.x - r * K;
+    const unsigned v = confs[r * KM + c];
+    if (v) atomicAdd(&a.conf[threadIdx.x], v);
+  }
+}
+
+// out[j] = sum_i in[i][j], fixed order
+__global__ void rows_reduce_f32_kernel(const float* __restrict__ in, int nrows, int ncols, float* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= ncols) return;
+  float s = 0.f;
+  for (int i = 0; i < nrows; ++i) s += in[(size_t)i * ncols + j];
+  out[j] = s;
+}
+__global__ void sum_f64_kernel(const double* __restrict__ in, int n, double* __restrict__ out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += in[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+// 0.5 * sum(w^2) over [0, n): per-workgroup partials in fp64 (tf.nn.l2_loss, isprs:648)
+__global__ void l2_partial_kernel(const float* __restrict__ w, size_t n, double* __restrict__ partial) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += (double)w[i] * (double)w[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if (threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = 0.5 * sh[0];
+}
+
+// ApplyMomentum (use_nesterov = False): g = grad*gscale (+ wd*w for the first n_decay entries: the kernels);
+// accum = momentum*accum + g; w -= lr*accum.
+__global__ void momentum_kernel(float* __restrict__ w, const float* __restrict__ grad, float* __restrict__ accum, size_t n,
+                                size_t n_decay, float lr, float wd, float momentum, float gscale) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float g = grad[i] * gscale;
+    const float wv = w[i];
+    if (i < n_decay) g += wd * wv;
+    const float a = momentum * accum[i] + g;
+    accum[i] = a;
+    w[i] = wv - lr * a;
+  }
+}
+
+// K x K confusion matrix of (label, prediction) under an optional mask; integer atomics (order-independent)
+__global__ void confusion_kernel(const unsigned char* __restrict__ labels, const unsigned char* __restrict__ pred,
+                                 const unsigned char* __restrict__ mask, size_t n, int K, int ignore_label,
+                                 unsigned int* __restrict__ conf) {
+  __shared__ unsigned int sh[64];
+  if (threadIdx.x < 64) sh[threadIdx.x] = 0u;
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    if (mask && !mask[i]) continue;
+    const int y = labels[i], p = pred[i];
+    if (y == ignore_label || y >= K || p >= K) continue;
+    atomicAdd(&sh[y * 8 + p], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < K * K) {
+    const int r = threadIdx.x / K, c = threadIdx.x - r * K;
+    const unsigned v = sh[r * 8 + c];
+    if (v) atomicAdd(&conf[threadIdx.x], v);
+  }
+}
+
+inline ActView mkview(float* base, int S, int P, int ld, int coff) {
+  ActView v; v.base = base; v.S = S; v.P = P; v.ld = ld; v.coff = coff; return v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int drs_stats_reduce(const float* partial, int nrows, int C, double* sums, void* stream) {
+  if (!partial || !sums || nrows < 1) return DRS_ERR_ARG;
+  hipLaunchKernelGGL(stats_reduce_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, nrows, C, sums);
+  return DRS_LAUNCH_CHECK();
+}
+
+int drs_bn_finish(const double* sums, double count, int C, float* mean_rstd, float* moving_mean, float* moving_var,
+                  float decay, int bessel, void* stream) {
+  if (!sums || !mean_rstd || count < 1.0) return DRS_ERR_ARG;
+  hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, count, C, mean_rstd,
+                     moving_mean, moving_var, (float)(1.0 - (double)decay), bessel);
+  return DRS_LAUNCH_CHECK();
+}
+
+int drs_bn_eval_coeffs(const float* moving_mean, const float* moving_var, int C, float* mean_rstd, void* stream) {
+  if (!moving_mean || !moving_var || !mean_rstd) return DRS_ERR_ARG;
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, moving_mean, moving_var, C,
+                     mean_rstd);
+  return DRS_LAUNCH_CHECK();
+}
+
+int drs_bn_act_pool_forward(const float* z, int B, int S, int C, const float* mean_rstd, float alpha, int pool,
+                            float* out, int P_out, int ld_out, int coff_out, unsigned char* argmax, void* stream) {
+  if (!z || !mean_rstd || !out || C % 4) return DRS_ERR_ARG;
+  const int Sp = S + 2 * P_out;
+  if ((long long)B * Sp > 65535) return DRS_ERR_ARG;
+  const int per_row = Sp * (C / 4);
+  dim3 grid((per_row + 255) / 256, B * Sp);
+  ActView v = mkview(out, S, P_out, ld_out, coff_out);
+  if (pool)
+    hipLaunchKernelGGL(bn_act_pool_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, z, B, S, C, mean_rstd, alpha, v, argmax);
+  else
+    hipLaunchKernelGGL(bn_act_pool_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, z, B, S, C, mean_rstd, alpha, v, argmax);
+  return DRS_LAUNCH_CHECK();
+}
+
+// rows of the slab drs_bn_backward_reduce writes (partial must hold rows * C * 2 floats)
+int drs_bn_backward_rows(int B, int S) { return (B * S * S + 63) / 64; }
+
+int drs_bn_backward_reduce(const float* ga, int ld_ga, int coff_ga, const float* z, const unsigned char* argmax, int B, int S,
+                           int C, const float* mean_rstd, float alpha, int pool, float* gxhat, float* partial, void* stream) {
+  if (!ga || !z || !mean_rstd || !gxhat || !partial || C % 4 || (pool && !argmax)) return DRS_ERR_ARG;
+  const int CQ = C / 4;
+  if (CQ > 256) return DRS_ERR_ARG;
+  const int PT = 256 / CQ;
+  const int nblk = drs_bn_backward_rows(B, S);
+  const size_t shm = (size_t)PT * C * 2 * sizeof(float);
+  if (pool)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(CQ * PT), shm, (hipStream_t)stream, ga, ld_ga, coff_ga, z,
+                       argmax, B, S, C, mean_rstd, alpha, gxhat, partial, 64);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(CQ * PT), shm, (hipStream_t)stream, ga, ld_ga, coff_ga, z,
+                       argmax, B, S, C, mean_rstd, alpha, gxhat, partial, 64);
+  return DRS_LAUNCH_CHECK();
+}
+
+int drs_bn_backward_apply(const float* gxhat, const float* z, int B, int S, int C, const float* mean_rstd, const double* sums,
+                          double count, float* gz, int P_out, int ld_out, int coff_out, void* stream) {
+  if (!gxhat || !z || !mean_rstd || !sums || !gz || C % 4) return DRS_ERR_ARG;
+  const int Sp = S + 2 * P_out;
+  if ((long long)B * Sp > 65535) return DRS_ERR_ARG;
+  const int per_row = Sp * (C / 4);
+  dim3 grid((per_row + 255) / 256, B * Sp);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, gxhat, z, B, S, C, mean_rstd, sums, count,
+                     mkview(gz, S, P_out, ld_out, coff_out));
+  return DRS_LAUNCH_CHECK();
+}
+
+int drs_classifier_rows(int B, int S) { return (B * S * S + 255) / 256; }
+
+int drs_classifier_loss(const float* feat, int B, int S, int P, int ld, int coff, int C, int K, const float* w,
+                        const float* bias, const unsigned char* labels, const unsigned char* loss_mask,
+                        const unsigned char* acc_mask, float inv_n, float* logits, unsigned char* pred, float* gfeat,
+                        int ld_g, int coff_g, float* dw_partial, float* db_partial, double* loss_partial,
+                        unsigned int* conf, void* stream) {
+  if (!feat || !w || !bias || K < 1 || K > 8 || C % 64 || C / 64 > 7) return DRS_ERR_ARG;
+  const long long M = (long long)B * S * S;
+  if (M <= 0 || M >= (1 << 24)) return DRS_ERR_ARG;
+  if (labels && !loss_partial) return DRS_ERR_ARG;
+  if (gfeat && (!dw_partial || !db_partial || !labels)) return DRS_ERR_ARG;
+  ClsArgs a;
+  a.feat = mkview(const_cast<float*>(feat), S, P, ld, coff); a.C = C; a.K = K; a.M = (int)M; a.w = w; a.bias = bias;
+  a.labels = labels; a.loss_mask = loss_mask; a.acc_mask = acc_mask; a.inv_n = inv_n; a.logits = logits; a.pred = pred;
+  a.gfeat = gfeat; a.ld_g = ld_g; a.coff_g = coff_g; a.dw_partial = dw_partial; a.db_partial = db_partial;
+  a.loss_partial = loss_partial; a.conf = conf; a.rows_per_block = 256;
+  a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
+  const int nblk = drs_classifier_rows(B, S);
+  hipStream_t st = (hipStream_t)stream;
+  switch (C / 64) {
+    case 1: hipLaunchKernelGGL(classifier_loss_kernel<1>, dim3(nblk), dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(classifier_loss_kernel<2>, dim3(nblk), dim3(256), 0, st, a); break;
+    case 3: hipLaunchKernelGGL(classifier_loss_kernel<3>, dim3(nblk), dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(classifier_loss_kernel<4>, dim3(nblk), dim3(256), 0, st, a); break;
+    case 5: hipLaunchKernelGGL(classifier_loss_kernel<5>, dim3(nblk), dim3(256), 0, st, a); break;
+    case 6: hipLaunchKernelGGL(classifier_loss_kernel<6>, dim3(nblk), dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL(classifier_loss_kernel<7>, dim3(nblk), dim3(256), 0, st, a); break;
+  }
+  return DRS_LAUNCH_CHECK();
+}
+
+int drs_rows_reduce_f32(const float* in, int nrows, int ncols, float* out, void* stream) {
+  if (!in || !out) return DRS_ERR_ARG;
+  hipLaunchKernelGGL(rows_reduce_f32_kernel, dim3((ncols + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, nrows, ncols, out);
+  return DRS_LAUNCH_CHECK();
+}
+
+int drs_sum_f64(const double* in, int n, double* out, void* stream) {
+  if (!in || !out) return DRS_ERR_ARG;
+  hipLaunchKernelGGL(sum_f64_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, in, n, out);
+  return DRS_LAUNCH_CHECK();
+}
+
+// l2 = 0.5 * sum(w[0..n)^2) -> out[0] (fp64); scratch holds 256 doubles
+int drs_l2_loss(const float* w, size_t n, double* scratch, double* out, void* stream) {
+  if (!w || !scratch || !out) return DRS_ERR_ARG;
+  hipLaunchKernelGGL(l2_partial_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, w, n, scratch);
+  hipLaunchKernelGGL(sum_f64_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, 256, out);
+  return DRS_LAUNCH_CHECK();
+}
+
+int drs_momentum_update(float* w, const float* grad, float* accum, size_t n, size_t n_decay, float lr, float weight_decay,
+                        float momentum, float grad_scale, void* stream) {
+  if (!w || !grad || !accum) return DRS_ERR_ARG;
+  const size_t nb = (n + 255) / 256;
+  hipLaunchKernelGGL(momentum_kernel, dim3(nb < 2048 ? (unsigned)nb : 2048u), dim3(256), 0, (hipStream_t)stream, w, grad, accum, n,
+                     n_decay, lr, weight_decay, momentum, grad_scale);
+  return DRS_LAUNCH_CHECK();
+}
+
+int drs_confusion(const unsigned char* labels, const unsigned char* pred, const unsigned char* mask, size_t n, int K,
+                  int ignore_label, unsigned int* conf, void* stream) {
+  if (!labels || !pred || !conf || K < 1 || K > 8) return DRS_ERR_ARG;
+  const size_t nb = (n + 255) / 256;
+  hipLaunchKernelGGL(confusion_kernel, dim3(nb < 1024 ? (unsigned)nb : 1024u), dim3(256), 0, (hipStream_t)stream, labels, pred, mask,
+                     n, K, ignore_label, conf);
+  return DRS_LAUNCH_CHECK();
+}
+
+}  // extern "C"

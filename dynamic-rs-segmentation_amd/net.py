@@ -1,0 +1,384 @@
+"""Device-side net: parameters, workspaces and the forward / backward / update sequence.
+
+Host mirror of what one `sess.run` evaluates in the reference
+(/root/reference/isprs_dilated_random.py): the `_conv_layer` block :700-723 per layer, the classifier
+:1024-1031, `loss_def` :1089-1099, `MomentumOptimizer(...).minimize` :1685-1687 and `tf.argmax` :1690.
+Three call shapes exist in the reference and are kept:
+
+    train  sess.run([optimizer, loss, pred_up], is_training=True)    isprs:1750-1752  -> DilatedNet.train_step
+    infer  sess.run([pred_up, logits],         is_training=False)   isprs:1274-1275  -> DilatedNet.forward
+    val    sess.run(pred_up,                   is_training=False)   isprs:1588       -> DilatedNet.forward
+
+There is no autograd graph: the net is a fixed chain, so the backward pass is an explicit reverse loop.
+PyTorch supplies device memory, the stream and (through `comm`) the collectives; all arithmetic is in
+libdrs_hip.so (include/drs.h).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .nets import Plan
+
+BN_DECAY = 0.999        # tf.contrib.layers.batch_norm default (isprs:658)
+MOMENTUM = 0.9          # isprs:1687
+LR_DECAY_STEPS = 50000  # isprs:1686
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class NoComm(object):
+    """Single-process stand-in for the collective interface (see dist.py)."""
+    world = 1
+    rank = 0
+
+    def all_reduce_sum(self, t):
+        return t
+
+
+class DilatedNet(object):
+    def __init__(self, net_type, channels, num_classes, weight_decay, b_max, s_max, device="cuda:0", seed=42,
+                 comm=None, bessel_moving_var=True, lr_decay_factor=0.5):
+        _lib.load()                       # fail loudly here if the HIP library is absent
+        self.plan = Plan(net_type, channels, num_classes)
+        self.wd = float(weight_decay)
+        self.b_max, self.s_max = int(b_max), int(s_max)
+        self.dev = torch.device(device)
+        self.comm = comm if comm is not None else NoComm()
+        self.bessel = 1 if bessel_moving_var else 0
+        self.lr_decay_factor = lr_decay_factor      # 0.5 isprs:1686; 0.1 coffee:1228, contest:1021
+        self.global_step = 0
+        if self.b_max * self.s_max * self.s_max >= (1 << 24):
+            raise ValueError("B*S*S must stay below 2^24")
+        p = self.plan
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.params = torch.zeros(p.n_params, **f32)
+        self.grads = torch.zeros(p.n_params, **f32)
+        self.mom = torch.zeros(p.n_params, **f32)
+        self.bn = torch.zeros(p.n_bn, **f32)
+        self._init_params(seed)
+        self._alloc()
+
+    # ------------------------------------------------------------------ parameters
+    def _init_params(self, seed):
+        """Xavier-uniform kernels (isprs:702), biases 0.1 (isprs:707), classifier bias 0 (isprs:1028),
+        moving mean 0 / variance 1 (contrib batch_norm initialisers)."""
+        rng = np.random.default_rng(seed)
+        host = np.zeros(self.plan.n_params, dtype=np.float32)
+        for name, (off, shape) in self.plan.offsets.items():
+            n = int(np.prod(shape))
+            if name.endswith("/weights"):
+                k1, k2, ci, co = shape
+                lim = math.sqrt(6.0 / (k1 * k2 * ci + k1 * k2 * co))
+                host[off:off + n] = rng.uniform(-lim, lim, size=n).astype(np.float32)
+            elif name != "conv_classifier/biases":
+                host[off:off + n] = 0.1
+        self.params.copy_(torch.from_numpy(host))
+        bn = np.zeros(self.plan.n_bn, dtype=np.float32)
+        for L in self.plan.layers:
+            o = self.plan.bn_offsets[L.name]
+            bn[o + L.cout:o + 2 * L.cout] = 1.0
+        self.bn.copy_(torch.from_numpy(bn))
+
+    def variable_names(self):
+        names = list(self.plan.offsets)
+        for L in self.plan.layers:
+            names += [L.name + "/moving_mean", L.name + "/moving_variance"]
+        return names
+
+    def _slice(self, flat, name):
+        if name.endswith("/moving_mean") or name.endswith("/moving_variance"):
+            lname = name.rsplit("/", 1)[0]
+            L = [l for l in self.plan.layers if l.name == lname][0]
+            o = self.plan.bn_offsets[lname] + (L.cout if name.endswith("variance") else 0)
+            return self.bn[o:o + L.cout], (L.cout,)
+        off, shape = self.plan.offsets[name]
+        return flat[off:off + int(np.prod(shape))], shape
+
+    def get_variable(self, name, slot=None):
+        """TF-scope-named access (`conv1/weights`, `conv1/moving_mean`, ...); slot='Momentum' reads the
+        optimizer accumulator (what tf.train.Saver would store, isprs:1693-1695)."""
+        flat = self.mom if slot == "Momentum" else self.params
+        t, shape = self._slice(flat, name)
+        return t.detach().cpu().numpy().reshape(shape).copy()
+
+    def set_variable(self, name, value, slot=None):
+        flat = self.mom if slot == "Momentum" else self.params
+        t, shape = self._slice(flat, name)
+        v = np.ascontiguousarray(np.asarray(value, dtype=np.float32).reshape(shape))
+        t.copy_(torch.from_numpy(v).reshape(-1))
+
+    def state_dict(self):
+        d = {n: self.get_variable(n) for n in self.variable_names()}
+        d.update({n + "/Momentum": self.get_variable(n, "Momentum") for n in self.plan.offsets})
+        d["main_global_step"] = np.array(self.global_step, dtype=np.int64)     # isprs:1685
+        return d
+
+    def load_state_dict(self, d):
+        for n in self.variable_names():
+            self.set_variable(n, d[n])
+        for n in self.plan.offsets:
+            if n + "/Momentum" in d:
+                self.set_variable(n, d[n + "/Momentum"], "Momentum")
+        self.global_step = int(d.get("main_global_step", 0))
+
+    # ------------------------------------------------------------------ workspaces
+    def _alloc(self):
+        p, B, S = self.plan, self.b_max, self.s_max
+        M = B * S * S
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        u8 = dict(dtype=torch.uint8, device=self.dev)
+        f64 = dict(dtype=torch.float64, device=self.dev)
+        L0 = p.layers[0]
+        self.x0 = torch.zeros(B * (S + 2 * L0.halo) ** 2 * L0.cin_k, **f32)      # conv1 input slab (crop target)
+        self.xin = [None] * len(p.layers)
+        if p.dense:
+            Pc = p.concat_halo
+            self.concat = torch.zeros(B * (S + 2 * Pc) ** 2 * p.c_last, **f32)
+            self.gconcat = torch.zeros(M * p.c_last, **f32)
+        else:
+            for i, L in enumerate(p.layers):
+                if i > 0:
+                    self.xin[i] = torch.zeros(B * (S + 2 * L.halo) ** 2 * L.cin_k, **f32)
+            self.feat = torch.zeros(M * p.c_last, **f32)
+        self.z = [torch.zeros(M * L.cout, **f32) for L in p.layers]
+        self.idx = [torch.zeros(M * L.cout, **u8) if p.pool else None for L in p.layers]
+        self.mean_rstd = [torch.zeros(L.cout * 2, **f32) for L in p.layers]
+        cmax = max(max(L.cout for L in p.layers), max(L.cin_k for L in p.layers[1:]))
+        hmax = max(L.halo for L in p.layers)
+        self.sums = torch.zeros(cmax * 2, **f64)
+        rows_fwd = max((M + _lib.query("drs_conv_mtile", L.cout) - 1) // _lib.query("drs_conv_mtile", L.cout)
+                       for L in p.layers)
+        rows_bwd = _lib.query("drs_bn_backward_rows", B, S)
+        self.partial = torch.zeros(max(rows_fwd, rows_bwd) * cmax * 2, **f32)
+        self.gA = torch.zeros(M * cmax, **f32)
+        self.gB = torch.zeros(M * cmax, **f32)
+        self.gxh = torch.zeros(M * cmax, **f32)
+        self.gz = torch.zeros(B * (S + 2 * hmax) ** 2 * cmax, **f32)
+        slab = max(_lib.query("drs_conv_wgrad_splits", B, S, L.k, L.cin_k, L.cout) * L.k * L.k * L.cin_k * L.cout
+                   for L in p.layers)
+        self.slab = torch.zeros(slab, **f32)
+        self.w0pad = torch.zeros(L0.k * L0.k * L0.cin_k * L0.cout, **f32)
+        self.wt = [None] + [torch.zeros(L.k * L.k * L.cin * L.cout, **f32) for L in p.layers[1:]]
+        crow = _lib.query("drs_classifier_rows", B, S)
+        self.dw_partial = torch.zeros(crow * p.c_last * p.K, **f32)
+        self.db_partial = torch.zeros(crow * p.K, **f32)
+        self.loss_partial = torch.zeros(crow, **f64)
+        self.scalars = torch.zeros(4, **f64)          # [0] CE sum (this rank), [1] l2, [2..3] spare
+        self.l2_scratch = torch.zeros(256, **f64)
+        self.logits = torch.zeros(M * p.K, **f32)
+        self.pred = torch.zeros(M, **u8)
+        self.conf = torch.zeros(p.K * p.K, dtype=torch.int32, device=self.dev)
+        self.labels = torch.zeros(M, **u8)
+        self.acc_mask = torch.ones(M, **u8)
+        self.loss_mask = torch.ones(M, **u8)
+
+    def workspace_bytes(self):
+        tot = 0
+        for v in vars(self).values():
+            for t in (v if isinstance(v, list) else [v]):
+                if isinstance(t, torch.Tensor):
+                    tot += t.numel() * t.element_size()
+        return tot
+
+    # ------------------------------------------------------------------ views
+    def _stream(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def _in_view(self, i):
+        """(tensor, halo, ld, coff) of the input of conv i."""
+        p = self.plan
+        L = p.layers[i]
+        if i == 0:
+            return self.x0, L.halo, L.cin_k, 0
+        if p.dense:
+            return self.concat, p.concat_halo, p.c_last, 0
+        return self.xin[i], L.halo, L.cin_k, 0
+
+    def _out_view(self, i):
+        """where the activated (pooled) output of conv i goes."""
+        p = self.plan
+        if p.dense:
+            return self.concat, p.concat_halo, p.c_last, p.concat_off[i]
+        if i + 1 < len(p.layers):
+            n = p.layers[i + 1]
+            return self.xin[i + 1], n.halo, n.cin_k, 0
+        return self.feat, 0, p.c_last, 0
+
+    def _feat_view(self):
+        p = self.plan
+        if p.dense:
+            return self.concat, p.concat_halo, p.c_last, 0
+        return self.feat, 0, p.c_last, 0
+
+    def input_slab(self):
+        """(tensor, halo, ld) of the conv1 input slab that drs_crop_normalize fills."""
+        L = self.plan.layers[0]
+        return self.x0, L.halo, L.cin_k
+
+    def _check(self, B, S):
+        if B < 1 or S < 1 or B > self.b_max or S > self.s_max:
+            raise ValueError("batch %d / patch size %d outside the allocated (%d, %d)" % (B, S, self.b_max, self.s_max))
+
+    # ------------------------------------------------------------------ feeding in the reference's sess.run form
+    def feed(self, batch_x, batch_y=None, crop_size=None, mask=None, acc_mask=None):
+        """Take the reference's feed_dict: x float32 [B, s*s*C] (row-major NHWC), y [B, s*s] class ids
+        (isprs:1746-1747, 1751), optional contest `mask` [B, s*s] (contest:1083-1086)."""
+        from .patches import pack_feed
+        return pack_feed(self, batch_x, batch_y, crop_size, mask, acc_mask)
+
+    # ------------------------------------------------------------------ forward
+    def _prepare_weights(self, st):
+        p = self.plan
+        L0 = p.layers[0]
+        off, _ = p.offsets[L0.name + "/weights"]
+        _lib.call("drs_filter_pad_cin", self.params[off:].data_ptr(), _ptr(self.w0pad), L0.k, L0.cin, L0.cin_k, L0.cout, st)
+
+    def _weight_ptr(self, i):
+        if i == 0:
+            return self.w0pad.data_ptr()
+        off, _ = self.plan.offsets[self.plan.layers[i].name + "/weights"]
+        return self.params[off:].data_ptr()
+
+    def _bias_ptr(self, name):
+        off, _ = self.plan.offsets[name + "/biases"]
+        return self.params[off:].data_ptr()
+
+    def _forward_layers(self, B, S, training, count):
+        p, st = self.plan, self._stream()
+        M = B * S * S
+        self._prepare_weights(st)
+        for i, L in enumerate(p.layers):
+            xin, Pin, ldin, cin_off = self._in_view(i)
+            stats = self.partial if training else None
+            _lib.call("drs_conv_forward", _ptr(xin), B, S, Pin, ldin, cin_off, self._weight_ptr(i), self._bias_ptr(L.name),
+                      L.k, L.rate, L.pad_b, L.cin_k, L.cout, _ptr(self.z[i]), L.cout, 0, 0, _ptr(stats), st)
+            bo = p.bn_offsets[L.name]
+            mm, mv = self.bn[bo:bo + L.cout], self.bn[bo + L.cout:bo + 2 * L.cout]
+            if training:
+                mt = _lib.query("drs_conv_mtile", L.cout)
+                _lib.call("drs_stats_reduce", _ptr(self.partial), (M + mt - 1) // mt, L.cout, _ptr(self.sums), st)
+                self.comm.all_reduce_sum(self.sums[:2 * L.cout])           # sync batch norm over the global batch
+                _lib.call("drs_bn_finish", _ptr(self.sums), float(count), L.cout, _ptr(self.mean_rstd[i]), _ptr(mm), _ptr(mv),
+                          BN_DECAY, self.bessel, st)
+            else:
+                _lib.call("drs_bn_eval_coeffs", _ptr(mm), _ptr(mv), L.cout, _ptr(self.mean_rstd[i]), st)
+            out, Pout, ldout, coff = self._out_view(i)
+            _lib.call("drs_bn_act_pool_forward", _ptr(self.z[i]), B, S, L.cout, _ptr(self.mean_rstd[i]), p.alpha,
+                      1 if p.pool else 0, _ptr(out), Pout, ldout, coff, _ptr(self.idx[i]) if (training and p.pool) else None, st)
+
+    def forward(self, B, S, want_logits=True, labels=False, acc_mask=False, ignore_label=-1):
+        """is_training=False pass over the slab filled by crop/feed: returns (pred uint8 [B,S,S] device,
+        logits float32 [B,S,S,K] device or None).  With labels=True the confusion matrix of (self.labels,
+        pred) is added into self.conf (validation, isprs:1599)."""
+        self._check(B, S)
+        p, st = self.plan, self._stream()
+        self._forward_layers(B, S, False, B * S * S)
+        feat, Pf, ldf, cf = self._feat_view()
+        off, _ = p.offsets["conv_classifier/weights"]
+        _lib.call("drs_classifier_loss", _ptr(feat), B, S, Pf, ldf, cf, p.c_last, p.K, self.params[off:].data_ptr(),
+                  self._bias_ptr("conv_classifier"), None, None, None, 0.0, _ptr(self.logits) if want_logits else None,
+                  _ptr(self.pred), None, 0, 0, None, None, None, None, st)
+        M = B * S * S
+        if labels:
+            _lib.call("drs_confusion", _ptr(self.labels), _ptr(self.pred), _ptr(self.acc_mask) if acc_mask else None, M, p.K,
+                      ignore_label, _ptr(self.conf), st)
+        return self.pred[:M].view(B, S, S), (self.logits[:M * p.K].view(B, S, S, p.K) if want_logits else None)
+
+    # ------------------------------------------------------------------ training step
+    def learning_rate(self, lr0):
+        """tf.train.exponential_decay(lr0, global_step, 50000, factor, staircase=True) (isprs:1686)."""
+        return lr0 * self.lr_decay_factor ** (self.global_step // LR_DECAY_STEPS)
+
+    def train_step(self, B, S, lr0, use_loss_mask=False, use_acc_mask=True, global_pixels=None, apply_update=True,
+                   want_logits=False):
+        """One optimisation step on the slab / labels / masks currently on the device.
+        Returns a dict of DEVICE tensors (no host synchronisation):
+          loss_parts  float64 [2] = (sum of CE over this rank's pixels / N_global after all-reduce, 0.5*sum w^2)
+          pred        uint8 [B,S,S];  conf int32 [K,K] (this step, this rank's pixels, all-reduced)
+        `global_pixels` = number of pixels the loss averages over on ALL ranks (defaults to B*S*S*world)."""
+        self._check(B, S)
+        p, st = self.plan, self._stream()
+        M = B * S * S
+        n_glob = float(global_pixels if global_pixels is not None else M * self.comm.world)
+        self._forward_layers(B, S, True, n_glob)
+        nL = len(p.layers)
+        for i in range(1, nL):
+            L = p.layers[i]
+            off, _ = p.offsets[L.name + "/weights"]
+            _lib.call("drs_filter_flip_transpose", self.params[off:].data_ptr(), _ptr(self.wt[i]), L.k, L.cin, L.cout, st)
+        # classifier + loss + gradient wrt the features
+        feat, Pf, ldf, cf = self._feat_view()
+        woff, _ = p.offsets["conv_classifier/weights"]
+        boff, _ = p.offsets["conv_classifier/biases"]
+        if p.dense:
+            gfeat, ldg, cg = self.gconcat, p.c_last, 0
+        else:
+            gfeat, ldg, cg = self.gA, p.c_last, 0
+        self.conf.zero_()
+        _lib.call("drs_classifier_loss", _ptr(feat), B, S, Pf, ldf, cf, p.c_last, p.K, self.params[woff:].data_ptr(),
+                  self.params[boff:].data_ptr(), _ptr(self.labels), _ptr(self.loss_mask) if use_loss_mask else None,
+                  _ptr(self.acc_mask) if use_acc_mask else None, 1.0 / n_glob, _ptr(self.logits) if want_logits else None,
+                  _ptr(self.pred), _ptr(gfeat), ldg, cg, _ptr(self.dw_partial), _ptr(self.db_partial), _ptr(self.loss_partial),
+                  _ptr(self.conf), st)
+        crow = _lib.query("drs_classifier_rows", B, S)
+        _lib.call("drs_rows_reduce_f32", _ptr(self.dw_partial), crow, p.c_last * p.K, self.grads[woff:].data_ptr(), st)
+        _lib.call("drs_rows_reduce_f32", _ptr(self.db_partial), crow, p.K, self.grads[boff:].data_ptr(), st)
+        _lib.call("drs_sum_f64", _ptr(self.loss_partial), crow, _ptr(self.scalars), st)
+        _lib.call("drs_l2_loss", _ptr(self.params), p.n_decay, _ptr(self.l2_scratch), self.scalars[1:].data_ptr(), st)
+        # reverse loop over the conv blocks
+        gcur, ldc, cc = gfeat, ldg, cg
+        gnext = self.gB
+        for i in reversed(range(nL)):
+            L = p.layers[i]
+            if p.dense:
+                gcur, ldc, cc = self.gconcat, p.c_last, p.concat_off[i]
+            _lib.call("drs_bn_backward_reduce", _ptr(gcur), ldc, cc, _ptr(self.z[i]), _ptr(self.idx[i]), B, S, L.cout,
+                      _ptr(self.mean_rstd[i]), p.alpha, 1 if p.pool else 0, _ptr(self.gxh), _ptr(self.partial), st)
+            _lib.call("drs_stats_reduce", _ptr(self.partial), _lib.query("drs_bn_backward_rows", B, S), L.cout, _ptr(self.sums), st)
+            self.comm.all_reduce_sum(self.sums[:2 * L.cout])
+            _lib.call("drs_bn_backward_apply", _ptr(self.gxh), _ptr(self.z[i]), B, S, L.cout, _ptr(self.mean_rstd[i]),
+                      _ptr(self.sums), n_glob, _ptr(self.gz), L.halo, L.cout, 0, st)
+            xin, Pin, ldin, cin_off = self._in_view(i)
+            goff, _ = p.offsets[L.name + "/weights"]
+            _lib.call("drs_conv_wgrad", _ptr(xin), B, S, Pin, ldin, cin_off, _ptr(self.gz), L.halo, L.cout, 0, L.k, L.rate,
+                      L.pad_b, L.cin_k, L.cin, L.cout, _ptr(self.slab), self.grads[goff:].data_ptr(), st)
+            if i > 0:
+                if p.dense:
+                    out, ldo, co, acc = self.gconcat, p.c_last, 0, 1
+                else:
+                    out, ldo, co, acc = gnext, L.cin, 0, 0
+                _lib.call("drs_conv_forward", _ptr(self.gz), B, S, L.halo, L.cout, 0, _ptr(self.wt[i]), None, L.k, L.rate,
+                          L.pad_a, L.cout, L.cin, _ptr(out), ldo, co, acc, None, st)
+                if not p.dense:
+                    gcur, ldc, cc = gnext, L.cin, 0
+                    gnext = self.gA if gnext is self.gB else self.gB
+        # conv biases sit in front of a mean-subtracting batch norm: their gradient is identically zero
+        b0, _ = p.offsets[p.layers[0].name + "/biases"]
+        self.grads[b0:boff].zero_()
+        if self.comm.world > 1:
+            self.comm.all_reduce_sum(self.grads)
+            self.comm.all_reduce_sum(self.scalars[:1])
+            self.comm.all_reduce_sum(self.conf)
+        self.scalars[0:1].mul_(1.0 / n_glob)
+        if apply_update:
+            self.apply_update(lr0)
+        return dict(loss_parts=self.scalars[:2], pred=self.pred[:M].view(B, S, S), conf=self.conf.view(p.K, p.K))
+
+    def apply_update(self, lr0):
+        p, st = self.plan, self._stream()
+        _lib.call("drs_momentum_update", _ptr(self.params), _ptr(self.grads), _ptr(self.mom), p.n_params, p.n_decay,
+                  self.learning_rate(lr0), self.wd, MOMENTUM, 1.0, st)
+        self.global_step += 1
+
+    def loss_value(self, loss_parts):
+        """total loss = mean CE + sum_k wd * l2_loss(kernel_k) (isprs:1089-1099, 646-651); synchronises."""
+        v = loss_parts.detach().cpu().numpy()
+        return float(v[0] + self.wd * v[1])
+
+    def get_gradient(self, name):
+        off, shape = self.plan.offsets[name]
+        return self.grads[off:off + int(np.prod(shape))].detach().cpu().numpy().reshape(shape).copy()

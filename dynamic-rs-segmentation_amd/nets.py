@@ -1,0 +1,99 @@
+"""Net tables and the execution plan of the four BASELINE nets.
+
+Host-side mirror of the reference's net builders (/root/reference/isprs_dilated_random.py:
+dilated_icpr_original :761-788, dilated_icpr_rate6_densely :914-959, dilated_grsl :962-993,
+dilated_grsl_rate8 :996-1033; dispatch by net_type :1660-1680).  The reference builds a
+TensorFlow graph; here a net is a list of `Layer` records that the HIP kernels are driven from.
+"""
+from collections import namedtuple
+
+# (scope, k, c_in (-1 = image bands), c_out, rate)
+_TABLES = {
+    "dilated_icpr_original": ("relu", False, False, 256, [
+        ("main_conv1", 5, -1, 64, 1), ("main_conv2", 5, 64, 64, 1), ("main_conv3", 4, 64, 128, 2),
+        ("main_conv4", 4, 128, 128, 2), ("main_conv5", 3, 128, 256, 4), ("main_conv6", 3, 256, 256, 4)]),
+    "dilated_grsl": ("lrelu", True, False, 256, [
+        ("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2), ("conv3", 4, 64, 128, 3),
+        ("conv4", 4, 128, 128, 4), ("conv5", 3, 128, 256, 5), ("conv6", 3, 256, 256, 6)]),
+    "dilated_grsl_rate8": ("lrelu", True, False, 256, [
+        ("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2), ("conv3", 4, 64, 128, 3), ("conv4", 4, 128, 128, 4),
+        ("conv5", 3, 128, 192, 5), ("conv6", 3, 192, 192, 6), ("conv7", 3, 192, 256, 7), ("conv8", 3, 256, 256, 8)]),
+    "dilated_icpr_rate6_densely": ("relu", False, True, 448, [
+        ("conv1", 5, -1, 32, 1), ("conv2", 5, 32, 32, 2), ("conv3", 4, 64, 64, 3),
+        ("conv4", 4, 128, 64, 4), ("conv5", 3, 192, 128, 5), ("conv6", 3, 320, 128, 6)]),
+}
+# isprs:1672 spells Dilated8Pooling 'dilated8_grsl'; coffee:1203, contest:1004 and README:33 'dilated_grsl_rate8'
+_ALIASES = {"dilated8_grsl": "dilated_grsl_rate8"}
+
+Layer = namedtuple("Layer", "name k cin cin_k cout rate pad_b pad_a halo")
+
+
+def known_net_types():
+    return sorted(list(_TABLES) + list(_ALIASES))
+
+
+def resolve(net_type):
+    name = _ALIASES.get(net_type, net_type)
+    if name not in _TABLES:
+        # the reference prints a red message and returns None (isprs:1679-1680); the mirror raises
+        raise ValueError("Error! Net type not identified: " + str(net_type))
+    return name
+
+
+def same_pad(k, rate):
+    """TF SAME padding at stride 1: total (k-1)*rate, the extra pixel goes after (bottom/right)."""
+    total = (k - 1) * rate
+    return total // 2, total - total // 2
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+class Plan(object):
+    """Static description of one net for given (bands, classes)."""
+
+    def __init__(self, net_type, channels, num_classes):
+        self.net_type = resolve(net_type)
+        act, self.pool, self.dense, self.c_last, convs = _TABLES[self.net_type]
+        self.alpha = 0.0 if act == "relu" else 0.1      # max(alpha*x, x): ReLU / leaky ReLU (isprs:620-621)
+        self.channels = channels
+        self.K = num_classes
+        self.layers = []
+        for (name, k, ci, co, r) in convs:
+            ci = channels if ci < 0 else ci
+            pb, pa = same_pad(k, r)
+            self.layers.append(Layer(name, k, ci, round_up(ci, 32), co, r, pb, pa, max(pb, pa)))
+        # flat parameter layout: every kernel (HWIO), then every bias; the classifier last in both groups
+        self.offsets = {}
+        off = 0
+        for L in self.layers:
+            self.offsets[L.name + "/weights"] = (off, (L.k, L.k, L.cin, L.cout))
+            off += L.k * L.k * L.cin * L.cout
+        self.offsets["conv_classifier/weights"] = (off, (1, 1, self.c_last, num_classes))
+        off += self.c_last * num_classes
+        self.n_decay = off                              # weight decay applies to kernels only (isprs:640-652)
+        for L in self.layers:
+            self.offsets[L.name + "/biases"] = (off, (L.cout,))
+            off += L.cout
+        self.offsets["conv_classifier/biases"] = (off, (num_classes,))
+        off += num_classes
+        self.n_params = off
+        # batch-norm moving statistics: per layer mean[C] then variance[C]
+        self.bn_offsets = {}
+        off = 0
+        for L in self.layers:
+            self.bn_offsets[L.name] = off
+            off += 2 * L.cout
+        self.n_bn = off
+        # dense net: channel offset of each layer's output inside the concat slab (isprs:921-948)
+        self.concat_off = []
+        if self.dense:
+            o = 0
+            for L in self.layers:
+                self.concat_off.append(o)
+                o += L.cout
+            self.concat_halo = max(L.halo for L in self.layers[1:])
+
+    def mac_per_pixel(self):
+        return sum(L.k * L.k * L.cin * L.cout for L in self.layers) + self.c_last * self.K

@@ -1,0 +1,147 @@
+/*
+ * drs.h -- C ABI of libdrs_hip.so: the MI355X (gfx950) kernels of the dilated-CNN multi-size patch
+ * training / sliding-window inference path of keillernogueira/dynamic-rs-segmentation.
+ *
+ * The reference has no FFI of its own: its device boundary is three `sess.run` call shapes
+ * (isprs_dilated_random.py:1750-1752 train, :1274-1275 infer, :1588 validate) behind which TensorFlow runs
+ * the ops listed below.  Each entry point here replaces one of those TensorFlow ops (or one per-pixel numpy
+ * loop next to them) and cites the reference line it stands in for.  The host-side mirror of the reference's
+ * net builders and step loops (dynamic-rs-segmentation_amd/net.py, loops.py) binds exactly these symbols.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (any allocator; PyTorch-ROCm tensors in the host
+ *     mirror); nothing is allocated, freed or synchronised inside the library;
+ *   - `stream` is a hipStream_t (NULL = the default stream); calls only enqueue work;
+ *   - every function returns 0 on success, DRS_ERR_ARG (1) for a rejected argument, DRS_ERR_HIP (2) for a
+ *     launch failure; nothing throws across the boundary; not re-entrant on one set of buffers;
+ *   - activations are channels-last (the reference's NHWC) with an explicit zero halo:
+ *     a "view" (base, S, P, ld, coff) addresses a slab [B][S+2P][S+2P][ld] floats whose interior pixel
+ *     (b, y, x), channel c of the slice lives at base[((b*(S+2P) + y+P)*(S+2P) + x+P)*ld + coff + c];
+ *     P = 0 gives the reference's plain [B, S, S, C] tensor; filters are HWIO = [k][k][Cin][Cout] as in the
+ *     reference (isprs:706);
+ *   - B*S*S must be < 2^24.
+ */
+#ifndef DRS_H_
+#define DRS_H_
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRS_OK 0
+#define DRS_ERR_ARG 1
+#define DRS_ERR_HIP 2
+
+/* ---- tf.nn.atrous_conv2d / tf.nn.conv2d (SAME, stride 1) + tf.nn.bias_add  (isprs:710-713) -------------
+ * out[p, coff_out + o] (=|+=) sum_{u,v,c} in[p + (u,v)*rate - pad_before, c] * w[u][v][c][o] + bias[o]
+ * `in` is a haloed view with P >= max(pad_before, pad_after); cin, cout multiples of 32 (conv1's 3..5 bands
+ * are zero-padded to 32 by drs_crop_normalize / drs_filter_pad_cin).  `out` is [B*S*S][ld_out].
+ * stats_partial (or NULL): [ceil(B*S*S / drs_conv_mtile(cout))][cout][2] per-tile (sum, sum of squares) of
+ * the outputs, the first half of train-mode batch norm (isprs:658-660).
+ * The input-gradient pass is this same call on the haloed output gradient with the filter from
+ * drs_filter_flip_transpose and pad_before := pad_after. */
+int drs_conv_mtile(int cout);
+int drs_conv_forward(const float* in, int B, int S, int P, int ld_in, int coff_in, const float* w, const float* bias,
+                     int k, int rate, int pad_before, int cin, int cout, float* out, int ld_out, int coff_out,
+                     int accumulate, float* stats_partial, void* stream);
+
+/* ---- filter gradient of the same op (what tf.gradients emits for isprs:710-712) --------------------------
+ * grad[u][v][c < cin_real][o] = sum_p x[p + (u,v)*rate - pad_before, c] * g[p, o];  x, g haloed views.
+ * slab: workspace of drs_conv_wgrad_splits(...) * k*k*cin*cout floats (per-split partial sums, summed in
+ * a fixed order -> bitwise reproducible). */
+int drs_conv_wgrad_splits(int B, int S, int k, int cin, int cout);
+int drs_conv_wgrad(const float* x, int B, int S, int Px, int ld_x, int coff_x, const float* g, int Pg, int ld_g,
+                   int coff_g, int k, int rate, int pad_before, int cin, int cin_real, int cout, float* slab,
+                   float* grad, void* stream);
+
+/* wt[k-1-u][k-1-v][o][c] = w[u][v][c][o]: the filter of the input-gradient pass */
+int drs_filter_flip_transpose(const float* w, float* wt, int k, int cin, int cout, void* stream);
+/* wp[u][v][c < cin_pad][o] = c < cin ? w[u][v][c][o] : 0 */
+int drs_filter_pad_cin(const float* w, float* wp, int k, int cin, int cin_pad, int cout, void* stream);
+
+/* ---- tf.contrib.layers.batch_norm(center=False, scale=False, eps=1e-3, decay=0.999)  (isprs:655-663) -----
+ * drs_stats_reduce : partial[nrows][C][2] (fp32) -> sums[C][2] (fp64), fixed order.  Under data parallelism
+ *                    the caller all-reduces `sums` between this call and the next (sync batch norm).
+ * drs_bn_finish    : sums, count -> mean_rstd[C][2] = (mean, 1/sqrt(biased var + eps)); if moving_* != NULL,
+ *                    moving -= (moving - batch) * (1 - decay) with the Bessel-corrected variance when bessel.
+ * drs_bn_eval_coeffs: is_training=False branch: mean_rstd from the moving statistics. */
+int drs_stats_reduce(const float* partial, int nrows, int C, double* sums, void* stream);
+int drs_bn_finish(const double* sums, double count, int C, float* mean_rstd, float* moving_mean, float* moving_var,
+                  float decay, int bessel, void* stream);
+int drs_bn_eval_coeffs(const float* moving_mean, const float* moving_var, int C, float* mean_rstd, void* stream);
+
+/* ---- normalise + tf.nn.relu | tf.maximum(0.1x, x) + tf.nn.max_pool(3x3, stride 1, SAME) ------------------
+ * (isprs:715-721, 620-621, 745-746, 1001).  z: [B*S*S][C] raw conv output; alpha = 0 (ReLU) or 0.1;
+ * out: haloed view (the halo zeros are written here); argmax (pool only, may be NULL): [B*S*S][C] window
+ * position 0..8 of the first maximum, which the backward pass routes gradients to (TF MaxPoolGrad). */
+int drs_bn_act_pool_forward(const float* z, int B, int S, int C, const float* mean_rstd, float alpha, int pool,
+                            float* out, int P_out, int ld_out, int coff_out, unsigned char* argmax, void* stream);
+
+/* ---- backward of the block above ----------------------------------------------------------------------
+ * reduce: ga [B*S*S][ld_ga]+coff_ga = gradient wrt the block output -> gxhat [B*S*S][C] (gradient wrt the
+ *         normalised activation) and partial[drs_bn_backward_rows(B,S)][C][2] = (sum g, sum g*xhat);
+ * apply : gz = rstd * (gxhat - sum_g/count - xhat * sum_gx/count) into a haloed view (halo zeroed). */
+int drs_bn_backward_rows(int B, int S);
+int drs_bn_backward_reduce(const float* ga, int ld_ga, int coff_ga, const float* z, const unsigned char* argmax, int B,
+                           int S, int C, const float* mean_rstd, float alpha, int pool, float* gxhat, float* partial,
+                           void* stream);
+int drs_bn_backward_apply(const float* gxhat, const float* z, int B, int S, int C, const float* mean_rstd,
+                          const double* sums, double count, float* gz, int P_out, int ld_out, int coff_out,
+                          void* stream);
+
+/* ---- 1x1 classifier + sparse softmax cross-entropy + tf.argmax (+ their gradients) ----------------------
+ * (isprs:1024-1031, 1089-1099, 1690; masked loss: contest_dilated_random.py:881-901; confusion matrix:
+ * calc_accuracy_by_crop isprs:510-531).  feat: haloed view with C channels (multiple of 64, <= 448);
+ * w [C][K], K <= 8.  labels == NULL -> inference (logits / pred only).  inv_n = 1 / number of pixels the
+ * loss averages over (all ranks).  Per-workgroup slabs (rows = drs_classifier_rows(B,S)):
+ * dw_partial [rows][C][K], db_partial [rows][K], loss_partial [rows] (sum of per-pixel CE, fp64).
+ * conf: [K][K] counters, ADDED to (integer atomics), rows = label, cols = prediction, gated by acc_mask. */
+int drs_classifier_rows(int B, int S);
+int drs_classifier_loss(const float* feat, int B, int S, int P, int ld, int coff, int C, int K, const float* w,
+                        const float* bias, const unsigned char* labels, const unsigned char* loss_mask,
+                        const unsigned char* acc_mask, float inv_n, float* logits, unsigned char* pred, float* gfeat,
+                        int ld_g, int coff_g, float* dw_partial, float* db_partial, double* loss_partial,
+                        unsigned int* conf, void* stream);
+
+/* fixed-order column sums / scalar sums used on the slabs above */
+int drs_rows_reduce_f32(const float* in, int nrows, int ncols, float* out, void* stream);
+int drs_sum_f64(const double* in, int n, double* out, void* stream);
+/* tf.nn.l2_loss over the kernels (isprs:646-651): out[0] = 0.5 * sum w^2; scratch = 256 doubles */
+int drs_l2_loss(const float* w, size_t n, double* scratch, double* out, void* stream);
+
+/* ---- tf.train.MomentumOptimizer(momentum).minimize  (isprs:1685-1687) -----------------------------------
+ * g = grad*grad_scale (+ weight_decay*w for the first n_decay entries = the kernels; biases are not decayed,
+ * isprs:640-652); accum = momentum*accum + g; w -= lr*accum. */
+int drs_momentum_update(float* w, const float* grad, float* accum, size_t n, size_t n_decay, float lr,
+                        float weight_decay, float momentum, float grad_scale, void* stream);
+
+/* ---- calc_accuracy_by_crop / whole-map confusion loops  (isprs:510-531, 1290-1296) ----------------------- */
+int drs_confusion(const unsigned char* labels, const unsigned char* pred, const unsigned char* mask, size_t n, int K,
+                  int ignore_label, unsigned int* conf, void* stream);
+
+/* ---- dynamically_create_patches + normalize_images  (isprs:245-334, 74-81; tiler isprs:337-400) ----------
+ * inst [B][4] = (map, row, col, flip) with the border shift-back already applied (isprs:260-269);
+ * rot [B][6] = (m00 m01 m10 m11 off0 off1) of scipy.ndimage.rotate(order=0, reshape=False) when rot_on[b];
+ * noise [B][S][S][C] (fp64, reference-exact) or NULL (device Philox N(0, 0.01)) when noise_on[b];
+ * out: conv1 input slab [B][S+2P][S+2P][ld] (channels C..ld-1 and the halo are zeroed);
+ * out_lab / out_mask [B][S][S] (uint8).  Normalisation touches channels 0,1,2 only. */
+int drs_crop_normalize(const void* tiles, int tiles_are_f64, const unsigned char* labels, const long long* tile_off,
+                       const long long* lab_off, const int* tile_h, const int* tile_w, int C, const int* inst,
+                       const double* rot, const unsigned char* rot_on, const double* noise,
+                       const unsigned char* noise_on, unsigned long long seed, const double* mean3, const double* std3,
+                       int B, int S, int P, int ld, float* out, unsigned char* out_lab, unsigned char* out_mask,
+                       void* stream);
+
+/* ---- overlap-add of window logits and arg-max of the average  (isprs:1261-1284, 1925-1949) ---------------
+ * windows [first_window, first_window + n_windows) of the row-major window grid at `stride` (last row/col
+ * shifted back to the border) are added, in that order, into prob [h][w][K] / occur [h][w]. */
+int drs_stitch_accumulate(float* prob, unsigned int* occur, const float* logits, int h, int w, int K, int S, int stride,
+                          int first_window, int n_windows, void* stream);
+int drs_stitch_finalize(const float* prob, const unsigned int* occur, int h, int w, int K, unsigned char* out,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRS_H_ */

@@ -1,0 +1,282 @@
+"""-m gpu: every HIP entry point of include/drs.h against the CPU oracle (oracle/tf_ops.py, fp64) on the
+same seeded inputs.  Tolerances: fp32 kernels vs fp64 oracle, relative to the tensor's max magnitude,
+1e-5 for single ops (BASELINE north_star: logits within 1e-3 relative end to end); integer outputs exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tf_ops as T
+from oracle import nets as onets
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, dev, padded, rel_err, stream, unpad   # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from drs_amd import _lib
+    assert torch.cuda.is_available()
+    _lib.load()
+    return _lib
+
+
+# every (k, rate) of the four nets with channel counts covering each tile configuration of the kernels
+CONV_CASES = [
+    (5, 1, 32, 64, 3, 9), (5, 2, 64, 64, 2, 12), (4, 3, 64, 128, 2, 11), (4, 4, 128, 128, 2, 10),
+    (3, 5, 128, 192, 2, 13), (3, 6, 192, 192, 1, 15), (3, 7, 192, 256, 1, 16), (3, 8, 256, 256, 2, 17),
+    (5, 1, 32, 32, 2, 25), (4, 2, 64, 128, 2, 8), (3, 4, 128, 256, 1, 9), (3, 6, 320, 128, 1, 14),
+    (4, 4, 128, 64, 1, 12), (3, 5, 192, 128, 1, 12), (5, 2, 32, 32, 3, 7),
+]
+
+
+@pytest.mark.parametrize("k,rate,cin,cout,B,S", CONV_CASES)
+def test_conv_forward_dgrad_wgrad(lib, k, rate, cin, cout, B, S):
+    rng = np.random.default_rng(k * 1000 + rate * 100 + cin + cout + S)
+    x = rng.normal(size=(B, S, S, cin)).astype(np.float32)
+    w = (rng.normal(size=(k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    bias = rng.normal(size=(cout,)).astype(np.float32)
+    g = rng.normal(size=(B, S, S, cout)).astype(np.float32)
+    pb, pa = onets.same_pad(k, rate)
+    P = max(pb, pa) + 1                      # a halo wider than needed must also work
+    M = B * S * S
+    xd = padded(x, P, ld=cin + 32, coff=32, fill=7.0)      # slice of a wider slab; foreign channels are junk
+    wd, bd = dev(w), dev(bias)
+    out = torch.full((M, cout + 32), -3.0, dtype=torch.float32, device=DEV)
+    mt = lib.query("drs_conv_mtile", cout)
+    rows = (M + mt - 1) // mt
+    stats = torch.zeros(rows * cout * 2, dtype=torch.float32, device=DEV)
+    lib.call("drs_conv_forward", xd.data_ptr(), B, S, P, cin + 32, 32, wd.data_ptr(), bd.data_ptr(), k, rate, pb, cin, cout,
+             out.data_ptr(), cout + 32, 32, 0, stats.data_ptr(), stream())
+    torch.cuda.synchronize()
+    ref = T.conv2d_same(x.astype(np.float64), w.astype(np.float64), rate) + bias.astype(np.float64)
+    got = out.cpu().numpy()
+    assert rel_err(got[:, 32:].reshape(B, S, S, cout), ref) < 1e-5
+    assert np.all(got[:, :32] == -3.0)                      # neighbouring channels untouched
+    st = stats.cpu().numpy().reshape(rows, cout, 2).astype(np.float64).sum(axis=0)
+    r2 = ref.reshape(-1, cout)
+    assert np.abs(st[:, 0] - r2.sum(axis=0)).max() < 1e-5 * np.abs(r2).sum(axis=0).max()
+    assert rel_err(st[:, 1], (r2 ** 2).sum(axis=0)) < 1e-5
+    # accumulate mode
+    lib.call("drs_conv_forward", xd.data_ptr(), B, S, P, cin + 32, 32, wd.data_ptr(), None, k, rate, pb, cin, cout,
+             out.data_ptr(), cout + 32, 32, 1, None, stream())
+    torch.cuda.synchronize()
+    ref2 = ref + T.conv2d_same(x.astype(np.float64), w.astype(np.float64), rate)
+    assert rel_err(out.cpu().numpy()[:, 32:].reshape(B, S, S, cout), ref2) < 1e-5
+
+    # gradients
+    gx_ref, gw_ref = T.conv2d_same_bwd(x.astype(np.float64), w.astype(np.float64), rate, g.astype(np.float64))
+    gd = padded(g, P, ld=cout, coff=0)
+    wt = torch.zeros(k * k * cin * cout, dtype=torch.float32, device=DEV)
+    lib.call("drs_filter_flip_transpose", wd.data_ptr(), wt.data_ptr(), k, cin, cout, stream())
+    gx = torch.zeros(M * cin, dtype=torch.float32, device=DEV)
+    lib.call("drs_conv_forward", gd.data_ptr(), B, S, P, cout, 0, wt.data_ptr(), None, k, rate, pa, cout, cin, gx.data_ptr(),
+             cin, 0, 0, None, stream())
+    nsplit = lib.query("drs_conv_wgrad_splits", B, S, k, cin, cout)
+    slab = torch.zeros(nsplit * k * k * cin * cout, dtype=torch.float32, device=DEV)
+    gw = torch.zeros(k * k * cin * cout, dtype=torch.float32, device=DEV)
+    lib.call("drs_conv_wgrad", xd.data_ptr(), B, S, P, cin + 32, 32, gd.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout,
+             slab.data_ptr(), gw.data_ptr(), stream())
+    torch.cuda.synchronize()
+    assert rel_err(gx.cpu().numpy().reshape(B, S, S, cin), gx_ref) < 1e-5
+    assert rel_err(gw.cpu().numpy().reshape(k, k, cin, cout), gw_ref) < 1e-5
+
+
+def test_conv1_band_padding(lib):
+    """3..5 image bands ride the 32-channel K-step: padded filter rows are zero, wgrad drops them again."""
+    rng = np.random.default_rng(5)
+    B, S, C, cout, k = 2, 11, 5, 64, 5
+    x = rng.normal(size=(B, S, S, C)).astype(np.float32)
+    w = rng.normal(size=(k, k, C, cout)).astype(np.float32) * 0.1
+    g = rng.normal(size=(B, S, S, cout)).astype(np.float32)
+    xd = padded(x, 2, ld=32, coff=0)
+    wp = torch.zeros(k * k * 32 * cout, dtype=torch.float32, device=DEV)
+    lib.call("drs_filter_pad_cin", dev(w).data_ptr(), wp.data_ptr(), k, C, 32, cout, stream())
+    out = torch.zeros(B * S * S * cout, dtype=torch.float32, device=DEV)
+    lib.call("drs_conv_forward", xd.data_ptr(), B, S, 2, 32, 0, wp.data_ptr(), None, k, 1, 2, 32, cout, out.data_ptr(), cout, 0, 0,
+             None, stream())
+    gd = padded(g, 2)
+    nsplit = lib.query("drs_conv_wgrad_splits", B, S, k, 32, cout)
+    slab = torch.zeros(nsplit * k * k * 32 * cout, dtype=torch.float32, device=DEV)
+    gw = torch.zeros(k * k * C * cout, dtype=torch.float32, device=DEV)
+    lib.call("drs_conv_wgrad", xd.data_ptr(), B, S, 2, 32, 0, gd.data_ptr(), 2, cout, 0, k, 1, 2, 32, C, cout, slab.data_ptr(),
+             gw.data_ptr(), stream())
+    torch.cuda.synchronize()
+    ref = T.conv2d_same(x.astype(np.float64), w.astype(np.float64), 1)
+    _, gw_ref = T.conv2d_same_bwd(x.astype(np.float64), w.astype(np.float64), 1, g.astype(np.float64))
+    assert rel_err(out.cpu().numpy().reshape(B, S, S, cout), ref) < 1e-5
+    assert rel_err(gw.cpu().numpy().reshape(k, k, C, cout), gw_ref) < 1e-5
+
+
+@pytest.mark.parametrize("C,pool,alpha,B,S,P", [(64, 1, 0.1, 2, 9, 4), (192, 1, 0.1, 1, 12, 0), (256, 0, 0.0, 2, 7, 6),
+                                              (32, 0, 0.0, 3, 10, 6), (128, 1, 0.1, 2, 25, 5)])
+def test_bn_act_pool_forward_backward(lib, C, pool, alpha, B, S, P):
+    rng = np.random.default_rng(C + S)
+    M = B * S * S
+    z = (rng.normal(size=(B, S, S, C)) * 1.5 + 0.3).astype(np.float32)
+    z[0, 0, 0, :] = z[0, 0, 1, :] = 10.0       # an exact tie of two maxima inside pooling windows
+    ga = rng.normal(size=(B, S, S, C)).astype(np.float32)
+    kind = "relu" if alpha == 0.0 else "lrelu"
+    z64 = z.astype(np.float64)
+    xh, mean, var = T.batch_norm_train(z64)
+    a = T.act_fwd(xh, kind)
+    if pool:
+        ref, idx_ref = T.max_pool_3x3(a)
+    else:
+        ref, idx_ref = a, None
+    zd = dev(z.reshape(M, C))
+    # statistics through the slab path the conv epilogue feeds
+    part = np.stack([z.reshape(M, C).sum(axis=0), (z.reshape(M, C).astype(np.float64) ** 2).sum(axis=0)], axis=1).astype(np.float32)
+    sums = torch.zeros(C * 2, dtype=torch.float64, device=DEV)
+    lib.call("drs_stats_reduce", dev(part.reshape(1, C, 2)).data_ptr(), 1, C, sums.data_ptr(), stream())
+    mr = torch.zeros(C * 2, dtype=torch.float32, device=DEV)
+    mm = torch.zeros(C, dtype=torch.float32, device=DEV)
+    mv = torch.ones(C, dtype=torch.float32, device=DEV)
+    lib.call("drs_bn_finish", sums.data_ptr(), float(M), C, mr.data_ptr(), mm.data_ptr(), mv.data_ptr(), 0.999, 1, stream())
+    torch.cuda.synchronize()
+    mrh = mr.cpu().numpy().reshape(C, 2)
+    assert rel_err(mrh[:, 0], mean) < 1e-5 and rel_err(mrh[:, 1], 1 / np.sqrt(var + 1e-3)) < 1e-5
+    assert rel_err(mm.cpu().numpy(), T.moving_update(np.zeros(C), mean)) < 1e-5
+    assert rel_err(mv.cpu().numpy(), T.moving_update(np.ones(C), var * M / (M - 1.0))) < 1e-6
+    ld = C + 8
+    out = torch.full((B * (S + 2 * P) ** 2 * ld,), 5.0, dtype=torch.float32, device=DEV)
+    idx = torch.zeros(M * C, dtype=torch.uint8, device=DEV)
+    lib.call("drs_bn_act_pool_forward", zd.data_ptr(), B, S, C, mr.data_ptr(), alpha, pool, out.data_ptr(), P, ld, 4,
+             idx.data_ptr() if pool else None, stream())
+    torch.cuda.synchronize()
+    got, full = unpad(out, B, S, P, ld, 4, C)
+    assert rel_err(got, ref) < 2e-5
+    if P:
+        halo = full[:, :, :, 4:4 + C].copy()
+        halo[:, P:P + S, P:P + S] = 0
+        assert np.all(halo == 0)                           # halo of the slice zeroed
+    assert np.all(full[:, :, :, :4] == 5.0) and np.all(full[:, :, :, 4 + C:] == 5.0)
+    if pool:
+        idx_h = idx.cpu().numpy().reshape(B, S, S, C)
+        # the winner may differ from the fp64 oracle only where two fp32 candidates tie or nearly tie
+        assert (idx_h != idx_ref).mean() < 1e-3
+        assert idx_h[0, 0, 0, 0] == 4 and idx_h[0, 0, 1, 0] == 3       # first maximum in scan order wins
+    # backward (uses the device's own arg-max codes, checked above)
+    if pool:
+        idx_use = idx.cpu().numpy().reshape(B, S, S, C)
+        gpool = T.max_pool_3x3_bwd(idx_use, ga.astype(np.float64))
+    else:
+        gpool = ga.astype(np.float64)
+    gxh_ref = T.act_bwd(xh, kind, gpool)
+    gz_ref = T.batch_norm_train_bwd(z64, mean, var, gxh_ref)
+    gad = torch.zeros(M, C + 16, dtype=torch.float32, device=DEV)
+    gad[:, 16:] = dev(ga.reshape(M, C))
+    gxh = torch.zeros(M * C, dtype=torch.float32, device=DEV)
+    rows = lib.query("drs_bn_backward_rows", B, S)
+    partial = torch.zeros(rows * C * 2, dtype=torch.float32, device=DEV)
+    lib.call("drs_bn_backward_reduce", gad.data_ptr(), C + 16, 16, zd.data_ptr(), idx.data_ptr() if pool else None, B, S, C,
+             mr.data_ptr(), alpha, pool, gxh.data_ptr(), partial.data_ptr(), stream())
+    bs = torch.zeros(C * 2, dtype=torch.float64, device=DEV)
+    lib.call("drs_stats_reduce", partial.data_ptr(), rows, C, bs.data_ptr(), stream())
+    Pg = 3
+    gz = torch.full((B * (S + 2 * Pg) ** 2 * C,), 9.0, dtype=torch.float32, device=DEV)
+    lib.call("drs_bn_backward_apply", gxh.data_ptr(), zd.data_ptr(), B, S, C, mr.data_ptr(), bs.data_ptr(), float(M), gz.data_ptr(),
+             Pg, C, 0, stream())
+    torch.cuda.synchronize()
+    assert rel_err(gxh.cpu().numpy().reshape(B, S, S, C), gxh_ref) < 2e-5
+    got, full = unpad(gz, B, S, Pg, C, 0, C)
+    assert rel_err(got, gz_ref) < 5e-5
+    full[:, Pg:Pg + S, Pg:Pg + S] = 0
+    assert np.all(full == 0)
+
+
+def test_bn_eval_coeffs(lib):
+    rng = np.random.default_rng(0)
+    C = 192
+    mm, mv = rng.normal(size=C).astype(np.float32), rng.uniform(0.5, 2, size=C).astype(np.float32)
+    mr = torch.zeros(C * 2, dtype=torch.float32, device=DEV)
+    lib.call("drs_bn_eval_coeffs", dev(mm).data_ptr(), dev(mv).data_ptr(), C, mr.data_ptr(), stream())
+    h = mr.cpu().numpy().reshape(C, 2)
+    np.testing.assert_array_equal(h[:, 0], mm)
+    assert rel_err(h[:, 1], 1 / np.sqrt(mv.astype(np.float64) + 1e-3)) < 1e-6
+
+
+@pytest.mark.parametrize("C,K,B,S,P,masked", [(256, 6, 2, 9, 0, False), (448, 2, 1, 12, 6, False), (256, 7, 2, 8, 0, True),
+                                             (64, 6, 1, 31, 1, False)])
+def test_classifier_loss(lib, C, K, B, S, P, masked):
+    rng = np.random.default_rng(C + K)
+    M = B * S * S
+    feat = rng.normal(size=(B, S, S, C)).astype(np.float32)
+    w = (rng.normal(size=(C, K)) / np.sqrt(C)).astype(np.float32)
+    bias = rng.normal(size=K).astype(np.float32) * 0.1
+    y = rng.integers(0, K, size=(B, S, S)).astype(np.uint8)
+    lm = rng.integers(0, 2, size=(B, S, S)).astype(np.uint8) if masked else None
+    am = rng.integers(0, 2, size=(B, S, S)).astype(np.uint8)
+    fd = padded(feat, P, fill=3.0) if P else dev(feat)
+    n = float(lm.sum()) if masked else float(M)
+    rows = lib.query("drs_classifier_rows", B, S)
+    logits = torch.zeros(M * K, dtype=torch.float32, device=DEV)
+    pred = torch.zeros(M, dtype=torch.uint8, device=DEV)
+    gfeat = torch.zeros(M * C, dtype=torch.float32, device=DEV)
+    dwp = torch.zeros(rows * C * K, dtype=torch.float32, device=DEV)
+    dbp = torch.zeros(rows * K, dtype=torch.float32, device=DEV)
+    lp = torch.zeros(rows, dtype=torch.float64, device=DEV)
+    conf = torch.zeros(K * K, dtype=torch.int32, device=DEV)
+    yd, amd = dev(y.reshape(-1)), dev(am.reshape(-1))
+    lmd = dev(lm.reshape(-1)) if masked else None
+    lib.call("drs_classifier_loss", fd.data_ptr(), B, S, P, C, 0, C, K, dev(w).data_ptr(), dev(bias).data_ptr(), yd.data_ptr(),
+             lmd.data_ptr() if masked else None, amd.data_ptr(), 1.0 / n, logits.data_ptr(), pred.data_ptr(), gfeat.data_ptr(), C, 0,
+             dwp.data_ptr(), dbp.data_ptr(), lp.data_ptr(), conf.data_ptr(), stream())
+    dw = torch.zeros(C * K, dtype=torch.float32, device=DEV)
+    db = torch.zeros(K, dtype=torch.float32, device=DEV)
+    ls = torch.zeros(1, dtype=torch.float64, device=DEV)
+    lib.call("drs_rows_reduce_f32", dwp.data_ptr(), rows, C * K, dw.data_ptr(), stream())
+    lib.call("drs_rows_reduce_f32", dbp.data_ptr(), rows, K, db.data_ptr(), stream())
+    lib.call("drs_sum_f64", lp.data_ptr(), rows, ls.data_ptr(), stream())
+    torch.cuda.synchronize()
+    f64 = feat.astype(np.float64)
+    lg_ref = f64 @ w.astype(np.float64) + bias.astype(np.float64)
+    ce, gl = T.softmax_ce(lg_ref, y, lm)
+    lg = logits.cpu().numpy().reshape(B, S, S, K)
+    assert rel_err(lg, lg_ref) < 1e-5
+    ph = pred.cpu().numpy().reshape(B, S, S)
+    np.testing.assert_array_equal(ph, lg.argmax(axis=3))             # first maximum of the device's own logits
+    assert (ph != lg_ref.argmax(axis=3)).mean() < 1e-3
+    assert abs(ls.item() / n - ce) < 1e-5 * max(1.0, abs(ce))
+    assert rel_err(gfeat.cpu().numpy().reshape(B, S, S, C), gl @ w.astype(np.float64).T) < 2e-5
+    assert rel_err(dw.cpu().numpy().reshape(C, K), f64.reshape(-1, C).T @ gl.reshape(-1, K)) < 2e-5
+    assert rel_err(db.cpu().numpy(), gl.reshape(-1, K).sum(axis=0)) < 2e-5
+    cm = np.zeros((K, K), dtype=np.int64)
+    np.add.at(cm, (y[am > 0], ph[am > 0]), 1)
+    np.testing.assert_array_equal(conf.cpu().numpy().reshape(K, K), cm)
+    # inference form: no labels
+    pred2 = torch.zeros(M, dtype=torch.uint8, device=DEV)
+    lib.call("drs_classifier_loss", fd.data_ptr(), B, S, P, C, 0, C, K, dev(w).data_ptr(), dev(bias).data_ptr(), None, None, None, 0.0,
+             None, pred2.data_ptr(), None, 0, 0, None, None, None, None, stream())
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(pred2.cpu().numpy().reshape(B, S, S), ph)
+
+
+def test_momentum_l2_confusion(lib):
+    rng = np.random.default_rng(1)
+    n, nd = 100003, 70001
+    w = rng.normal(size=n).astype(np.float32)
+    g = rng.normal(size=n).astype(np.float32)
+    a = rng.normal(size=n).astype(np.float32)
+    wd_, gd_, ad_ = dev(w), dev(g), dev(a)
+    lib.call("drs_momentum_update", wd_.data_ptr(), gd_.data_ptr(), ad_.data_ptr(), n, nd, 0.01, 0.005, 0.9, 1.0, stream())
+    sc = torch.zeros(256, dtype=torch.float64, device=DEV)
+    out = torch.zeros(1, dtype=torch.float64, device=DEV)
+    lib.call("drs_l2_loss", dev(w).data_ptr(), nd, sc.data_ptr(), out.data_ptr(), stream())
+    torch.cuda.synchronize()
+    gg = g.astype(np.float64) + np.where(np.arange(n) < nd, 0.005 * w.astype(np.float64), 0)
+    acc = 0.9 * a.astype(np.float64) + gg
+    assert rel_err(ad_.cpu().numpy(), acc) < 1e-6
+    assert rel_err(wd_.cpu().numpy(), w - 0.01 * acc) < 1e-6
+    assert abs(out.item() - 0.5 * (w[:nd].astype(np.float64) ** 2).sum()) < 1e-9 * nd
+    K = 6
+    y = rng.integers(0, 7, size=50000).astype(np.uint8)      # 6 = eroded boundary, ignored (isprs:1294)
+    p = rng.integers(0, K, size=50000).astype(np.uint8)
+    m = rng.integers(0, 2, size=50000).astype(np.uint8)
+    conf = torch.zeros(K * K, dtype=torch.int32, device=DEV)
+    lib.call("drs_confusion", dev(y).data_ptr(), dev(p).data_ptr(), dev(m).data_ptr(), 50000, K, 6, conf.data_ptr(), stream())
+    torch.cuda.synchronize()
+    cm = np.zeros((K, K), dtype=np.int64)
+    keep = (m > 0) & (y != 6)
+    np.add.at(cm, (y[keep], p[keep]), 1)
+    np.testing.assert_array_equal(conf.cpu().numpy().reshape(K, K), cm)

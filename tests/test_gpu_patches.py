@@ -1,0 +1,108 @@
+"""-m gpu: drs_crop_normalize and the stitch kernels against the reference-generated goldens and oracle/host_ref.py.
+Bit-exact (the kernel works in fp64 and rounds once to the float32 feed)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import host_ref as H
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, dev, stream   # noqa: E402
+
+
+def _net(ch, B, S):
+    from drs_amd.net import DilatedNet
+    return DilatedNet("dilated_grsl", ch, 6, 0.005, b_max=B, s_max=S, device=DEV)
+
+
+def _slab(net, B, S):
+    slab, P, ld = net.input_slab()
+    a = slab[:B * (S + 2 * P) ** 2 * ld].cpu().numpy().reshape(B, S + 2 * P, S + 2 * P, ld)
+    return a, P, ld
+
+
+def test_crop_matches_reference_goldens(golden_dir):
+    from drs_amd import patches as P
+    g = np.load(os.path.join(golden_dir, "patches.npz"))
+    tiles, labs, inst = [g["tile0"], g["tile1"]], [g["lab0"], g["lab1"]], g["inst"]
+    mean = np.array([0.5, 0.4, 0.3, 0.0, 0.0])
+    std = np.array([0.25, 0.2, 0.1, 1.0, 1.0])
+    pool = P.TilePool(tiles, labs, DEV, dtype=np.float64)
+    for s in (9, 12, 25):
+        net = _net(5, len(inst), s)
+        for train in (False, True):
+            aug = None
+            if train:
+                np.random.seed(1234 + s)
+                aug = P.draw_augmentation(inst, s, 5, noise="host")
+            P.crop_to_net(net, pool, inst, s, mean, std, aug)
+            torch.cuda.synchronize()
+            key = "train" if train else "eval"
+            want = g["%s_p_%d" % (key, s)].copy()
+            H.normalize_images(want, mean, std)                      # isprs:1745: normalise after the crop
+            a, Pd, ld = _slab(net, len(inst), s)
+            np.testing.assert_array_equal(a[:, Pd:Pd + s, Pd:Pd + s, :5], want.astype(np.float32))
+            assert np.all(a[:, :, :, 5:] == 0)                       # band padding
+            halo = a.copy()
+            halo[:, Pd:Pd + s, Pd:Pd + s] = 0
+            assert np.all(halo == 0)
+            M = len(inst) * s * s
+            np.testing.assert_array_equal(net.labels[:M].cpu().numpy().reshape(-1, s, s), g["%s_c_%d" % (key, s)])
+            np.testing.assert_array_equal(net.acc_mask[:M].cpu().numpy().reshape(-1, s, s).astype(bool), g["%s_m_%d" % (key, s)])
+
+
+def test_crop_float32_pool_and_device_noise():
+    from drs_amd import patches as P
+    rng = np.random.default_rng(0)
+    tiles = [rng.uniform(size=(70, 90, 4))]
+    labs = [rng.integers(0, 6, size=(70, 90))]
+    inst = np.array([[0, 3, 5, 10], [0, 60, 80, 77], [0, 20, 20, 180]])
+    S = 16
+    net = _net(4, 3, S)
+    pool = P.TilePool(tiles, labs, DEV, dtype=np.float32)
+    mean, std = [0.5, 0.5, 0.5], [0.2, 0.2, 0.2]
+    P.crop_to_net(net, pool, inst, S, mean, std)
+    a, Pd, ld = _slab(net, 3, S)
+    want, _, _ = H.dynamically_create_patches([tiles[0].astype(np.float32).astype(np.float64)], labs, inst, S, is_train=False)
+    H.normalize_images(want, mean + [0], std + [1])
+    np.testing.assert_array_equal(a[:, Pd:Pd + S, Pd:Pd + S, :4], want.astype(np.float32))
+    # device-side N(0, 0.01) noise: right moments, no exact reproduction of numpy's stream
+    aug = P.Augmentation(3)
+    aug.noise_on[:] = 1
+    aug.seed = 12345
+    P.crop_to_net(net, pool, inst, S, [0, 0, 0], [1, 1, 1], aug)
+    b, _, _ = _slab(net, 3, S)
+    raw, _, _ = H.dynamically_create_patches([tiles[0].astype(np.float32).astype(np.float64)], labs, inst, S, is_train=False)
+    d = b[:, Pd:Pd + S, Pd:Pd + S, :4].astype(np.float64) - raw
+    assert abs(d.mean()) < 1e-3 and abs(d.std() - 0.01) < 1e-3
+
+
+@pytest.mark.parametrize("h,w,S,K,bs", [(70, 90, 25, 6, 16), (64, 64, 16, 2, 7), (50, 131, 20, 7, 64), (33, 40, 33, 6, 3)])
+def test_stitch_matches_reference_order(h, w, S, K, bs):
+    from drs_amd import _lib, patches as P
+    rng = np.random.default_rng(h + w)
+    st = H.stride_for(S)
+    nh, nw = P.window_counts(h, w, S, st)
+    assert (nh, nw) == H.window_counts(h, w, S, st)
+    tile = np.zeros((h, w, 1))
+    lab = np.zeros((h, w), dtype=np.uint8)
+    prob = torch.zeros(h * w * K, dtype=torch.float32, device=DEV)
+    occ = torch.zeros(h * w, dtype=torch.int32, device=DEV)
+    batches = []
+    nb = -(-nh * nw // bs)
+    for i in range(nb):
+        _, _, pos = H.create_patches_per_map(tile, lab, S, st, i, bs)
+        lg = rng.normal(size=(len(pos), S, S, K)).astype(np.float32)
+        batches.append((lg, pos))
+        np.testing.assert_array_equal(P.window_positions(h, w, S, st, i, bs), np.asarray(pos).astype(np.int64))
+        _lib.call("drs_stitch_accumulate", prob.data_ptr(), occ.data_ptr(), dev(lg).data_ptr(), h, w, K, S, st, i * bs, len(pos), stream())
+    out = torch.zeros(h * w, dtype=torch.uint8, device=DEV)
+    _lib.call("drs_stitch_finalize", prob.data_ptr(), occ.data_ptr(), h, w, K, out.data_ptr(), stream())
+    torch.cuda.synchronize()
+    p_ref, o_ref, am_ref = H.stitch_tile(h, w, K, S, batches)
+    np.testing.assert_array_equal(prob.cpu().numpy().reshape(h, w, K), p_ref)      # same addition order -> bit-exact
+    np.testing.assert_array_equal(occ.cpu().numpy().reshape(h, w), o_ref[:, :, 0])
+    np.testing.assert_array_equal(out.cpu().numpy().reshape(h, w), am_ref)
