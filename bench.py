@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training patches/sec of dilated_grsl_rate8 (Dilated8Pooling) on 64x64x5 patches.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one global batch of 128 synthetic patches: device crop + augment +
+normalise, forward, loss, backward, (sync-BN / gradient all-reduce when N > 1), momentum update, confusion
+matrix.  The global batch is fixed, so N ranks take 128/N patches each ("scaling": "strong").  Inputs (the
+2048x2048x5 tile, labels, instance table) are resident in HBM before the timed region.  Rank 0 prints ONE JSON
+line with the contract's keys plus "roofline" (dominant kernel: the fp32-MFMA implicit-GEMM convolution, timed
+live with HIP events on the launch stream), "kernels" (the same figures for every kernel family) and
+"cpu_baseline" (the oracle's PyTorch-CPU port of the reference step, bounded sample, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NET, CHANNELS, CLASSES = "dilated_grsl_rate8", 5, 6
+GLOBAL_BATCH, PATCH = 128, 64
+TILE = 2048
+LR, WD = 0.01, 0.005
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The reference step restated with PyTorch-CPU fp32 ops (oracle/torch_ref.py) + the reference's host pipeline
+    (numpy crop, normalise of bands 0..2, vectorised confusion matrix), on this host's cores."""
+    from oracle.torch_ref import TorchNet
+    from oracle import host_ref as H
+    from drs_amd.synthetic import make_tile, grid_instances
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    B = 16
+    tile, lab = make_tile(512, 512, CHANNELS, CLASSES, seed=1234)
+    inst = grid_instances(512, 512, PATCH, 25, B * 8, seed=0)
+    mean, std = [0.5, 0.5, 0.5, 0, 0], [0.1, 0.1, 0.1, 1, 1]
+    from oracle.tf_ops import OracleNet
+    o = OracleNet(NET, CHANNELS, CLASSES, dtype=np.float32, seed=42)
+    net = TorchNet(NET, CHANNELS, CLASSES, params=o.p, dtype=torch.float32)
+    track = np.zeros((CLASSES, CLASSES), dtype=np.uint32)
+    times = []
+    np.random.seed(0)
+    t_start = time.time()
+    step = 0
+    while True:
+        rows = inst[(step * B) % len(inst):(step * B) % len(inst) + B]
+        t0 = time.time()
+        x, y, m = H.dynamically_create_patches([tile], [lab], rows, PATCH, is_train=True)
+        H.normalize_images(x, mean, std)
+        _, pred = net.train_step(x.astype(np.float32), y, LR, WD)
+        H.calc_accuracy_by_crop(y, pred, track, m, CLASSES)
+        dt = time.time() - t0
+        if step > 0:
+            times.append(dt)
+        step += 1
+        if step >= 2 and (time.time() - t_start > seconds_budget or len(times) >= 5):
+            break
+    med = float(np.median(times))
+    return dict(value=B / med, unit="patches/s", cores=ncores, kind="port",
+                sample="%d timed steps (1 warm-up) of batch %d, same net / 64x64x5 patches / host crop+augment+normalise+"
+                       "confusion; median step %.2f s" % (len(times), B, med))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+
+    from drs_amd.net import DilatedNet, KernelTimer
+    from drs_amd import patches as P
+    from drs_amd.synthetic import make_tile, grid_instances
+    from drs_amd.dist import TorchComm, shard_slice
+
+    comm = None
+    if world > 1:
+        comm = TorchComm("nccl")
+    rank = comm.rank if comm else 0
+    B_local = GLOBAL_BATCH // world
+    if GLOBAL_BATCH % world:
+        sys.exit("global batch %d not divisible by %d ranks" % (GLOBAL_BATCH, world))
+
+    tile, lab = make_tile(TILE, TILE, CHANNELS, CLASSES, seed=1234)
+    pool = P.TilePool([tile], [lab], dev, dtype=np.float64)
+    inst = grid_instances(TILE, TILE, PATCH, 25, GLOBAL_BATCH * 100, seed=0)      # the super-batch (isprs:1630-1632)
+    mean = tile[:, :, :3].mean(axis=(0, 1)).tolist()
+    std = tile[:, :, :3].std(axis=(0, 1)).tolist()
+    net = DilatedNet(NET, CHANNELS, CLASSES, WD, b_max=B_local, s_max=PATCH, device=dev, seed=42, comm=comm)
+    sl = shard_slice(GLOBAL_BATCH, rank, world)
+
+    import random
+    random.seed(7)
+    np.random.seed(7)
+    shuffle = np.asarray(random.sample(range(len(inst)), len(inst)))
+    it = 0
+    epoch_cm = torch.zeros(CLASSES, CLASSES, dtype=torch.int64, device=dev)
+
+    def one_step():
+        nonlocal shuffle, it
+        shuffle, batch, it = P.select_batch(shuffle, GLOBAL_BATCH, it, len(inst))
+        rows = inst[batch]
+        aug = P.draw_augmentation(rows, PATCH, CHANNELS, noise="device")       # every rank draws the whole batch
+        mine = P.Augmentation(B_local)
+        mine.rot_on, mine.rot, mine.noise_on, mine.flip, mine.seed = aug.rot_on[sl], aug.rot[sl], aug.noise_on[sl], aug.flip[sl], aug.seed + rank
+        P.crop_to_net(net, pool, rows[sl], PATCH, mean, std, mine)
+        out = net.train_step(B_local, PATCH, LR)
+        epoch_cm.add_(out["conf"])
+        return out
+
+    for _ in range(args.warmup):
+        one_step()
+    if comm:
+        comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(args.steps):
+        out = one_step()
+    if comm:
+        comm.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if comm:
+        elapsed = comm.max_float(elapsed, dev)
+    loss = net.loss_value(out["loss_parts"])
+
+    # ---- per-kernel timing pass (outside the timed region): HIP events around every launch
+    kernels, roofline = None, None
+    if not args.no_kernel_timing:
+        net.timer = KernelTimer()
+        for _ in range(3):
+            one_step()
+        summ = net.timer.summary()
+        net.timer = None
+        kernels = {}
+        for kind, d in sorted(summ.items()):
+            avg_ms = d["ms"] / d["launches"]
+            if kind.startswith("conv_"):
+                ach = d["work"] / (d["ms"] * 1e-3) / 1e12
+                kernels[kind] = dict(bound="mfma", launches_per_step=d["launches"] // 3, avg_ms=round(avg_ms, 4),
+                                     achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4))
+            else:
+                ach = d["work"] / (d["ms"] * 1e-3) / 1e9
+                kernels[kind] = dict(bound="hbm", launches_per_step=d["launches"] // 3, avg_ms=round(avg_ms, 4),
+                                     achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4))
+        # dominant kernel: conv_igemm_kernel (forward and input-gradient launches are the same kernel)
+        w = sum(summ[k]["work"] for k in ("conv_fwd", "conv_dgrad") if k in summ)
+        ms = sum(summ[k]["ms"] for k in ("conv_fwd", "conv_dgrad") if k in summ)
+        nl = sum(summ[k]["launches"] for k in ("conv_fwd", "conv_dgrad") if k in summ)
+        ach = w / (ms * 1e-3) / 1e12
+        roofline = dict(kernel="conv_igemm_kernel (fwd + dgrad launches)", bound="mfma", achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS,
+                        unit="TFLOP/s", frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                        launches=nl, avg_launch_ms=round(ms / nl, 4), algorithmic_gflop_per_launch=round(w / nl / 1e9, 2))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        value = GLOBAL_BATCH * args.steps / elapsed
+        line = {
+            "metric": "training patches/sec dilated_grsl_rate8 64x64x5", "value": round(value, 2), "unit": "patches/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "dilated_grsl_rate8 (Dilated8Pooling) training step, single_fixed 64x64, 5-band synthetic "
+                                   "2048x2048 tile, global batch 128 (crop+augment+normalise, fwd, loss, bwd, momentum, confusion)",
+                       "global_batch": GLOBAL_BATCH, "patch": PATCH, "bands": CHANNELS, "classes": CLASSES,
+                       "parallelism": "dp%d" % world, "sync_bn": True},
+            "final_loss": round(loss, 5),
+            "train_tflops": round(value * 3 * 2 * net.plan.mac_per_pixel() * PATCH * PATCH / 1e12, 2),
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if comm:
+        comm.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -440,10 +440,10 @@ int drs_stats_reduce(const float* partial, int nrows, int C, double* sums, void*
 }
 
 int drs_bn_finish(const double* sums, double count, int C, float* mean_rstd, float* moving_mean, float* moving_var,
-                  float decay, int bessel, void* stream) {
+                  double decay, int bessel, void* stream) {
   if (!sums || !mean_rstd || count < 1.0) return DRS_ERR_ARG;
   hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, count, C, mean_rstd,
-                     moving_mean, moving_var, (float)(1.0 - (double)decay), bessel);
+                     moving_mean, moving_var, (float)(1.0 - decay), bessel);
   return DRS_LAUNCH_CHECK();
 }
 

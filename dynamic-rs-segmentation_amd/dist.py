@@ -1,0 +1,57 @@
+"""Data parallelism: one process per GPU, torch.distributed over RCCL/xGMI ('nccl' IS RCCL on ROCm).
+
+The reference is single-process (isprs:1707); this is the build's addition.  A training
+step shards its batch over the ranks (same patch size, same RNG streams on every rank, so all ranks agree on
+the size draw, the batch indices and the augmentation without any exchange) and needs exactly these
+collectives, all sums:
+  * per batch-norm layer, forward:  [sum z, sum z^2]      (2*C fp64)  -> the reference's global-batch statistics
+  * per batch-norm layer, backward: [sum g, sum g*xhat]   (2*C fp64)
+  * once per step: the flat fp32 gradient buffer (8.37 MB for Dilated8Pooling), the CE sum (1 fp64) and the
+    K x K confusion matrix (int32)
+Sliding-window inference shards windows over ranks with no data-path collective until the final band gather.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class TorchComm(object):
+    """all_reduce_sum over the default process group (backend 'nccl' on GPUs, 'gloo' on CPU tests)."""
+
+    def __init__(self, backend=None, init=True):
+        if init and not dist.is_initialized():
+            backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend=backend)
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+
+    def all_reduce_sum(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier()
+
+    def max_float(self, v, device):
+        t = torch.tensor([float(v)], dtype=torch.float64, device=device)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def shard_slice(n, rank, world):
+    """contiguous share of n items for `rank` (n must divide evenly: batch-norm counts assume equal shards)."""
+    if n % world:
+        raise ValueError("global batch %d is not divisible by %d ranks" % (n, world))
+    per = n // world
+    return slice(rank * per, (rank + 1) * per)
+
+
+def window_shard(n_windows, batch_size, rank, world):
+    """whole batches of consecutive windows per rank, round-robin over batches (inference)."""
+    nb = -(-n_windows // batch_size)
+    return [i for i in range(nb) if i % world == rank]

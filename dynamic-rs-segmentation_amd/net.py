@@ -30,6 +30,28 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+class KernelTimer(object):
+    """HIP-event timing of individual launches on the stream the kernels are enqueued on (torch's current
+    stream).  Used by bench.py for the per-kernel roofline figures; off in normal runs."""
+
+    def __init__(self):
+        self.records = []        # (kind, algorithmic work, start event, end event)
+
+    def add(self, kind, work, e0, e1):
+        self.records.append((kind, work, e0, e1))
+
+    def summary(self):
+        """kind -> dict(launches, ms (sum), work (sum)); synchronises."""
+        torch.cuda.synchronize()
+        out = {}
+        for kind, work, e0, e1 in self.records:
+            d = out.setdefault(kind, dict(launches=0, ms=0.0, work=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["work"] += work
+        return out
+
+
 class NoComm(object):
     """Single-process stand-in for the collective interface (see dist.py)."""
     world = 1
@@ -51,6 +73,8 @@ class DilatedNet(object):
         self.bessel = 1 if bessel_moving_var else 0
         self.lr_decay_factor = lr_decay_factor      # 0.5 isprs:1686; 0.1 coffee:1228, contest:1021
         self.global_step = 0
+        self.debug = None
+        self.timer = None
         if self.b_max * self.s_max * self.s_max >= (1 << 24):
             raise ValueError("B*S*S must stay below 2^24")
         p = self.plan
@@ -219,6 +243,16 @@ class DilatedNet(object):
         L = self.plan.layers[0]
         return self.x0, L.halo, L.cin_k
 
+    def _k(self, kind, work, name, *args):
+        """enqueue one library call; with a KernelTimer attached, bracket it with HIP events."""
+        if self.timer is None:
+            return _lib.call(name, *args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.call(name, *args)
+        e1.record()
+        self.timer.add(kind, work, e0, e1)
+
     def _check(self, B, S):
         if B < 1 or S < 1 or B > self.b_max or S > self.s_max:
             raise ValueError("batch %d / patch size %d outside the allocated (%d, %d)" % (B, S, self.b_max, self.s_max))
@@ -254,8 +288,9 @@ class DilatedNet(object):
         for i, L in enumerate(p.layers):
             xin, Pin, ldin, cin_off = self._in_view(i)
             stats = self.partial if training else None
-            _lib.call("drs_conv_forward", _ptr(xin), B, S, Pin, ldin, cin_off, self._weight_ptr(i), self._bias_ptr(L.name),
-                      L.k, L.rate, L.pad_b, L.cin_k, L.cout, _ptr(self.z[i]), L.cout, 0, 0, _ptr(stats), st)
+            self._k("conv_fwd", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_forward", _ptr(xin), B, S, Pin, ldin, cin_off,
+                    self._weight_ptr(i), self._bias_ptr(L.name),
+                    L.k, L.rate, L.pad_b, L.cin_k, L.cout, _ptr(self.z[i]), L.cout, 0, 0, _ptr(stats), st)
             bo = p.bn_offsets[L.name]
             mm, mv = self.bn[bo:bo + L.cout], self.bn[bo + L.cout:bo + 2 * L.cout]
             if training:
@@ -267,8 +302,9 @@ class DilatedNet(object):
             else:
                 _lib.call("drs_bn_eval_coeffs", _ptr(mm), _ptr(mv), L.cout, _ptr(self.mean_rstd[i]), st)
             out, Pout, ldout, coff = self._out_view(i)
-            _lib.call("drs_bn_act_pool_forward", _ptr(self.z[i]), B, S, L.cout, _ptr(self.mean_rstd[i]), p.alpha,
-                      1 if p.pool else 0, _ptr(out), Pout, ldout, coff, _ptr(self.idx[i]) if (training and p.pool) else None, st)
+            self._k("bn_act_pool_fwd", M * L.cout * (9.0 if (training and p.pool) else 8.0), "drs_bn_act_pool_forward",
+                    _ptr(self.z[i]), B, S, L.cout, _ptr(self.mean_rstd[i]), p.alpha, 1 if p.pool else 0, _ptr(out), Pout, ldout,
+                    coff, _ptr(self.idx[i]) if (training and p.pool) else None, st)
 
     def forward(self, B, S, want_logits=True, labels=False, acc_mask=False, ignore_label=-1):
         """is_training=False pass over the slab filled by crop/feed: returns (pred uint8 [B,S,S] device,
@@ -299,12 +335,15 @@ class DilatedNet(object):
         Returns a dict of DEVICE tensors (no host synchronisation):
           loss_parts  float64 [2] = (sum of CE over this rank's pixels / N_global after all-reduce, 0.5*sum w^2)
           pred        uint8 [B,S,S];  conf int32 [K,K] (this step, this rank's pixels, all-reduced)
-        `global_pixels` = number of pixels the loss averages over on ALL ranks (defaults to B*S*S*world)."""
+        `global_pixels` = number of pixels the loss averages over on ALL ranks (defaults to B*S*S*world; the
+        contest form passes the number of unmasked pixels).  Every rank must hold the same B (the batch-norm
+        count is B*S*S*world)."""
         self._check(B, S)
         p, st = self.plan, self._stream()
         M = B * S * S
+        n_bn = float(M * self.comm.world)        # batch-norm statistics run over every pixel of the global batch
         n_glob = float(global_pixels if global_pixels is not None else M * self.comm.world)
-        self._forward_layers(B, S, True, n_glob)
+        self._forward_layers(B, S, True, n_bn)
         nL = len(p.layers)
         for i in range(1, nL):
             L = p.layers[i]
@@ -319,8 +358,8 @@ class DilatedNet(object):
         else:
             gfeat, ldg, cg = self.gA, p.c_last, 0
         self.conf.zero_()
-        _lib.call("drs_classifier_loss", _ptr(feat), B, S, Pf, ldf, cf, p.c_last, p.K, self.params[woff:].data_ptr(),
-                  self.params[boff:].data_ptr(), _ptr(self.labels), _ptr(self.loss_mask) if use_loss_mask else None,
+        self._k("classifier_loss", M * p.c_last * 8.0, "drs_classifier_loss", _ptr(feat), B, S, Pf, ldf, cf, p.c_last, p.K,
+                self.params[woff:].data_ptr(), self.params[boff:].data_ptr(), _ptr(self.labels), _ptr(self.loss_mask) if use_loss_mask else None,
                   _ptr(self.acc_mask) if use_acc_mask else None, 1.0 / n_glob, _ptr(self.logits) if want_logits else None,
                   _ptr(self.pred), _ptr(gfeat), ldg, cg, _ptr(self.dw_partial), _ptr(self.db_partial), _ptr(self.loss_partial),
                   _ptr(self.conf), st)
@@ -336,23 +375,28 @@ class DilatedNet(object):
             L = p.layers[i]
             if p.dense:
                 gcur, ldc, cc = self.gconcat, p.c_last, p.concat_off[i]
-            _lib.call("drs_bn_backward_reduce", _ptr(gcur), ldc, cc, _ptr(self.z[i]), _ptr(self.idx[i]), B, S, L.cout,
-                      _ptr(self.mean_rstd[i]), p.alpha, 1 if p.pool else 0, _ptr(self.gxh), _ptr(self.partial), st)
+            self._k("bn_bwd_reduce", M * L.cout * (13.0 if p.pool else 12.0), "drs_bn_backward_reduce", _ptr(gcur), ldc, cc,
+                    _ptr(self.z[i]), _ptr(self.idx[i]), B, S, L.cout, _ptr(self.mean_rstd[i]), p.alpha, 1 if p.pool else 0,
+                    _ptr(self.gxh), _ptr(self.partial), st)
             _lib.call("drs_stats_reduce", _ptr(self.partial), _lib.query("drs_bn_backward_rows", B, S), L.cout, _ptr(self.sums), st)
             self.comm.all_reduce_sum(self.sums[:2 * L.cout])
-            _lib.call("drs_bn_backward_apply", _ptr(self.gxh), _ptr(self.z[i]), B, S, L.cout, _ptr(self.mean_rstd[i]),
-                      _ptr(self.sums), n_glob, _ptr(self.gz), L.halo, L.cout, 0, st)
+            self._k("bn_bwd_apply", M * L.cout * 12.0, "drs_bn_backward_apply", _ptr(self.gxh), _ptr(self.z[i]), B, S, L.cout,
+                    _ptr(self.mean_rstd[i]), _ptr(self.sums), n_bn, _ptr(self.gz), L.halo, L.cout, 0, st)
+            if self.debug is not None:      # diagnostics only: per-layer snapshots for tests/diag_net.py
+                self.debug["gxh%d" % i] = self.gxh[:M * L.cout].clone()
+                self.debug["gz%d" % i] = self.gz[:B * (S + 2 * L.halo) ** 2 * L.cout].clone()
             xin, Pin, ldin, cin_off = self._in_view(i)
             goff, _ = p.offsets[L.name + "/weights"]
-            _lib.call("drs_conv_wgrad", _ptr(xin), B, S, Pin, ldin, cin_off, _ptr(self.gz), L.halo, L.cout, 0, L.k, L.rate,
-                      L.pad_b, L.cin_k, L.cin, L.cout, _ptr(self.slab), self.grads[goff:].data_ptr(), st)
+            self._k("conv_wgrad", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_wgrad", _ptr(xin), B, S, Pin, ldin, cin_off,
+                    _ptr(self.gz), L.halo, L.cout, 0, L.k, L.rate, L.pad_b, L.cin_k, L.cin, L.cout, _ptr(self.slab),
+                    self.grads[goff:].data_ptr(), st)
             if i > 0:
                 if p.dense:
                     out, ldo, co, acc = self.gconcat, p.c_last, 0, 1
                 else:
                     out, ldo, co, acc = gnext, L.cin, 0, 0
-                _lib.call("drs_conv_forward", _ptr(self.gz), B, S, L.halo, L.cout, 0, _ptr(self.wt[i]), None, L.k, L.rate,
-                          L.pad_a, L.cout, L.cin, _ptr(out), ldo, co, acc, None, st)
+                self._k("conv_dgrad", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_forward", _ptr(self.gz), B, S, L.halo, L.cout,
+                        0, _ptr(self.wt[i]), None, L.k, L.rate, L.pad_a, L.cout, L.cin, _ptr(out), ldo, co, acc, None, st)
                 if not p.dense:
                     gcur, ldc, cc = gnext, L.cin, 0
                     gnext = self.gA if gnext is self.gB else self.gB
@@ -370,8 +414,8 @@ class DilatedNet(object):
 
     def apply_update(self, lr0):
         p, st = self.plan, self._stream()
-        _lib.call("drs_momentum_update", _ptr(self.params), _ptr(self.grads), _ptr(self.mom), p.n_params, p.n_decay,
-                  self.learning_rate(lr0), self.wd, MOMENTUM, 1.0, st)
+        self._k("momentum_update", p.n_params * 20.0, "drs_momentum_update", _ptr(self.params), _ptr(self.grads), _ptr(self.mom),
+                p.n_params, p.n_decay, self.learning_rate(lr0), self.wd, MOMENTUM, 1.0, st)
         self.global_step += 1
 
     def loss_value(self, loss_parts):

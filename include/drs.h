@@ -68,7 +68,7 @@ int drs_filter_pad_cin(const float* w, float* wp, int k, int cin, int cin_pad, i
  * drs_bn_eval_coeffs: is_training=False branch: mean_rstd from the moving statistics. */
 int drs_stats_reduce(const float* partial, int nrows, int C, double* sums, void* stream);
 int drs_bn_finish(const double* sums, double count, int C, float* mean_rstd, float* moving_mean, float* moving_var,
-                  float decay, int bessel, void* stream);
+                  double decay, int bessel, void* stream);
 int drs_bn_eval_coeffs(const float* moving_mean, const float* moving_var, int C, float* mean_rstd, void* stream);
 
 /* ---- normalise + tf.nn.relu | tf.maximum(0.1x, x) + tf.nn.max_pool(3x3, stride 1, SAME) ------------------
@@ -125,7 +125,8 @@ int drs_confusion(const unsigned char* labels, const unsigned char* pred, const 
  * rot [B][6] = (m00 m01 m10 m11 off0 off1) of scipy.ndimage.rotate(order=0, reshape=False) when rot_on[b];
  * noise [B][S][S][C] (fp64, reference-exact) or NULL (device Philox N(0, 0.01)) when noise_on[b];
  * out: conv1 input slab [B][S+2P][S+2P][ld] (channels C..ld-1 and the halo are zeroed);
- * out_lab / out_mask [B][S][S] (uint8).  Normalisation touches channels 0,1,2 only. */
+ * out_lab / out_mask [B][S][S] (uint8).  Normalisation touches channels 0,1,2 only.
+ * mean3 / std3 are HOST pointers to 3 doubles each (copied into the kernel arguments). */
 int drs_crop_normalize(const void* tiles, int tiles_are_f64, const unsigned char* labels, const long long* tile_off,
                        const long long* lab_off, const int* tile_h, const int* tile_w, int C, const int* inst,
                        const double* rot, const unsigned char* rot_on, const double* noise,

@@ -97,21 +97,23 @@ def act_fwd(x, kind):
     return np.maximum(x.dtype.type(0.1) * x, x)
 
 
-def act_bwd(x, kind, g):
+def act_bwd(x, kind, g, positive=None):
+    """`positive` overrides the x > 0 decision (see OracleNet: decision-aligned comparison)."""
     slope = 0.0 if kind == "relu" else 0.1
-    return np.where(x > 0, g, g * g.dtype.type(slope))
+    return np.where((x > 0) if positive is None else positive, g, g * g.dtype.type(slope))
 
 
 # --------------------------------------------------------------------------- max pool
-def max_pool_3x3(x):
+def max_pool_3x3(x, forced_idx=None):
     """tf.nn.max_pool(ksize 3x3, strides 1, SAME) (isprs:745-746, 1001).  Padding never
     wins.  Also returns the arg-max code 0..8 (window scan order, first maximum wins)
-    that TF's CPU MaxPoolGrad uses to route gradients."""
+    that TF's CPU MaxPoolGrad uses to route gradients.  `forced_idx` overrides the winner
+    (decision-aligned comparison, see OracleNet)."""
     B, H, W, C = x.shape
     xp = np.full((B, H + 2, W + 2, C), -np.inf, dtype=x.dtype)
     xp[:, 1:-1, 1:-1, :] = x
     stack = np.stack([xp[:, dy:dy + H, dx:dx + W, :] for dy in range(3) for dx in range(3)], axis=0)
-    idx = np.argmax(stack, axis=0)           # first maximum in scan order
+    idx = np.argmax(stack, axis=0) if forced_idx is None else forced_idx.astype(np.int64)   # first maximum in scan order
     out = np.take_along_axis(stack, idx[None], axis=0)[0]
     return out, idx.astype(np.uint8)
 
@@ -169,7 +171,14 @@ class OracleNet(object):
     """The reference graph for one net_type: net builders isprs:761-1033, block order
     _conv_layer isprs:700-723 (conv -> +bias -> BN -> act [-> 3x3 max-pool]), classifier
     isprs:1024-1031, loss isprs:1089-1099 (+ wd * l2_loss per kernel, isprs:646-651),
-    MomentumOptimizer isprs:1685-1687."""
+    MomentumOptimizer isprs:1685-1687.
+
+    Decision-aligned comparison: ReLU / leaky-ReLU signs and max-pool winners are discontinuous in the
+    input, so a float32 implementation and this float64 restatement can legitimately disagree on a few
+    near-tie elements (|xhat| ~ 1e-7, or two window candidates equal to the last bit); each such flip moves a
+    gradient entry by O(1/pixels).  ``decisions`` (one dict per conv layer with boolean ``pos`` = xhat > 0
+    and uint8 ``idx`` = pool winner, both taken from the implementation under test) pins those discrete
+    choices so that everything continuous can be compared tightly."""
 
     def __init__(self, net_type, channels, num_classes, dtype=np.float64, seed=42,
                  bessel_moving_var=True):
@@ -196,7 +205,7 @@ class OracleNet(object):
         return name.endswith("/weights") or name.endswith("/biases")
 
     # ---- forward; keeps what backward needs in self.cache when is_training
-    def forward(self, x, is_training):
+    def forward(self, x, is_training, decisions=None):
         dt = self.dtype.type
         x = x.astype(self.dtype)
         cache = []
@@ -216,11 +225,12 @@ class OracleNet(object):
                 xh = batch_norm_eval(z, self.p[name + "/moving_mean"], self.p[name + "/moving_variance"])
                 mean = var = None
             a = act_fwd(xh, self.spec["act"])
+            dec = decisions[li] if decisions is not None else {}
             if self.spec["pool"]:
-                out, idx = max_pool_3x3(a)
+                out, idx = max_pool_3x3(a, dec.get("idx"))
             else:
                 out, idx = a, None
-            cache.append((inp, z, mean, var, xh, idx))
+            cache.append((inp, z, mean, var, xh, idx, dec.get("pos")))
             if dense:
                 concat = out if li == 0 else np.concatenate([concat, out], axis=3)   # isprs:921-948
                 cur = concat
@@ -231,10 +241,10 @@ class OracleNet(object):
         self.cache = (cache, feat)
         return logits
 
-    def loss_and_grads(self, x, y, weight_decay, mask=None):
-        """Returns (total loss, pred, grads dict).  BN in training mode."""
+    def loss_and_grads(self, x, y, weight_decay, mask=None, decisions=None):
+        """Returns (total loss, pred, grads dict, logits).  BN in training mode."""
         dt = self.dtype.type
-        logits = self.forward(x, True)
+        logits = self.forward(x, True, decisions)
         ce, gl = softmax_ce(logits, y, mask)
         l2 = sum(0.5 * (self.p[n] ** 2).sum() for n in self.p if n.endswith("/weights"))   # tf.nn.l2_loss
         loss = ce + weight_decay * l2
@@ -247,14 +257,14 @@ class OracleNet(object):
         dense = self.spec["dense"]
         for li in reversed(range(len(self.convs))):
             name, k, ci, co, r = self.convs[li]
-            inp, z, mean, var, xh, idx = cache[li]
+            inp, z, mean, var, xh, idx, pos = cache[li]
             if dense:
                 gout = gcur[..., gcur.shape[-1] - co:]
                 grest = gcur[..., :gcur.shape[-1] - co]
             else:
                 gout = gcur
             ga = max_pool_3x3_bwd(idx, gout) if self.spec["pool"] else gout
-            gxh = act_bwd(xh, self.spec["act"], ga)
+            gxh = act_bwd(xh, self.spec["act"], ga, pos)
             gz = batch_norm_train_bwd(z, mean, var, gxh)
             gin, gw = conv2d_same_bwd(inp, self.p[name + "/weights"], r, gz)
             g[name + "/weights"] = gw
@@ -277,9 +287,9 @@ class OracleNet(object):
             self.p[n] = self.p[n] - dt(lr) * self.mom[n]
         self.global_step += 1
 
-    def train_step(self, x, y, lr0, weight_decay, lr_factor=0.5, mask=None):
+    def train_step(self, x, y, lr0, weight_decay, lr_factor=0.5, mask=None, decisions=None):
         """sess.run([optimizer, loss, pred_up]) with is_training=True (isprs:1750-1752)."""
         lr = learning_rate(lr0, self.global_step, lr_factor)
-        loss, pred, g, logits = self.loss_and_grads(x, y, weight_decay, mask)
+        loss, pred, g, logits = self.loss_and_grads(x, y, weight_decay, mask, decisions)
         self.apply_momentum(g, lr)
         return loss, pred

@@ -91,7 +91,8 @@ def test_conv1_band_padding(lib):
     g = rng.normal(size=(B, S, S, cout)).astype(np.float32)
     xd = padded(x, 2, ld=32, coff=0)
     wp = torch.zeros(k * k * 32 * cout, dtype=torch.float32, device=DEV)
-    lib.call("drs_filter_pad_cin", dev(w).data_ptr(), wp.data_ptr(), k, C, 32, cout, stream())
+    wsrc = dev(w)
+    lib.call("drs_filter_pad_cin", wsrc.data_ptr(), wp.data_ptr(), k, C, 32, cout, stream())
     out = torch.zeros(B * S * S * cout, dtype=torch.float32, device=DEV)
     lib.call("drs_conv_forward", xd.data_ptr(), B, S, 2, 32, 0, wp.data_ptr(), None, k, 1, 2, 32, cout, out.data_ptr(), cout, 0, 0,
              None, stream())
@@ -128,7 +129,8 @@ def test_bn_act_pool_forward_backward(lib, C, pool, alpha, B, S, P):
     # statistics through the slab path the conv epilogue feeds
     part = np.stack([z.reshape(M, C).sum(axis=0), (z.reshape(M, C).astype(np.float64) ** 2).sum(axis=0)], axis=1).astype(np.float32)
     sums = torch.zeros(C * 2, dtype=torch.float64, device=DEV)
-    lib.call("drs_stats_reduce", dev(part.reshape(1, C, 2)).data_ptr(), 1, C, sums.data_ptr(), stream())
+    partd = dev(part.reshape(1, C, 2))
+    lib.call("drs_stats_reduce", partd.data_ptr(), 1, C, sums.data_ptr(), stream())
     mr = torch.zeros(C * 2, dtype=torch.float32, device=DEV)
     mm = torch.zeros(C, dtype=torch.float32, device=DEV)
     mv = torch.ones(C, dtype=torch.float32, device=DEV)
@@ -190,7 +192,8 @@ def test_bn_eval_coeffs(lib):
     C = 192
     mm, mv = rng.normal(size=C).astype(np.float32), rng.uniform(0.5, 2, size=C).astype(np.float32)
     mr = torch.zeros(C * 2, dtype=torch.float32, device=DEV)
-    lib.call("drs_bn_eval_coeffs", dev(mm).data_ptr(), dev(mv).data_ptr(), C, mr.data_ptr(), stream())
+    mmd, mvd = dev(mm), dev(mv)
+    lib.call("drs_bn_eval_coeffs", mmd.data_ptr(), mvd.data_ptr(), C, mr.data_ptr(), stream())
     h = mr.cpu().numpy().reshape(C, 2)
     np.testing.assert_array_equal(h[:, 0], mm)
     assert rel_err(h[:, 1], 1 / np.sqrt(mv.astype(np.float64) + 1e-3)) < 1e-6
@@ -218,8 +221,9 @@ def test_classifier_loss(lib, C, K, B, S, P, masked):
     lp = torch.zeros(rows, dtype=torch.float64, device=DEV)
     conf = torch.zeros(K * K, dtype=torch.int32, device=DEV)
     yd, amd = dev(y.reshape(-1)), dev(am.reshape(-1))
+    wdev, bdev = dev(w), dev(bias)
     lmd = dev(lm.reshape(-1)) if masked else None
-    lib.call("drs_classifier_loss", fd.data_ptr(), B, S, P, C, 0, C, K, dev(w).data_ptr(), dev(bias).data_ptr(), yd.data_ptr(),
+    lib.call("drs_classifier_loss", fd.data_ptr(), B, S, P, C, 0, C, K, wdev.data_ptr(), bdev.data_ptr(), yd.data_ptr(),
              lmd.data_ptr() if masked else None, amd.data_ptr(), 1.0 / n, logits.data_ptr(), pred.data_ptr(), gfeat.data_ptr(), C, 0,
              dwp.data_ptr(), dbp.data_ptr(), lp.data_ptr(), conf.data_ptr(), stream())
     dw = torch.zeros(C * K, dtype=torch.float32, device=DEV)
@@ -246,7 +250,7 @@ def test_classifier_loss(lib, C, K, B, S, P, masked):
     np.testing.assert_array_equal(conf.cpu().numpy().reshape(K, K), cm)
     # inference form: no labels
     pred2 = torch.zeros(M, dtype=torch.uint8, device=DEV)
-    lib.call("drs_classifier_loss", fd.data_ptr(), B, S, P, C, 0, C, K, dev(w).data_ptr(), dev(bias).data_ptr(), None, None, None, 0.0,
+    lib.call("drs_classifier_loss", fd.data_ptr(), B, S, P, C, 0, C, K, wdev.data_ptr(), bdev.data_ptr(), None, None, None, 0.0,
              None, pred2.data_ptr(), None, 0, 0, None, None, None, None, stream())
     torch.cuda.synchronize()
     np.testing.assert_array_equal(pred2.cpu().numpy().reshape(B, S, S), ph)
@@ -262,7 +266,8 @@ def test_momentum_l2_confusion(lib):
     lib.call("drs_momentum_update", wd_.data_ptr(), gd_.data_ptr(), ad_.data_ptr(), n, nd, 0.01, 0.005, 0.9, 1.0, stream())
     sc = torch.zeros(256, dtype=torch.float64, device=DEV)
     out = torch.zeros(1, dtype=torch.float64, device=DEV)
-    lib.call("drs_l2_loss", dev(w).data_ptr(), nd, sc.data_ptr(), out.data_ptr(), stream())
+    w2 = dev(w)
+    lib.call("drs_l2_loss", w2.data_ptr(), nd, sc.data_ptr(), out.data_ptr(), stream())
     torch.cuda.synchronize()
     gg = g.astype(np.float64) + np.where(np.arange(n) < nd, 0.005 * w.astype(np.float64), 0)
     acc = 0.9 * a.astype(np.float64) + gg
@@ -274,7 +279,8 @@ def test_momentum_l2_confusion(lib):
     p = rng.integers(0, K, size=50000).astype(np.uint8)
     m = rng.integers(0, 2, size=50000).astype(np.uint8)
     conf = torch.zeros(K * K, dtype=torch.int32, device=DEV)
-    lib.call("drs_confusion", dev(y).data_ptr(), dev(p).data_ptr(), dev(m).data_ptr(), 50000, K, 6, conf.data_ptr(), stream())
+    yd, pd_, md = dev(y), dev(p), dev(m)
+    lib.call("drs_confusion", yd.data_ptr(), pd_.data_ptr(), md.data_ptr(), 50000, K, 6, conf.data_ptr(), stream())
     torch.cuda.synchronize()
     cm = np.zeros((K, K), dtype=np.int64)
     keep = (m > 0) & (y != 6)

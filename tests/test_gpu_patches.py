@@ -98,7 +98,9 @@ def test_stitch_matches_reference_order(h, w, S, K, bs):
         lg = rng.normal(size=(len(pos), S, S, K)).astype(np.float32)
         batches.append((lg, pos))
         np.testing.assert_array_equal(P.window_positions(h, w, S, st, i, bs), np.asarray(pos).astype(np.int64))
-        _lib.call("drs_stitch_accumulate", prob.data_ptr(), occ.data_ptr(), dev(lg).data_ptr(), h, w, K, S, st, i * bs, len(pos), stream())
+        lgd = dev(lg)
+        _lib.call("drs_stitch_accumulate", prob.data_ptr(), occ.data_ptr(), lgd.data_ptr(), h, w, K, S, st, i * bs, len(pos), stream())
+        torch.cuda.synchronize()
     out = torch.zeros(h * w, dtype=torch.uint8, device=DEV)
     _lib.call("drs_stitch_finalize", prob.data_ptr(), occ.data_ptr(), h, w, K, out.data_ptr(), stream())
     torch.cuda.synchronize()
