@@ -39,9 +39,13 @@ def cpu_baseline(seconds_budget=25.0):
     from oracle.torch_ref import TorchNet
     from oracle import host_ref as H
     from drs_amd.synthetic import make_tile, grid_instances
-    ncores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    ncores = max(1, min(avail, 16))       # the GPU box gives one GPU a 16-core share of the host
     torch.set_num_threads(ncores)
-    B = 16
+    B = 8
     tile, lab = make_tile(512, 512, CHANNELS, CLASSES, seed=1234)
     inst = grid_instances(512, 512, PATCH, 25, B * 8, seed=0)
     mean, std = [0.5, 0.5, 0.5, 0, 0], [0.1, 0.1, 0.1, 1, 1]

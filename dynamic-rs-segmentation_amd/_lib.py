@@ -17,7 +17,8 @@ SIGNATURES = {
     "drs_conv_wgrad": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "drs_filter_flip_transpose": (_i, [_p, _p, _i, _i, _i, _p]),
     "drs_filter_pad_cin": (_i, [_p, _p, _i, _i, _i, _i, _p]),
-    "drs_stats_reduce": (_i, [_p, _i, _i, _p, _p]),
+    "drs_colsum_scratch_doubles": (_i, [_i]),
+    "drs_stats_reduce": (_i, [_p, _i, _i, _p, _p, _p]),
     "drs_bn_finish": (_i, [_p, _d, _i, _p, _p, _p, _d, _i, _p]),
     "drs_bn_eval_coeffs": (_i, [_p, _p, _i, _p, _p]),
     "drs_bn_act_pool_forward": (_i, [_p, _i, _i, _i, _p, _f, _i, _p, _i, _i, _i, _p, _p]),
@@ -27,7 +28,7 @@ SIGNATURES = {
     "drs_classifier_rows": (_i, [_i, _i]),
     "drs_classifier_loss": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _p, _p, _p,
                                  _p, _p]),
-    "drs_rows_reduce_f32": (_i, [_p, _i, _i, _p, _p]),
+    "drs_rows_reduce_f32": (_i, [_p, _i, _i, _p, _p, _p]),
     "drs_sum_f64": (_i, [_p, _i, _p, _p]),
     "drs_l2_loss": (_i, [_p, _sz, _p, _p, _p]),
     "drs_momentum_update": (_i, [_p, _p, _p, _sz, _sz, _f, _f, _f, _f, _p]),
@@ -54,6 +55,9 @@ def load():
     if not os.path.isfile(LIB_PATH):
         raise DrsError("HIP library not built: %s is missing (run dynamic-rs-segmentation_amd/csrc/build.sh "
                        "or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    # PyTorch supplies device memory and streams, so the library must share ITS HIP runtime: import torch first
+    # (libdrs_hip.so then binds to the already-loaded libamdhip64.so.7 instead of pulling in a second copy)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol

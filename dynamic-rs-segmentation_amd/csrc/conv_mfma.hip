@@ -346,14 +346,14 @@ __global__ void pad_cin_kernel(const float* __restrict__ w, float* __restrict__ 
 template <int BM, int BN, int WM, int WN>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
   const int mt = (a.M + BM - 1) / BM, nt = a.Cout / BN;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(mt * nt), dim3(256), 0, st, a);
+  DRS_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN>), dim3(mt * nt), dim3(256), 0, st, a);
   return DRS_LAUNCH_CHECK();
 }
 
 template <int TR, int TO>
 int launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t st) {
   constexpr int NT = 64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1);
-  hipLaunchKernelGGL((wgrad_kernel<TR, TO>), dim3(nsplit * a.ntr * a.nto), dim3(NT), 0, st, a);
+  DRS_LAUNCH((wgrad_kernel<TR, TO>), dim3(nsplit * a.ntr * a.nto), dim3(NT), 0, st, a);
   return DRS_LAUNCH_CHECK();
 }
 
@@ -430,7 +430,7 @@ int drs_conv_wgrad(const float* x, int B, int S, int Px, int ld_x, int coff_x, c
   else rc = launch_wgrad<32, 32>(a, nsplit, st);
   if (rc) return rc;
   const int n = k * k * cin_real * cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), dim3(256), 0, st, slab,
+  DRS_LAUNCH(wgrad_reduce_kernel, dim3((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), dim3(256), 0, st, slab,
                      grad, nsplit, k * k, cin, cin_real, cout);
   return DRS_LAUNCH_CHECK();
 }
@@ -438,7 +438,7 @@ int drs_conv_wgrad(const float* x, int B, int S, int Px, int ld_x, int coff_x, c
 int drs_filter_flip_transpose(const float* w, float* wt, int k, int cin, int cout, void* stream) {
   if (!w || !wt) return DRS_ERR_ARG;
   const int n = k * k * cin * cout;
-  hipLaunchKernelGGL(flip_transpose_kernel, dim3((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), dim3(256), 0,
+  DRS_LAUNCH(flip_transpose_kernel, dim3((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), dim3(256), 0,
                      (hipStream_t)stream, w, wt, k, cin, cout);
   return DRS_LAUNCH_CHECK();
 }
@@ -446,7 +446,7 @@ int drs_filter_flip_transpose(const float* w, float* wt, int k, int cin, int cou
 int drs_filter_pad_cin(const float* w, float* wp, int k, int cin, int cin_pad, int cout, void* stream) {
   if (!w || !wp || cin_pad < cin) return DRS_ERR_ARG;
   const int n = k * k * cin_pad * cout;
-  hipLaunchKernelGGL(pad_cin_kernel, dim3((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), dim3(256), 0,
+  DRS_LAUNCH(pad_cin_kernel, dim3((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), dim3(256), 0,
                      (hipStream_t)stream, w, wp, k * k, cin, cin_pad, cout);
   return DRS_LAUNCH_CHECK();
 }

@@ -48,3 +48,5 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 static inline int drs_check(hipError_t e) { return e == hipSuccess ? DRS_OK : DRS_ERR_HIP; }
 #define DRS_LAUNCH_CHECK() drs_check(hipGetLastError())
+// launch with the thread's sticky "last error" cleared first, so that DRS_LAUNCH_CHECK reports this launch only
+#define DRS_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)

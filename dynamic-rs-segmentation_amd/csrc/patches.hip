@@ -193,8 +193,8 @@ int drs_crop_normalize(const void* tiles, int tiles_are_f64, const unsigned char
   for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.stdv[c] = std3[c]; }
   a.out = out; a.S = S; a.P = P; a.ld = ld; a.out_lab = out_lab; a.out_mask = out_mask;
   dim3 grid((Sp + 63) / 64, B * Sp);
-  if (tiles_are_f64) hipLaunchKernelGGL(crop_kernel<double>, grid, dim3(64), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(crop_kernel<float>, grid, dim3(64), 0, (hipStream_t)stream, a);
+  if (tiles_are_f64) DRS_LAUNCH(crop_kernel<double>, grid, dim3(64), 0, (hipStream_t)stream, a);
+  else DRS_LAUNCH(crop_kernel<float>, grid, dim3(64), 0, (hipStream_t)stream, a);
   return DRS_LAUNCH_CHECK();
 }
 
@@ -212,7 +212,7 @@ int drs_stitch_accumulate(float* prob, unsigned int* occur, const float* logits,
   const int y1 = (r_last * stride < h - S ? r_last * stride : h - S) + S;
   a.row0 = y0; a.nrows = y1 - y0;
   dim3 grid((w + 255) / 256, a.nrows);
-  hipLaunchKernelGGL(stitch_accumulate_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  DRS_LAUNCH(stitch_accumulate_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   return DRS_LAUNCH_CHECK();
 }
 
@@ -220,7 +220,7 @@ int drs_stitch_finalize(const float* prob, const unsigned int* occur, int h, int
   if (!prob || !occur || !out || K < 1 || K > 8) return DRS_ERR_ARG;
   const size_t n = (size_t)h * w;
   const size_t nb = (n + 255) / 256;
-  hipLaunchKernelGGL(stitch_finalize_kernel, dim3(nb < 4096 ? (unsigned)nb : 4096u), dim3(256), 0, (hipStream_t)stream, prob, occur,
+  DRS_LAUNCH(stitch_finalize_kernel, dim3(nb < 4096 ? (unsigned)nb : 4096u), dim3(256), 0, (hipStream_t)stream, prob, occur,
                      n, K, out);
   return DRS_LAUNCH_CHECK();
 }

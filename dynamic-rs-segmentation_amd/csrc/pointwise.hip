@@ -18,18 +18,36 @@ constexpr float BN_EPS = 0.001f;
 __device__ __forceinline__ float act(float x, float alpha) { return fmaxf(alpha * x, x); }   // alpha = 0 -> ReLU
 
 // ------------------------------------------------------------------------------------------------ BN statistics
-// partial[row][c][2] (fp32, one row per conv M tile / per reduce workgroup) -> sums[c][2] in fp64, fixed order
-__global__ void stats_reduce_kernel(const float* __restrict__ partial, int nrows, int C, double* __restrict__ sums) {
+// Column sums of a row-major fp32 slab [nrows][ncols] in a FIXED order (bitwise reproducible), accumulated in fp64:
+// level 1: COLSUM_BLOCKS row bands x 4 row lanes per band -> scratch[COLSUM_BLOCKS][ncols] (fp64);
+// level 2: one thread per column adds the bands in order.  Used for the batch-norm statistic slabs
+// (ncols = 2*C: per channel (sum, sum of squares) or (sum g, sum g*xhat)) and for the classifier gradient slabs.
+constexpr int COLSUM_BLOCKS = 32;
+
+__global__ void colsum_l1_kernel(const float* __restrict__ in, int nrows, int ncols, double* __restrict__ scratch) {
+  __shared__ double sh[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const int rpb = (nrows + COLSUM_BLOCKS - 1) / COLSUM_BLOCKS;
+  const int r0 = blockIdx.y * rpb;
+  int r1 = r0 + rpb;
+  r1 = r1 < nrows ? r1 : nrows;
+  double s = 0.0;
+  if (c < ncols)
+    for (int r = r0 + ty; r < r1; r += 4) s += (double)in[(size_t)r * ncols + c];
+  sh[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < ncols) scratch[(size_t)blockIdx.y * ncols + c] = ((sh[0][tx] + sh[1][tx]) + sh[2][tx]) + sh[3][tx];
+}
+
+template <typename OUT>
+__global__ void colsum_l2_kernel(const double* __restrict__ scratch, int ncols, OUT* __restrict__ out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < nrows; ++r) {
-    const float2 v = *reinterpret_cast<const float2*>(partial + ((size_t)r * C + c) * 2);
-    s1 += (double)v.x;
-    s2 += (double)v.y;
-  }
-  sums[2 * c] = s1;
-  sums[2 * c + 1] = s2;
+  if (c >= ncols) return;
+  double s = 0.0;
+#pragma unroll 4
+  for (int b = 0; b < COLSUM_BLOCKS; ++b) s += scratch[(size_t)b * ncols + c];
+  out[c] = (OUT)s;
 }
 
 // sums (global over the batch, all ranks) -> mean, rstd; moving averages updated as
@@ -355,14 +373,6 @@ __global__ __launch_bounds__(256) void classifier_loss_kernel(const ClsArgs a) {
   }
 }
 
-// out[j] = sum_i in[i][j], fixed order
-__global__ void rows_reduce_f32_kernel(const float* __restrict__ in, int nrows, int ncols, float* __restrict__ out) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= ncols) return;
-  float s = 0.f;
-  for (int i = 0; i < nrows; ++i) s += in[(size_t)i * ncols + j];
-  out[j] = s;
-}
 __global__ void sum_f64_kernel(const double* __restrict__ in, int n, double* __restrict__ out) {
   __shared__ double sh[256];
   double s = 0.0;
@@ -433,23 +443,27 @@ inline ActView mkview(float* base, int S, int P, int ld, int coff) {
 
 extern "C" {
 
-int drs_stats_reduce(const float* partial, int nrows, int C, double* sums, void* stream) {
-  if (!partial || !sums || nrows < 1) return DRS_ERR_ARG;
-  hipLaunchKernelGGL(stats_reduce_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, nrows, C, sums);
+int drs_colsum_scratch_doubles(int ncols) { return COLSUM_BLOCKS * ncols; }
+
+int drs_stats_reduce(const float* partial, int nrows, int C, double* sums, double* scratch, void* stream) {
+  if (!partial || !sums || !scratch || nrows < 1) return DRS_ERR_ARG;
+  const int ncols = 2 * C;
+  DRS_LAUNCH(colsum_l1_kernel, dim3((ncols + 63) / 64, COLSUM_BLOCKS), dim3(256), 0, (hipStream_t)stream, partial, nrows, ncols, scratch);
+  DRS_LAUNCH(colsum_l2_kernel<double>, dim3((ncols + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, ncols, sums);
   return DRS_LAUNCH_CHECK();
 }
 
 int drs_bn_finish(const double* sums, double count, int C, float* mean_rstd, float* moving_mean, float* moving_var,
                   double decay, int bessel, void* stream) {
   if (!sums || !mean_rstd || count < 1.0) return DRS_ERR_ARG;
-  hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, count, C, mean_rstd,
+  DRS_LAUNCH(bn_finish_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, count, C, mean_rstd,
                      moving_mean, moving_var, (float)(1.0 - decay), bessel);
   return DRS_LAUNCH_CHECK();
 }
 
 int drs_bn_eval_coeffs(const float* moving_mean, const float* moving_var, int C, float* mean_rstd, void* stream) {
   if (!moving_mean || !moving_var || !mean_rstd) return DRS_ERR_ARG;
-  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, moving_mean, moving_var, C,
+  DRS_LAUNCH(bn_eval_coeffs_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, moving_mean, moving_var, C,
                      mean_rstd);
   return DRS_LAUNCH_CHECK();
 }
@@ -463,14 +477,14 @@ int drs_bn_act_pool_forward(const float* z, int B, int S, int C, const float* me
   dim3 grid((per_row + 255) / 256, B * Sp);
   ActView v = mkview(out, S, P_out, ld_out, coff_out);
   if (pool)
-    hipLaunchKernelGGL(bn_act_pool_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, z, B, S, C, mean_rstd, alpha, v, argmax);
+    DRS_LAUNCH(bn_act_pool_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, z, B, S, C, mean_rstd, alpha, v, argmax);
   else
-    hipLaunchKernelGGL(bn_act_pool_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, z, B, S, C, mean_rstd, alpha, v, argmax);
+    DRS_LAUNCH(bn_act_pool_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, z, B, S, C, mean_rstd, alpha, v, argmax);
   return DRS_LAUNCH_CHECK();
 }
 
 // rows of the slab drs_bn_backward_reduce writes (partial must hold rows * C * 2 floats)
-int drs_bn_backward_rows(int B, int S) { return (B * S * S + 63) / 64; }
+int drs_bn_backward_rows(int B, int S) { return (B * S * S + 255) / 256; }
 
 int drs_bn_backward_reduce(const float* ga, int ld_ga, int coff_ga, const float* z, const unsigned char* argmax, int B, int S,
                            int C, const float* mean_rstd, float alpha, int pool, float* gxhat, float* partial, void* stream) {
@@ -481,11 +495,11 @@ int drs_bn_backward_reduce(const float* ga, int ld_ga, int coff_ga, const float*
   const int nblk = drs_bn_backward_rows(B, S);
   const size_t shm = (size_t)PT * C * 2 * sizeof(float);
   if (pool)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(CQ * PT), shm, (hipStream_t)stream, ga, ld_ga, coff_ga, z,
-                       argmax, B, S, C, mean_rstd, alpha, gxhat, partial, 64);
+    DRS_LAUNCH(bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(CQ * PT), shm, (hipStream_t)stream, ga, ld_ga, coff_ga, z,
+                       argmax, B, S, C, mean_rstd, alpha, gxhat, partial, 256);
   else
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(CQ * PT), shm, (hipStream_t)stream, ga, ld_ga, coff_ga, z,
-                       argmax, B, S, C, mean_rstd, alpha, gxhat, partial, 64);
+    DRS_LAUNCH(bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(CQ * PT), shm, (hipStream_t)stream, ga, ld_ga, coff_ga, z,
+                       argmax, B, S, C, mean_rstd, alpha, gxhat, partial, 256);
   return DRS_LAUNCH_CHECK();
 }
 
@@ -496,7 +510,7 @@ int drs_bn_backward_apply(const float* gxhat, const float* z, int B, int S, int 
   if ((long long)B * Sp > 65535) return DRS_ERR_ARG;
   const int per_row = Sp * (C / 4);
   dim3 grid((per_row + 255) / 256, B * Sp);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, gxhat, z, B, S, C, mean_rstd, sums, count,
+  DRS_LAUNCH(bn_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, gxhat, z, B, S, C, mean_rstd, sums, count,
                      mkview(gz, S, P_out, ld_out, coff_out));
   return DRS_LAUNCH_CHECK();
 }
@@ -522,34 +536,35 @@ int drs_classifier_loss(const float* feat, int B, int S, int P, int ld, int coff
   const int nblk = drs_classifier_rows(B, S);
   hipStream_t st = (hipStream_t)stream;
   switch (C / 64) {
-    case 1: hipLaunchKernelGGL(classifier_loss_kernel<1>, dim3(nblk), dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL(classifier_loss_kernel<2>, dim3(nblk), dim3(256), 0, st, a); break;
-    case 3: hipLaunchKernelGGL(classifier_loss_kernel<3>, dim3(nblk), dim3(256), 0, st, a); break;
-    case 4: hipLaunchKernelGGL(classifier_loss_kernel<4>, dim3(nblk), dim3(256), 0, st, a); break;
-    case 5: hipLaunchKernelGGL(classifier_loss_kernel<5>, dim3(nblk), dim3(256), 0, st, a); break;
-    case 6: hipLaunchKernelGGL(classifier_loss_kernel<6>, dim3(nblk), dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL(classifier_loss_kernel<7>, dim3(nblk), dim3(256), 0, st, a); break;
+    case 1: DRS_LAUNCH(classifier_loss_kernel<1>, dim3(nblk), dim3(256), 0, st, a); break;
+    case 2: DRS_LAUNCH(classifier_loss_kernel<2>, dim3(nblk), dim3(256), 0, st, a); break;
+    case 3: DRS_LAUNCH(classifier_loss_kernel<3>, dim3(nblk), dim3(256), 0, st, a); break;
+    case 4: DRS_LAUNCH(classifier_loss_kernel<4>, dim3(nblk), dim3(256), 0, st, a); break;
+    case 5: DRS_LAUNCH(classifier_loss_kernel<5>, dim3(nblk), dim3(256), 0, st, a); break;
+    case 6: DRS_LAUNCH(classifier_loss_kernel<6>, dim3(nblk), dim3(256), 0, st, a); break;
+    default: DRS_LAUNCH(classifier_loss_kernel<7>, dim3(nblk), dim3(256), 0, st, a); break;
   }
   return DRS_LAUNCH_CHECK();
 }
 
-int drs_rows_reduce_f32(const float* in, int nrows, int ncols, float* out, void* stream) {
-  if (!in || !out) return DRS_ERR_ARG;
-  hipLaunchKernelGGL(rows_reduce_f32_kernel, dim3((ncols + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, nrows, ncols, out);
+int drs_rows_reduce_f32(const float* in, int nrows, int ncols, float* out, double* scratch, void* stream) {
+  if (!in || !out || !scratch || nrows < 1) return DRS_ERR_ARG;
+  DRS_LAUNCH(colsum_l1_kernel, dim3((ncols + 63) / 64, COLSUM_BLOCKS), dim3(256), 0, (hipStream_t)stream, in, nrows, ncols, scratch);
+  DRS_LAUNCH(colsum_l2_kernel<float>, dim3((ncols + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, ncols, out);
   return DRS_LAUNCH_CHECK();
 }
 
 int drs_sum_f64(const double* in, int n, double* out, void* stream) {
   if (!in || !out) return DRS_ERR_ARG;
-  hipLaunchKernelGGL(sum_f64_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, in, n, out);
+  DRS_LAUNCH(sum_f64_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, in, n, out);
   return DRS_LAUNCH_CHECK();
 }
 
 // l2 = 0.5 * sum(w[0..n)^2) -> out[0] (fp64); scratch holds 256 doubles
 int drs_l2_loss(const float* w, size_t n, double* scratch, double* out, void* stream) {
   if (!w || !scratch || !out) return DRS_ERR_ARG;
-  hipLaunchKernelGGL(l2_partial_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, w, n, scratch);
-  hipLaunchKernelGGL(sum_f64_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, 256, out);
+  DRS_LAUNCH(l2_partial_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, w, n, scratch);
+  DRS_LAUNCH(sum_f64_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, 256, out);
   return DRS_LAUNCH_CHECK();
 }
 
@@ -557,7 +572,7 @@ int drs_momentum_update(float* w, const float* grad, float* accum, size_t n, siz
                         float momentum, float grad_scale, void* stream) {
   if (!w || !grad || !accum) return DRS_ERR_ARG;
   const size_t nb = (n + 255) / 256;
-  hipLaunchKernelGGL(momentum_kernel, dim3(nb < 2048 ? (unsigned)nb : 2048u), dim3(256), 0, (hipStream_t)stream, w, grad, accum, n,
+  DRS_LAUNCH(momentum_kernel, dim3(nb < 2048 ? (unsigned)nb : 2048u), dim3(256), 0, (hipStream_t)stream, w, grad, accum, n,
                      n_decay, lr, weight_decay, momentum, grad_scale);
   return DRS_LAUNCH_CHECK();
 }
@@ -566,7 +581,7 @@ int drs_confusion(const unsigned char* labels, const unsigned char* pred, const 
                   int ignore_label, unsigned int* conf, void* stream) {
   if (!labels || !pred || !conf || K < 1 || K > 8) return DRS_ERR_ARG;
   const size_t nb = (n + 255) / 256;
-  hipLaunchKernelGGL(confusion_kernel, dim3(nb < 1024 ? (unsigned)nb : 1024u), dim3(256), 0, (hipStream_t)stream, labels, pred, mask,
+  DRS_LAUNCH(confusion_kernel, dim3(nb < 1024 ? (unsigned)nb : 1024u), dim3(256), 0, (hipStream_t)stream, labels, pred, mask,
                      n, K, ignore_label, conf);
   return DRS_LAUNCH_CHECK();
 }

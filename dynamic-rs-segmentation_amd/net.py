@@ -174,6 +174,7 @@ class DilatedNet(object):
         cmax = max(max(L.cout for L in p.layers), max(L.cin_k for L in p.layers[1:]))
         hmax = max(L.halo for L in p.layers)
         self.sums = torch.zeros(cmax * 2, **f64)
+        self.colsum_scratch = torch.zeros(_lib.query("drs_colsum_scratch_doubles", max(2 * cmax, p.c_last * p.K)), **f64)
         rows_fwd = max((M + _lib.query("drs_conv_mtile", L.cout) - 1) // _lib.query("drs_conv_mtile", L.cout)
                        for L in p.layers)
         rows_bwd = _lib.query("drs_bn_backward_rows", B, S)
@@ -295,7 +296,7 @@ class DilatedNet(object):
             mm, mv = self.bn[bo:bo + L.cout], self.bn[bo + L.cout:bo + 2 * L.cout]
             if training:
                 mt = _lib.query("drs_conv_mtile", L.cout)
-                _lib.call("drs_stats_reduce", _ptr(self.partial), (M + mt - 1) // mt, L.cout, _ptr(self.sums), st)
+                _lib.call("drs_stats_reduce", _ptr(self.partial), (M + mt - 1) // mt, L.cout, _ptr(self.sums), _ptr(self.colsum_scratch), st)
                 self.comm.all_reduce_sum(self.sums[:2 * L.cout])           # sync batch norm over the global batch
                 _lib.call("drs_bn_finish", _ptr(self.sums), float(count), L.cout, _ptr(self.mean_rstd[i]), _ptr(mm), _ptr(mv),
                           BN_DECAY, self.bessel, st)
@@ -364,8 +365,8 @@ class DilatedNet(object):
                   _ptr(self.pred), _ptr(gfeat), ldg, cg, _ptr(self.dw_partial), _ptr(self.db_partial), _ptr(self.loss_partial),
                   _ptr(self.conf), st)
         crow = _lib.query("drs_classifier_rows", B, S)
-        _lib.call("drs_rows_reduce_f32", _ptr(self.dw_partial), crow, p.c_last * p.K, self.grads[woff:].data_ptr(), st)
-        _lib.call("drs_rows_reduce_f32", _ptr(self.db_partial), crow, p.K, self.grads[boff:].data_ptr(), st)
+        _lib.call("drs_rows_reduce_f32", _ptr(self.dw_partial), crow, p.c_last * p.K, self.grads[woff:].data_ptr(), _ptr(self.colsum_scratch), st)
+        _lib.call("drs_rows_reduce_f32", _ptr(self.db_partial), crow, p.K, self.grads[boff:].data_ptr(), _ptr(self.colsum_scratch), st)
         _lib.call("drs_sum_f64", _ptr(self.loss_partial), crow, _ptr(self.scalars), st)
         _lib.call("drs_l2_loss", _ptr(self.params), p.n_decay, _ptr(self.l2_scratch), self.scalars[1:].data_ptr(), st)
         # reverse loop over the conv blocks
@@ -378,7 +379,8 @@ class DilatedNet(object):
             self._k("bn_bwd_reduce", M * L.cout * (13.0 if p.pool else 12.0), "drs_bn_backward_reduce", _ptr(gcur), ldc, cc,
                     _ptr(self.z[i]), _ptr(self.idx[i]), B, S, L.cout, _ptr(self.mean_rstd[i]), p.alpha, 1 if p.pool else 0,
                     _ptr(self.gxh), _ptr(self.partial), st)
-            _lib.call("drs_stats_reduce", _ptr(self.partial), _lib.query("drs_bn_backward_rows", B, S), L.cout, _ptr(self.sums), st)
+            _lib.call("drs_stats_reduce", _ptr(self.partial), _lib.query("drs_bn_backward_rows", B, S), L.cout, _ptr(self.sums),
+                      _ptr(self.colsum_scratch), st)
             self.comm.all_reduce_sum(self.sums[:2 * L.cout])
             self._k("bn_bwd_apply", M * L.cout * 12.0, "drs_bn_backward_apply", _ptr(self.gxh), _ptr(self.z[i]), B, S, L.cout,
                     _ptr(self.mean_rstd[i]), _ptr(self.sums), n_bn, _ptr(self.gz), L.halo, L.cout, 0, st)

@@ -61,12 +61,14 @@ int drs_filter_flip_transpose(const float* w, float* wt, int k, int cin, int cou
 int drs_filter_pad_cin(const float* w, float* wp, int k, int cin, int cin_pad, int cout, void* stream);
 
 /* ---- tf.contrib.layers.batch_norm(center=False, scale=False, eps=1e-3, decay=0.999)  (isprs:655-663) -----
- * drs_stats_reduce : partial[nrows][C][2] (fp32) -> sums[C][2] (fp64), fixed order.  Under data parallelism
- *                    the caller all-reduces `sums` between this call and the next (sync batch norm).
+ * drs_stats_reduce : partial[nrows][C][2] (fp32) -> sums[C][2] (fp64), fixed order; scratch holds
+ *                    drs_colsum_scratch_doubles(2*C) doubles.  Under data parallelism the caller all-reduces
+ *                    `sums` between this call and the next (sync batch norm).
  * drs_bn_finish    : sums, count -> mean_rstd[C][2] = (mean, 1/sqrt(biased var + eps)); if moving_* != NULL,
  *                    moving -= (moving - batch) * (1 - decay) with the Bessel-corrected variance when bessel.
  * drs_bn_eval_coeffs: is_training=False branch: mean_rstd from the moving statistics. */
-int drs_stats_reduce(const float* partial, int nrows, int C, double* sums, void* stream);
+int drs_colsum_scratch_doubles(int ncols);
+int drs_stats_reduce(const float* partial, int nrows, int C, double* sums, double* scratch, void* stream);
 int drs_bn_finish(const double* sums, double count, int C, float* mean_rstd, float* moving_mean, float* moving_var,
                   double decay, int bessel, void* stream);
 int drs_bn_eval_coeffs(const float* moving_mean, const float* moving_var, int C, float* mean_rstd, void* stream);
@@ -104,8 +106,8 @@ int drs_classifier_loss(const float* feat, int B, int S, int P, int ld, int coff
                         int ld_g, int coff_g, float* dw_partial, float* db_partial, double* loss_partial,
                         unsigned int* conf, void* stream);
 
-/* fixed-order column sums / scalar sums used on the slabs above */
-int drs_rows_reduce_f32(const float* in, int nrows, int ncols, float* out, void* stream);
+/* fixed-order column sums (scratch: drs_colsum_scratch_doubles(ncols) doubles) / scalar sums used on the slabs above */
+int drs_rows_reduce_f32(const float* in, int nrows, int ncols, float* out, double* scratch, void* stream);
 int drs_sum_f64(const double* in, int n, double* out, void* stream);
 /* tf.nn.l2_loss over the kernels (isprs:646-651): out[0] = 0.5 * sum w^2; scratch = 256 doubles */
 int drs_l2_loss(const float* w, size_t n, double* scratch, double* out, void* stream);

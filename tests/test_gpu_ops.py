@@ -130,7 +130,8 @@ def test_bn_act_pool_forward_backward(lib, C, pool, alpha, B, S, P):
     part = np.stack([z.reshape(M, C).sum(axis=0), (z.reshape(M, C).astype(np.float64) ** 2).sum(axis=0)], axis=1).astype(np.float32)
     sums = torch.zeros(C * 2, dtype=torch.float64, device=DEV)
     partd = dev(part.reshape(1, C, 2))
-    lib.call("drs_stats_reduce", partd.data_ptr(), 1, C, sums.data_ptr(), stream())
+    scr = torch.zeros(lib.query("drs_colsum_scratch_doubles", 2 * C), dtype=torch.float64, device=DEV)
+    lib.call("drs_stats_reduce", partd.data_ptr(), 1, C, sums.data_ptr(), scr.data_ptr(), stream())
     mr = torch.zeros(C * 2, dtype=torch.float32, device=DEV)
     mm = torch.zeros(C, dtype=torch.float32, device=DEV)
     mv = torch.ones(C, dtype=torch.float32, device=DEV)
@@ -174,7 +175,7 @@ def test_bn_act_pool_forward_backward(lib, C, pool, alpha, B, S, P):
     lib.call("drs_bn_backward_reduce", gad.data_ptr(), C + 16, 16, zd.data_ptr(), idx.data_ptr() if pool else None, B, S, C,
              mr.data_ptr(), alpha, pool, gxh.data_ptr(), partial.data_ptr(), stream())
     bs = torch.zeros(C * 2, dtype=torch.float64, device=DEV)
-    lib.call("drs_stats_reduce", partial.data_ptr(), rows, C, bs.data_ptr(), stream())
+    lib.call("drs_stats_reduce", partial.data_ptr(), rows, C, bs.data_ptr(), scr.data_ptr(), stream())
     Pg = 3
     gz = torch.full((B * (S + 2 * Pg) ** 2 * C,), 9.0, dtype=torch.float32, device=DEV)
     lib.call("drs_bn_backward_apply", gxh.data_ptr(), zd.data_ptr(), B, S, C, mr.data_ptr(), bs.data_ptr(), float(M), gz.data_ptr(),
@@ -229,8 +230,9 @@ def test_classifier_loss(lib, C, K, B, S, P, masked):
     dw = torch.zeros(C * K, dtype=torch.float32, device=DEV)
     db = torch.zeros(K, dtype=torch.float32, device=DEV)
     ls = torch.zeros(1, dtype=torch.float64, device=DEV)
-    lib.call("drs_rows_reduce_f32", dwp.data_ptr(), rows, C * K, dw.data_ptr(), stream())
-    lib.call("drs_rows_reduce_f32", dbp.data_ptr(), rows, K, db.data_ptr(), stream())
+    scr = torch.zeros(lib.query("drs_colsum_scratch_doubles", C * K), dtype=torch.float64, device=DEV)
+    lib.call("drs_rows_reduce_f32", dwp.data_ptr(), rows, C * K, dw.data_ptr(), scr.data_ptr(), stream())
+    lib.call("drs_rows_reduce_f32", dbp.data_ptr(), rows, K, db.data_ptr(), scr.data_ptr(), stream())
     lib.call("drs_sum_f64", lp.data_ptr(), rows, ls.data_ptr(), stream())
     torch.cuda.synchronize()
     f64 = feat.astype(np.float64)
