@@ -190,7 +190,7 @@ struct WgradArgs {
 };
 
 template <int TR, int TO>
-__global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1)) void wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) void wgrad_kernel(const WgradArgs a) {
   constexpr int WR = TR >= 64 ? 2 : 1, WC = TO >= 64 ? 2 : 1;
   constexpr int NT = 64 * WR * WC;
   constexpr int WTR = TR / WR, WTO = TO / WC;
@@ -200,8 +200,10 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1)) void 
   constexpr int XQ = TR / 4, GQ = TO / 4;     // float4 per pixel row
   constexpr int NX = BP * XQ / NT, NG = BP * GQ / NT;
   constexpr int XPS = NT / XQ, GPS = NT / GQ; // pixel stride between a thread's successive loads
+  constexpr uint32_t INVALID = 0xffffffffu;
 
   __shared__ __attribute__((aligned(16))) float lds[BP * LDX + BP * LDG];
+  __shared__ uint32_t tabx[2][BP], tabg[2][BP];   // padded element offsets of the chunk's pixels (per-chunk, double-buffered)
   float* Xs = lds;
   float* Gs = lds + BP * LDX;
 
@@ -237,25 +239,27 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1)) void 
   int cend = cbeg + a.chunks_per_split;
   cend = cend < nchunks_total ? cend : nchunks_total;
 
+  // the pixel -> padded-offset arithmetic (two divisions per pixel) is done once per chunk by BP threads, not by
+  // every thread for every load: the first BP threads fill the tables for chunk `chunk` into slot `chunk & 1`
+  auto fill_tables = [&](int chunk) {
+    if (t < BP && chunk < cend) {
+      const int p = chunk * BP + t;
+      const int pc = p < a.M ? p : a.M - 1;                    // clamped X rows meet a zero G row
+      tabx[chunk & 1][t] = padded_pixel_off(pc, a.S, a.Px, a.ld_x, a.rcpS, a.rcpSS, -a.pad, -a.pad);
+      tabg[chunk & 1][t] = p < a.M ? padded_pixel_off(p, a.S, a.Pg, a.ld_g, a.rcpS, a.rcpSS, 0, 0) : INVALID;
+    }
+  };
+
   f32x4 rx[NX], rg[NG];
   auto gload = [&](int chunk) {
-    const int pb = chunk * BP;
+    const uint32_t* tx = tabx[chunk & 1];
+    const uint32_t* tg = tabg[chunk & 1];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      int p = pb + xpix + XPS * i;
-      p = p < a.M ? p : a.M - 1;               // clamped rows meet a zero G row
-      const uint32_t off = padded_pixel_off(p, a.S, a.Px, a.ld_x, a.rcpS, a.rcpSS, -a.pad, -a.pad);
-      rx[i] = *reinterpret_cast<const f32x4*>(a.x + off + xconst);
-    }
+    for (int i = 0; i < NX; ++i) rx[i] = *reinterpret_cast<const f32x4*>(a.x + tx[xpix + XPS * i] + xconst);
 #pragma unroll
     for (int i = 0; i < NG; ++i) {
-      const int p = pb + gpix + GPS * i;
-      if (p < a.M) {
-        const uint32_t off = padded_pixel_off(p, a.S, a.Pg, a.ld_g, a.rcpS, a.rcpSS, 0, 0);
-        rg[i] = *reinterpret_cast<const f32x4*>(a.g + off + gconst);
-      } else {
-        rg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      const uint32_t off = tg[gpix + GPS * i];
+      rg[i] = off != INVALID ? *reinterpret_cast<const f32x4*>(a.g + off + gconst) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   auto lstore = [&]() {
@@ -266,12 +270,16 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1)) void 
   };
 
   if (cbeg < cend) {
+    fill_tables(cbeg);
+    fill_tables(cbeg + 1);
+    __syncthreads();
     gload(cbeg);
     lstore();
     __syncthreads();
     const int xr = wr * WTR + li, gc = wc * WTO + li;
     for (int ch = cbeg; ch < cend; ++ch) {
-      if (ch + 1 < cend) gload(ch + 1);
+      if (ch + 1 < cend) gload(ch + 1);          // reads table slot (ch+1)&1, filled one iteration ago
+      fill_tables(ch + 2);                       // overwrites slot ch&1, last read by gload(ch) one iteration ago
 #pragma unroll
       for (int s = 0; s < BP / 2; ++s) {
         float af[TMr], bf[TNo];
