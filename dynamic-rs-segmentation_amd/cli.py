@@ -1,0 +1,144 @@
+"""Command line: the reference's positional surface, unchanged.
+
+isprs flavour  (isprs_dilated_random.py:1987-2042, 16 arguments):
+    input_path output_path currentModelPath trainingInstances testing_instances learningRate weight_decay
+    batch_size niter reference_crop_size reference_stride_crop net_type distribution_type probValues update_type process
+coffee / contest flavours (coffee_dilated_random.py:1106-1150, contest_dilated_random.py:1229-1271, 14 [+ operation]):
+    path_train path_test output_path currentModelPath lr wd batch niter ref_crop ref_stride net_type distribution_type
+    probValues update_type [operation]
+
+Dataset readers (TIFF/JPG through gdal / scipy.misc / skimage, torch-ASCII dumps, PGM) are outside the hot path
+(SURVEY.md section 8f-2).  Tiles are read from `<input_path><instance>.npz` (arrays `image` [H,W,C] float in [0,1],
+`label` [H,W] uint8) or generated when input_path is `synthetic:<H>x<W>x<C>/<dataset-name>/`.
+"""
+import os
+import sys
+import zlib
+
+import numpy as np
+
+from . import loops, patches as P, sampling as SP
+from .nets import resolve
+from .synthetic import make_tile
+
+ISPRS_PARAMS = ["input_path", "output_path(for model, images, etc)", "currentModelPath", "trainingInstances",
+                "testing_instances", "learningRate", "weight_decay", "batch_size", "niter", "reference_crop_size",
+                "reference_stride_crop",
+                "net_type[dilated_icpr_original|dilated_grsl|dilated_icpr_rate6_densely|dilated_grsl_rate8|dilated8_grsl]",
+                "distribution_type[single_fixed|multi_fixed|uniform|multinomial]", "probValues", "update_type [acc|loss]",
+                "process [training|validate_test|generate_final_maps]"]
+
+
+def print_params(list_params, argv):
+    print("+" * 97)
+    for i in range(1, len(argv)):
+        print(list_params[i - 1] + "= " + argv[i])
+    print("+" * 97)
+
+
+def load_images(path, instances, process, num_classes=6):
+    """Stand-in for isprs:187-242 (see module docstring)."""
+    images, masks = [], []
+    for f in instances:
+        print(loops.BatchColors.OKBLUE + "Reading instance " + str(f) + loops.BatchColors.ENDC)
+        if path.startswith("synthetic:"):
+            h, w, c = [int(v) for v in path[len("synthetic:"):].split("/")[0].split("x")]
+            img, lab = make_tile(h, w, c, num_classes, seed=zlib.crc32(str(f).encode()) % (2 ** 31))
+        else:
+            with np.load(os.path.join(path, str(f) + ".npz")) as d:
+                img, lab = np.asarray(d["image"], dtype=np.float64), np.asarray(d["label"], dtype=np.uint8)
+        images.append(img)
+        masks.append(lab)
+    return images, masks
+
+
+def init_size_scores(distribution_type, values, occur_init=0):
+    """isprs:2054-2064 (contest initialises patch_occur with ones, contest:1275)."""
+    if distribution_type == "multi_fixed":
+        n = len(values)
+    elif distribution_type in ("uniform", "multinomial"):
+        n = values[-1] - values[0] + 1
+    else:
+        return None, None, None, None
+    probs = P.define_multinomial_probs(values) if distribution_type == "multinomial" else None
+    return (np.zeros(n, dtype=np.float32), np.full(n, occur_init, dtype=np.int32), np.zeros(n, dtype=np.int32), probs)
+
+
+def cached(path, make):
+    """cwd .npy caches of the reference (isprs:2087-2115)."""
+    if os.path.isfile(path):
+        return np.load(path, allow_pickle=True)
+    v = make()
+    np.save(path, np.asarray(v, dtype=object) if isinstance(v, list) else v)
+    return v
+
+
+def main(argv=None, device="cuda:0", comm=None):
+    argv = list(sys.argv if argv is None else argv)
+    if len(argv) < len(ISPRS_PARAMS) + 1:
+        sys.exit("Usage: " + argv[0] + " " + " ".join(ISPRS_PARAMS))
+    print_params(ISPRS_PARAMS, argv)
+    (input_path, output_path, former_model_path, tr, te, lr, wd, bs, niter, ref_crop, ref_stride, net_type,
+     distribution_type, prob_values, update_type, process) = argv[1:17]
+    dataset = input_path[:-1].split("/")[-1].lower()
+    training_instances, testing_instances = tr.split(","), te.split(",")
+    lr_initial, weight_decay, batch_size, niter = float(lr), float(wd), int(bs), int(niter)
+    reference_crop_size, reference_stride_crop = int(ref_crop), int(ref_stride)
+    values = [int(i) for i in prob_values.split(",")]
+    resolve(net_type)
+    display_step = 50
+    if dataset == "vaihingen":
+        resample_batch = 20
+    elif dataset == "postdam":
+        resample_batch = 10
+    else:
+        print("Error! No dataset identified: ", dataset)
+        resample_batch = 20
+    patch_acc_loss, patch_occur, patch_chosen_values, probs = init_size_scores(distribution_type, values)
+
+    print(loops.BatchColors.WARNING + "Reading images..." + loops.BatchColors.ENDC)
+    training_data, training_labels = load_images(input_path, training_instances, process)
+    testing_data, testing_labels = load_images(input_path, testing_instances, process)
+    tag = os.path.join(os.getcwd(), "dataset_" + dataset + "_crop_" + str(reference_crop_size) + "_stride_" + str(reference_stride_crop))
+    train_dist = test_dist = None
+    if process == "training":
+        train_dist = SP.create_distributions_over_classes(training_labels, reference_crop_size, reference_stride_crop)
+        test_dist = SP.create_distributions_over_classes(testing_labels, reference_crop_size, reference_stride_crop)
+    rot = None
+    if train_dist is not None:
+        rot = cached(tag + "_rotation.npy", lambda: SP.create_rotation_distribution(train_dist))
+    if os.path.isfile(tag + "_mean.npy"):
+        mean_full, std_full = np.load(tag + "_mean.npy"), np.load(tag + "_std.npy")
+    else:
+        dist_for_stats = train_dist or SP.create_distributions_over_classes(training_labels, reference_crop_size, reference_stride_crop)
+        mean_full, std_full = SP.dynamically_calculate_mean_and_std(training_data, dist_for_stats, crop_size=25)   # isprs:2109-2110
+        np.save(tag + "_mean.npy", mean_full)
+        np.save(tag + "_std.npy", std_full)
+
+    if process == "training":
+        return loops.train(training_data, training_labels, train_dist, rot, testing_data, testing_labels, test_dist,
+                           testing_instances, lr_initial, batch_size, niter, weight_decay, mean_full, std_full, update_type,
+                           distribution_type, values, patch_acc_loss, patch_occur, patch_chosen_values, probs, resample_batch,
+                           output_path, display_step, net_type, dataset, former_model_path, device=device, comm=comm)
+    from .net import DilatedNet
+    step = loops.step_from_model_path(former_model_path)
+    sized = distribution_type in ("multi_fixed", "uniform", "multinomial")
+    if sized:
+        patch_acc_loss = np.load(output_path + "patch_acc_loss_step_" + str(step) + ".npy")
+        patch_occur = np.load(output_path + "patch_occur_step_" + str(step) + ".npy")
+    s_max = max(values)
+    net = DilatedNet(net_type, training_data[0].shape[-1], 6, weight_decay, b_max=batch_size, s_max=s_max, device=device, comm=comm)
+    loops.load_checkpoint(net, former_model_path)
+    if process == "validate_test":
+        crop = (loops.select_best_patch_size(distribution_type, values, patch_acc_loss, patch_occur, update_type, debug=True)
+                if sized else int(values[0]))
+        return loops.validate_test(net, testing_data, testing_labels, testing_instances, batch_size, mean_full, std_full, crop,
+                                   step, output_path, comm)
+    if process == "generate_final_maps":
+        return loops.generate_final_maps(net, testing_data, testing_instances, batch_size, mean_full, std_full, update_type,
+                                         distribution_type, values, dataset, output_path, patch_acc_loss, patch_occur, comm)
+    print(loops.BatchColors.FAIL + "Process " + process + "not found!" + loops.BatchColors.ENDC)
+
+
+if __name__ == "__main__":
+    main()

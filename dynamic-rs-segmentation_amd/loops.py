@@ -1,0 +1,383 @@
+"""Step loops: training, patch validation, whole-tile sliding-window inference.
+
+Host mirror of /root/reference/isprs_dilated_random.py `train` :1621-1851, `validation` :1569-1618,
+`validate_test` :1241-1344 and `generate_final_maps` :1854-1957 (control flow, constants, log line formats and
+side files), with every per-pixel operation on the device.  Differences that are deliberate:
+
+  * the reference reads `loss`, `pred_up` back every step and runs a per-pixel Python loop on them
+    (calc_accuracy_by_crop, isprs:1754); here the confusion matrix and the loss stay on the device and are read back
+    ONE STEP LATE (while the next step runs), so the host never stalls the GPU.  The size-score update is a sum, so
+    the lag does not change any result; it is flushed before every display / save / validation point;
+  * the TensorFlow checkpoint becomes `model-<step>.npz` (same names, same `-<step>` resume convention, isprs:1708-1715);
+  * under data parallelism every rank runs the same host code with the same RNG streams and takes its slice of the batch.
+"""
+import datetime
+import math
+import os
+import random
+
+import numpy as np
+import torch
+
+from . import metrics as MT
+from . import patches as P
+from . import sampling as SP
+from .dist import shard_slice
+from .net import DilatedNet, NoComm
+
+EPOCH_NUMBER = 1000      # isprs:1642
+VAL_INTERVAL = 1000      # isprs:1643
+SUPER_BATCH = 100        # isprs:1632
+
+
+class BatchColors:
+    OKBLUE, OKGREEN, WARNING, FAIL, ENDC = "\033[94m", "\033[92m", "\033[93m", "\033[91m", "\033[0m"
+
+
+def select_best_patch_size(distribution_type, values, patch_acc_loss, patch_occur, is_loss_or_acc="acc",
+                           patch_chosen_values=None, debug=False):
+    """isprs:549-608 (mutates patch_occur: zeros -> 1, exactly like the reference)."""
+    patch_occur[np.where(patch_occur == 0)] = 1
+    patch_mean = patch_acc_loss / patch_occur
+    if is_loss_or_acc == "acc":
+        i = int(np.argmax(patch_mean))
+    elif is_loss_or_acc == "loss":
+        order = np.argsort(patch_mean)
+        i = int([j for j in order if patch_occur[j] > 0][0])
+    else:
+        raise ValueError("update_type must be acc or loss")
+    if patch_chosen_values is not None:
+        patch_chosen_values[i] += 1
+    cur = int(values[i]) if distribution_type == "multi_fixed" else values[0] + i
+    if debug:
+        print("patch_acc_loss", patch_acc_loss)
+        print("patch_occur", patch_occur)
+        print("patch_mean", patch_mean)
+        print("Current patch size ", cur)
+        if patch_chosen_values is not None:
+            print("Distr of chosen sizes ", patch_chosen_values)
+    return cur
+
+
+def _cm_str(cm):
+    return np.array_str(np.asarray(cm)).replace("\n", "")
+
+
+def save_checkpoint(net, output_path, step, patch_acc_loss=None, patch_occur=None, patch_chosen_values=None):
+    """saver.save(sess, output_path + 'model', global_step=step) + the three .npy side files (isprs:1798-1802)."""
+    np.savez(output_path + "model-" + str(step) + ".npz", **net.state_dict())
+    if patch_acc_loss is not None:
+        np.save(output_path + "patch_acc_loss_step_" + str(step) + ".npy", patch_acc_loss)
+        np.save(output_path + "patch_occur_step_" + str(step) + ".npy", patch_occur)
+        np.save(output_path + "patch_chosen_values_step_" + str(step) + ".npy", patch_chosen_values)
+
+
+def load_checkpoint(net, former_model_path):
+    path = former_model_path if former_model_path.endswith(".npz") else former_model_path + ".npz"
+    with np.load(path) as d:
+        net.load_state_dict({k: d[k] for k in d.files})
+    print(BatchColors.OKBLUE + "Model restored from " + former_model_path + BatchColors.ENDC)
+
+
+def step_from_model_path(former_model_path):
+    """isprs:1709: int(former_model_path.split('-')[-1])."""
+    return int(former_model_path.replace(".npz", "").split("-")[-1])
+
+
+# ------------------------------------------------------------------------------------------------- validation
+def validation(net, test_pool, selected_testing_instances, mean_full, std_full, batch_size, step, crop_size, comm=None):
+    """isprs:1569-1618: forward-only over the held-out instances at `crop_size`, one confusion matrix.
+    Returns (confusion matrix, pixels processed)."""
+    comm = comm or NoComm()
+    K = net.plan.K
+    n = len(selected_testing_instances)
+    nb = -(-n // batch_size)
+    net.conf.zero_()
+    for i in range(nb):
+        if i % comm.world != comm.rank:          # batches are independent: round-robin over ranks
+            continue
+        rows = selected_testing_instances[i * batch_size:min((i + 1) * batch_size, n)]
+        for j in range(0, len(rows), net.b_max):
+            part = rows[j:j + net.b_max]
+            P.crop_to_net(net, test_pool, part, crop_size, mean_full, std_full)
+            net.forward(len(part), crop_size, want_logits=False, labels=True)
+    cm_dev = net.conf.clone()
+    comm.all_reduce_sum(cm_dev)
+    cm = cm_dev.cpu().numpy().reshape(K, K).astype(np.uint32)
+    total, oa, na = MT.overall_and_normalized(cm)
+    if comm.rank == 0:
+        print("---- Iter " + str(step) +
+              " -- Time " + str(datetime.datetime.now().time()) +
+              " -- Validation: Overall Accuracy= " + str(total) +
+              " Overall Accuracy= " + "{:.6f}".format(oa) +
+              " Normalized Accuracy= " + "{:.6f}".format(na) +
+              " F1 Score= " + "{:.4f}".format(MT.f1_macro(cm)) +
+              " Kappa= " + "{:.4f}".format(MT.cohen_kappa(cm)) +
+              " Confusion Matrix= " + _cm_str(cm))
+    return cm, n * crop_size * crop_size
+
+
+# ------------------------------------------------------------------------------------------------- training
+class _Pending(object):
+    """Results of a step that are read back one step late."""
+
+    def __init__(self, net, out, size_index, step, epoch_counter):
+        # pinned destinations: the device-to-host copies are truly asynchronous, the host keeps enqueueing
+        self.conf = torch.empty(out["conf"].shape, dtype=out["conf"].dtype, pin_memory=True)
+        self.loss_parts = torch.empty(out["loss_parts"].shape, dtype=out["loss_parts"].dtype, pin_memory=True)
+        self.conf.copy_(out["conf"], non_blocking=True)
+        self.loss_parts.copy_(out["loss_parts"], non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+        self.size_index, self.step, self.epoch_counter, self.wd = size_index, step, epoch_counter, net.wd
+
+    def get(self):
+        self.event.synchronize()
+        cm = self.conf.numpy().astype(np.uint32)
+        lp = self.loss_parts.numpy()
+        return cm, float(lp[0] + self.wd * lp[1])
+
+
+def train(training_data, training_labels, training_class_distribution, training_rotation_distribution, testing_data,
+          testing_labels, testing_class_distribution, testing_instances, lr_initial, batch_size, niter, weight_decay,
+          mean_full, std_full, update_type, distribution_type, values, patch_acc_loss, patch_occur, patch_chosen_values,
+          probs, resample_batch, output_path, display_step, net_type, dataset, former_model_path=None, *,
+          num_classes=6, device="cuda:0", comm=None, noise="device", lr_decay_factor=0.5, tile_dtype=np.float64,
+          loss_score_scaled_by_epoch=True, quiet_sizes=False, val_cache_dir=None):
+    """isprs:1621-1851, same positional parameters.  Returns the trained DilatedNet."""
+    comm = comm or NoComm()
+    say = (lambda *a: print(*a)) if comm.rank == 0 else (lambda *a: None)
+    say(BatchColors.OKGREEN + "TRAINING" + BatchColors.ENDC)
+    channels = training_data[0].shape[-1]
+    say("channels ", channels)
+
+    selected_training_instances = SP.select_super_batch_instances(training_class_distribution, training_rotation_distribution,
+                                                                  batch_size, super_batch=SUPER_BATCH)
+    total_length = len(selected_training_instances)
+    cache = os.path.join(val_cache_dir or os.getcwd(), "dataset_" + dataset + ".npy")      # isprs:1634-1639
+    if os.path.isfile(cache):
+        selected_testing_instances = np.load(cache)
+    else:
+        selected_testing_instances = SP.select_super_batch_instances(testing_class_distribution, batch_size=batch_size,
+                                                                     super_batch=SUPER_BATCH)
+        if comm.rank == 0:
+            np.save(cache, selected_testing_instances)
+
+    if batch_size % comm.world:
+        raise ValueError("batch_size must be divisible by the number of ranks")
+    b_local = batch_size // comm.world
+    sl = shard_slice(batch_size, comm.rank, comm.world)
+    s_max = int(values[0]) if distribution_type == "single_fixed" else int(max(values))
+    net = DilatedNet(net_type, channels, num_classes, weight_decay, b_max=b_local, s_max=s_max, device=device, comm=comm,
+                     lr_decay_factor=lr_decay_factor)
+    train_pool = P.TilePool(training_data, training_labels, device, dtype=tile_dtype)
+    test_pool = P.TilePool(testing_data, testing_labels, device, dtype=tile_dtype)
+
+    shuffle = np.asarray(random.sample(range(total_length), total_length))
+    epoch_counter = 1
+    current_iter = 1
+    sized = distribution_type in ("multi_fixed", "uniform", "multinomial")
+    if former_model_path is not None and "model" in former_model_path:
+        current_iter = step_from_model_path(former_model_path)
+        if sized:
+            patch_acc_loss = np.load(output_path + "patch_acc_loss_step_" + str(current_iter) + ".npy")
+            patch_occur = np.load(output_path + "patch_occur_step_" + str(current_iter) + ".npy")
+            patch_chosen_values = np.load(output_path + "patch_chosen_values_step_" + str(current_iter) + ".npy")
+        load_checkpoint(net, former_model_path)
+    else:
+        say("Model totally initialized!")
+
+    it = 0
+    epoch_mean = 0.0
+    epoch_cm_train = np.zeros((num_classes, num_classes), dtype=np.uint32)
+    pending = []
+    last = dict(cm=None, loss=None, acc=0)
+
+    def consume(p):
+        nonlocal epoch_mean, epoch_cm_train
+        cm, loss = p.get()
+        acc, _, acc_norm = MT.overall_and_normalized(cm)
+        epoch_mean += acc
+        epoch_cm_train += cm
+        if sized:
+            if update_type == "loss":
+                patch_acc_loss[p.size_index] += loss * (p.epoch_counter / 10.0) if loss_score_scaled_by_epoch else loss
+            else:
+                patch_acc_loss[p.size_index] += acc_norm
+            patch_occur[p.size_index] += 1
+        last.update(cm=cm, loss=loss, acc=acc)
+
+    def flush():
+        while pending:
+            consume(pending.pop(0))
+
+    step = current_iter
+    for step in range(current_iter, niter + 1):
+        cur_patch_size, cur_size_int = P.draw_patch_size(distribution_type, values, probs)
+        if not quiet_sizes:
+            say(cur_patch_size)
+        shuffle, batch, it = P.select_batch(shuffle, batch_size, it, total_length)
+        rows = selected_training_instances[batch]
+        aug = P.draw_augmentation(rows, cur_patch_size, channels, noise=noise)
+        mine = P.Augmentation(b_local)
+        mine.rot_on, mine.rot, mine.noise_on, mine.flip = aug.rot_on[sl], aug.rot[sl], aug.noise_on[sl], aug.flip[sl]
+        mine.noise = aug.noise[sl] if aug.noise is not None else None
+        mine.seed = aug.seed + comm.rank
+        P.crop_to_net(net, train_pool, rows[sl], cur_patch_size, mean_full, std_full, mine)
+        out = net.train_step(b_local, cur_patch_size, lr_initial)
+        pending.append(_Pending(net, out, cur_size_int, step, epoch_counter))
+        while len(pending) > 1:
+            consume(pending.pop(0))
+
+        if step != 0 and step % display_step == 0:
+            flush()
+            cm = last["cm"]
+            _, oa, na = MT.overall_and_normalized(cm)
+            say("Iter " + str(step) + " -- Time " + str(datetime.datetime.now().time()) +
+                " -- Training Minibatch: Loss= " + "{:.6f}".format(last["loss"]) +
+                " Absolut Right Pred= " + str(int(last["acc"])) +
+                " Overall Accuracy= " + "{:.4f}".format(oa) +
+                " Normalized Accuracy= " + "{:.4f}".format(na) +
+                " Confusion Matrix= " + _cm_str(cm))
+
+        if step != 0 and step % EPOCH_NUMBER == 0:
+            flush()
+            _, _, na = MT.overall_and_normalized(epoch_cm_train)
+            say("-- Iter " + str(step) + " -- Training Epoch:" +
+                " Overall Accuracy= " + "{:.6f}".format(epoch_mean / float(np.sum(epoch_cm_train))) +
+                " Normalized Accuracy= " + "{:.6f}".format(na) +
+                " Confusion Matrix= " + _cm_str(epoch_cm_train))
+            epoch_mean = 0.0
+            epoch_cm_train = np.zeros((num_classes, num_classes), dtype=np.uint32)
+
+        if step != 0 and step % VAL_INTERVAL == 0:
+            flush()
+            if comm.rank == 0:
+                save_checkpoint(net, output_path, step, *((patch_acc_loss, patch_occur, patch_chosen_values) if sized else ()))
+            cur_patch_val = (select_best_patch_size(distribution_type, values, patch_acc_loss, patch_occur, update_type,
+                                                    patch_chosen_values, debug=comm.rank == 0) if sized else int(values[0]))
+            validation(net, test_pool, selected_testing_instances, mean_full, std_full, batch_size, step, cur_patch_val, comm)
+
+        if min(it + batch_size, total_length) == total_length or total_length == it + batch_size:     # isprs:1822
+            if epoch_counter % resample_batch == 0:
+                say("epoch_counter ", epoch_counter)
+                selected_training_instances = SP.select_super_batch_instances(training_class_distribution,
+                                                                              training_rotation_distribution, batch_size,
+                                                                              super_batch=SUPER_BATCH)
+                total_length = len(selected_training_instances)
+            epoch_counter += 1
+
+    flush()
+    say("Optimization Finished!")
+    if comm.rank == 0:
+        save_checkpoint(net, output_path, step, *((patch_acc_loss, patch_occur, patch_chosen_values) if sized else ()))
+    cur_patch_val = (select_best_patch_size(distribution_type, values, patch_acc_loss, patch_occur, update_type,
+                                            patch_chosen_values, debug=comm.rank == 0) if sized else int(values[0]))
+    validation(net, test_pool, selected_testing_instances, mean_full, std_full, batch_size, step, cur_patch_val, comm)
+    return net
+
+
+# ------------------------------------------------------------------------------------------------- whole tiles
+def predict_tile(net, pool, map_index, crop_size, batch_size, mean_full, std_full, comm=None):
+    """The inner loop of validate_test / generate_final_maps (isprs:1261-1284, 1925-1949) for one tile: windows at
+    stride floor(s/2) (isprs:1243), logits overlap-added in window order, arg-max of the average.  Returns the
+    uint8 label map as a DEVICE tensor [h, w].  Under data parallelism batches of windows go round-robin over the
+    ranks and the partial sums are added (sum all-reduce of prob / occur)."""
+    from . import _lib
+    comm = comm or NoComm()
+    h, w = pool.h[map_index], pool.w[map_index]
+    K = net.plan.K
+    stride = int(math.floor(crop_size / 2.0))
+    n_h, n_w = P.window_counts(h, w, crop_size, stride)
+    total = n_h * n_w
+    prob = torch.zeros(h * w * K, dtype=torch.float32, device=net.dev)
+    occur = torch.zeros(h * w, dtype=torch.int32, device=net.dev)
+    bs = min(batch_size, net.b_max)
+    nb = -(-total // bs)
+    st = net._stream()
+    for i in range(nb):
+        if i % comm.world != comm.rank:
+            continue
+        pos = P.window_positions(h, w, crop_size, stride, i, bs)
+        inst = np.concatenate([np.full((len(pos), 1), map_index), pos], axis=1)
+        P.crop_to_net(net, pool, inst, crop_size, mean_full, std_full)
+        _, logits = net.forward(len(pos), crop_size, want_logits=True)
+        _lib.call("drs_stitch_accumulate", prob.data_ptr(), occur.data_ptr(), logits.data_ptr(), h, w, K, crop_size, stride,
+                  i * bs, len(pos), st)
+    if comm.world > 1:
+        comm.all_reduce_sum(prob)
+        comm.all_reduce_sum(occur)
+    out = torch.zeros(h * w, dtype=torch.uint8, device=net.dev)
+    _lib.call("drs_stitch_finalize", prob.data_ptr(), occur.data_ptr(), h, w, K, out.data_ptr(), st)
+    return out.view(h, w), total
+
+
+def validate_test(net, testing_data, testing_labels, testing_instances, batch_size, mean_full, std_full, crop_size, step,
+                  output_path=None, comm=None, pool=None, ignore_label=6):
+    """isprs:1241-1344: per tile, sliding-window prediction and scores (label 6 = eroded boundary is skipped,
+    isprs:1294).  Returns (all-maps confusion matrix, list of label maps as numpy)."""
+    from . import _lib
+    comm = comm or NoComm()
+    K = net.plan.K
+    pool = pool or P.TilePool(testing_data, testing_labels, net.dev)
+    all_cm = np.zeros((K, K), dtype=np.uint32)
+    all_kappa = np.zeros(len(testing_data), dtype=np.float32)
+    all_f1 = np.zeros(len(testing_data), dtype=np.float32)
+    all_f1_per_class = np.zeros(K, dtype=np.float32)
+    maps = []
+    for k in range(len(testing_data)):
+        pred, _ = predict_tile(net, pool, k, crop_size, batch_size, mean_full, std_full, comm)
+        h, w = pool.h[k], pool.w[k]
+        conf = torch.zeros(K * K, dtype=torch.int32, device=net.dev)
+        lab = pool.labels[int(pool.lab_off[k].item()):int(pool.lab_off[k].item()) + h * w]
+        _lib.call("drs_confusion", lab.data_ptr(), pred.data_ptr(), None, h * w, K, ignore_label, conf.data_ptr(), net._stream())
+        cm = conf.cpu().numpy().reshape(K, K).astype(np.uint32)
+        all_cm += cm
+        total, oa, na = MT.overall_and_normalized(cm)
+        f1c, present = MT.f1_per_class(cm)
+        f1_full = np.zeros(K, dtype=np.float32)
+        f1_full[present] = f1c
+        all_kappa[k], all_f1[k] = MT.cohen_kappa(cm), MT.f1_macro(cm)
+        all_f1_per_class += f1_full
+        maps.append(pred.cpu().numpy())
+        if comm.rank == 0:
+            print("---- Iter " + str(step) +
+                  " -- Test Map " + str(testing_instances[k]) + ": Overall Accuracy= " + str(total) +
+                  " Overall Accuracy= " + "{:.6f}".format(oa) +
+                  " Normalized Accuracy= " + "{:.6f}".format(na) +
+                  " F1 Score per class= " + np.array_str(f1_full).replace("\n", "") +
+                  " F1 Score= " + "{:.4f}".format(all_f1[k]) +
+                  " Kappa= " + "{:.4f}".format(all_kappa[k]) +
+                  " Confusion Matrix= " + _cm_str(cm))
+    total, oa, na = MT.overall_and_normalized(all_cm)
+    if comm.rank == 0:
+        print("---- Iter " + str(step) +
+              " -- Test ALL MAPS: Overall Accuracy= " + str(total) +
+              " Overall Accuracy= " + "{:.6f}".format(oa) +
+              " Normalized Accuracy= " + "{:.6f}".format(na) +
+              " F1 Score= " + np.array_str(all_f1).replace("\n", " ") +
+              " Mean F1 Score= " + "{:.6f}".format(np.sum(all_f1) / float(len(testing_data))) +
+              " F1 Score per class= " + np.array_str(all_f1_per_class / float(len(testing_data))).replace("\n", "") +
+              " Kappa= " + np.array_str(all_kappa).replace("\n", " ") +
+              " Mean Kappa Score= " + "{:.6f}".format(np.sum(all_kappa) / float(len(testing_data))) +
+              " Confusion Matrix= " + _cm_str(all_cm))
+    return all_cm, maps
+
+
+def generate_final_maps(net, testing_data, testing_instances, batch_size, mean_full, std_full, update_type,
+                        distribution_type, values, dataset, output_path, patch_acc_loss=None, patch_occur=None, comm=None):
+    """isprs:1854-1957: best (or fixed) patch size, sliding-window label map per tile, saved as
+    `<prefix><instance>_class.npy` (the reference writes colour TIFFs through PIL, out of the hot path)."""
+    comm = comm or NoComm()
+    sized = distribution_type in ("multi_fixed", "uniform", "multinomial")
+    crop_size = (select_best_patch_size(distribution_type, values, patch_acc_loss, patch_occur, update_type, debug=comm.rank == 0)
+                 if sized else int(values[0]))
+    pool = P.TilePool(testing_data, None, net.dev)
+    maps = []
+    for k in range(len(testing_data)):
+        pred, _ = predict_tile(net, pool, k, crop_size, batch_size, mean_full, std_full, comm)
+        maps.append(pred.cpu().numpy())
+        if comm.rank == 0 and output_path:
+            prefix = "top_mosaic_09cm_area" if dataset == "vaihingen" else "top_potsdam_"
+            np.save(output_path + prefix + str(testing_instances[k]) + "_class.npy", maps[-1])
+    return maps

@@ -67,7 +67,7 @@ def dynamically_calculate_mean_and_std(data, indexes, crop_size):
 
     def flush():
         arr = np.asarray(chunk)
-        means.append(arr.mean(axis=(0, 1, 2)) if arr.size else np.full(data[0].shape[2], np.nan))
+        means.append(np.mean(np.mean(np.mean(arr, axis=0), axis=0), axis=0) if arr.size else np.full(data[0].shape[2], np.nan))
         stds.append(np.std(arr[:, 0, 0, :], axis=0, ddof=1) if arr.size else np.full(data[0].shape[2], np.nan))
 
     for i, (m, x, y) in enumerate(total):

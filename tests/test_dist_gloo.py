@@ -1,0 +1,114 @@
+"""CPU, world_size 2 over gloo: the data-parallel algorithm the HIP path uses (batch shards, sync batch norm through
+all-reduced sums in both directions, one flat gradient all-reduce, 1/N_global loss scaling) reproduces the
+single-process result.  The arithmetic here is the oracle's (test infrastructure); the collective wrapper, the
+sharding helpers and the exchange sequence are the product's (drs_amd.dist; sequence as in drs_amd.net.train_step)."""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import tf_ops as T
+
+
+def _sharded_loss_and_grads(o, x, y, comm, n_global, wd):
+    """OracleNet.loss_and_grads with every batch statistic exchanged as all-reduced sums (what each rank does)."""
+    def allsum(a):
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))
+        comm.all_reduce_sum(t)
+        return t.numpy()
+    spec = o.spec
+    cur, cache = x, []
+    for li, (name, k, ci, co, r) in enumerate(o.convs):
+        z = T.conv2d_same(cur, o.p[name + "/weights"], r) + o.p[name + "/biases"]
+        s = allsum(np.stack([z.sum(axis=(0, 1, 2)), (z ** 2).sum(axis=(0, 1, 2))]))
+        mean = s[0] / n_global
+        var = s[1] / n_global - mean ** 2
+        rstd = 1 / np.sqrt(var + T.BN_EPS)
+        xh = (z - mean) * rstd
+        a = T.act_fwd(xh, spec["act"])
+        out, idx = T.max_pool_3x3(a) if spec["pool"] else (a, None)
+        cache.append((cur, z, rstd, xh, idx))
+        cur = out
+    logits = cur @ o.p["conv_classifier/weights"][0, 0] + o.p["conv_classifier/biases"]
+    K = logits.shape[-1]
+    ce_mean_local, gl = T.softmax_ce(logits, y)
+    n_local = logits.size // K
+    gl = gl * (n_local / n_global)                      # dL/dlogits with the GLOBAL 1/N
+    ce_sum = allsum(np.array([ce_mean_local * n_local]))[0] / n_global
+    g = {"conv_classifier/weights": (cur.reshape(-1, cur.shape[-1]).T @ gl.reshape(-1, K)).reshape(1, 1, -1, K),
+         "conv_classifier/biases": gl.reshape(-1, K).sum(axis=0)}
+    gcur = gl @ o.p["conv_classifier/weights"][0, 0].T
+    for li in reversed(range(len(o.convs))):
+        name, k, ci, co, r = o.convs[li]
+        inp, z, rstd, xh, idx = cache[li]
+        ga = T.max_pool_3x3_bwd(idx, gcur) if spec["pool"] else gcur
+        gxh = T.act_bwd(xh, spec["act"], ga)
+        s = allsum(np.stack([gxh.sum(axis=(0, 1, 2)), (gxh * xh).sum(axis=(0, 1, 2))]))
+        gz = rstd * (gxh - s[0] / n_global - xh * s[1] / n_global)
+        gcur, gw = T.conv2d_same_bwd(inp, o.p[name + "/weights"], r, gz)
+        g[name + "/weights"] = gw
+    names = sorted(g)
+    flat = allsum(np.concatenate([g[n].reshape(-1) for n in names]))        # ONE flat gradient all-reduce
+    off = 0
+    for n in names:
+        g[n] = flat[off:off + g[n].size].reshape(g[n].shape)
+        off += g[n].size
+        if n.endswith("/weights"):
+            g[n] = g[n] + wd * o.p[n]
+    return ce_sum, g
+
+
+def _worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"], os.environ["WORLD_SIZE"] = str(rank), str(world)
+    from drs_amd.dist import TorchComm, shard_slice, window_shard
+    comm = TorchComm("gloo")
+    assert comm.world == world and comm.rank == rank
+    net, ch, K, B, S = "dilated_grsl", 3, 6, 4, 9
+    rng = np.random.default_rng(0)                      # same streams on every rank
+    x = rng.normal(size=(B, S, S, ch))
+    y = rng.integers(0, K, size=(B, S, S))
+    o = T.OracleNet(net, ch, K, seed=1)
+    sl = shard_slice(B, rank, world)
+    loss, g = _sharded_loss_and_grads(o, x[sl], y[sl], comm, float(B * S * S), 0.005)
+    # every window batch is owned by exactly one rank
+    owned = torch.zeros(7, dtype=torch.int32)
+    for i in window_shard(50, 8, rank, world):
+        owned[i] += 1
+    comm.all_reduce_sum(owned)
+    assert owned.tolist() == [1] * 7
+    if rank == 0:
+        np.savez(tmp, loss=loss, **{k.replace("/", "__"): v for k, v in g.items()})
+    comm.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_step_equals_single_process(tmp_path):
+    out = str(tmp_path / "dp.npz")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    net, ch, K, B, S = "dilated_grsl", 3, 6, 4, 9
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(B, S, S, ch))
+    y = rng.integers(0, K, size=(B, S, S))
+    o = T.OracleNet(net, ch, K, seed=1)
+    loss_ref, _, g_ref, _ = o.loss_and_grads(x, y, 0.005)
+    l2 = sum(0.5 * (o.p[n] ** 2).sum() for n in o.p if n.endswith("/weights"))
+    d = np.load(out)
+    assert abs(float(d["loss"]) + 0.005 * l2 - loss_ref) < 1e-10
+    for n in g_ref:
+        if n.endswith("/weights") or n == "conv_classifier/biases":
+            np.testing.assert_allclose(d[n.replace("/", "__")], g_ref[n], rtol=1e-7, atol=1e-10, err_msg=n)
+
+
+def test_shard_slice_rejects_uneven_batches():
+    from drs_amd.dist import shard_slice
+    assert shard_slice(128, 3, 8) == slice(48, 64)
+    try:
+        shard_slice(10, 0, 4)
+        assert False
+    except ValueError:
+        pass

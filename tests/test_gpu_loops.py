@@ -1,0 +1,125 @@
+"""-m gpu: the step loops (train / validation / sliding-window inference) end to end on small synthetic tiles."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import host_ref as H
+from oracle import tf_ops as T
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, rel_err   # noqa: E402
+
+
+def _tiles():
+    from drs_amd.synthetic import make_tile
+    a = make_tile(96, 110, 5, 6, seed=1, n_seeds=30)
+    b = make_tile(80, 96, 5, 6, seed=2, n_seeds=30)
+    return [a[0], b[0]], [a[1], b[1]]
+
+
+def test_train_loop_checkpoint_resume_and_validation(tmp_path, capsys):
+    from drs_amd import loops, sampling as SP
+    from drs_amd.cli import init_size_scores
+    data, labels = _tiles()
+    random.seed(0)
+    np.random.seed(0)
+    dist = SP.create_distributions_over_classes(labels, 25, 10)
+    rot = SP.create_rotation_distribution(dist)
+    mean, std = SP.dynamically_calculate_mean_and_std(data, dist, 25)
+    values = [9, 13]
+    acc, occ, chosen, probs = init_size_scores("multi_fixed", values)
+    out = str(tmp_path) + "/"
+    net = loops.train(data, labels, dist, rot, data, labels, dist, ["a", "b"], 0.01, 8, 6, 0.005, mean, std, "acc", "multi_fixed",
+                      values, acc, occ, chosen, probs, 20, out, 2, "dilated_grsl", "vaihingen", "none", device=DEV,
+                      val_cache_dir=str(tmp_path))
+    text = capsys.readouterr().out
+    assert "Training Minibatch: Loss=" in text and "Validation: Overall Accuracy=" in text and "Optimization Finished!" in text
+    assert occ.sum() >= 6 and net.global_step == 6
+    for f in ("model-6.npz", "patch_acc_loss_step_6.npy", "patch_occur_step_6.npy", "patch_chosen_values_step_6.npy"):
+        assert os.path.isfile(out + f), f
+    w_before = net.get_variable("conv3/weights")
+    # resume: step is parsed from the '-6' suffix, state and the size scores come back (isprs:1708-1715)
+    net2 = loops.train(data, labels, dist, rot, data, labels, dist, ["a", "b"], 0.01, 8, 8, 0.005, mean, std, "acc", "multi_fixed",
+                       values, None, None, None, probs, 20, out, 2, "dilated_grsl", "vaihingen", out + "model-6", device=DEV,
+                       val_cache_dir=str(tmp_path))
+    assert net2.global_step == 6 + 3          # resumes AT step 6 (range(current_iter, niter+1)), like the reference
+    assert not np.array_equal(net2.get_variable("conv3/weights"), w_before)
+    assert np.isfinite(net2.get_variable("conv1/moving_variance")).all()
+
+
+def test_training_reduces_loss_on_a_fixed_batch():
+    from drs_amd.net import DilatedNet
+    rng = np.random.default_rng(0)
+    B, S, ch, K = 4, 16, 5, 6
+    d = DilatedNet("dilated8_grsl", ch, K, 0.0005, b_max=B, s_max=S, device=DEV)
+    x = rng.normal(size=(B, S * S * ch)).astype(np.float32)
+    y = (rng.integers(0, 2, size=(B, S * S)) * 3).astype(np.int64)
+    losses = []
+    for i in range(25):
+        d.feed(x, y, S)
+        out = d.train_step(B, S, 0.05)
+        losses.append(d.loss_value(out["loss_parts"]))
+    assert losses[-1] < 0.5 * losses[0], losses
+
+
+def test_sliding_window_tile_matches_oracle():
+    from drs_amd import loops, patches as P
+    from drs_amd.net import DilatedNet
+    rng = np.random.default_rng(4)
+    net_type, ch, K, S, bs = "dilated_grsl", 5, 6, 16, 5
+    tile = rng.uniform(size=(40, 53, ch))
+    lab = rng.integers(0, 7, size=(40, 53)).astype(np.uint8)          # 6 = eroded boundary
+    mean, std = np.array([0.5, 0.5, 0.5, 0, 0]), np.array([0.25, 0.25, 0.25, 1, 1])
+    d = DilatedNet(net_type, ch, K, 0.005, b_max=bs, s_max=S, device=DEV, seed=3)
+    o = T.OracleNet(net_type, ch, K, seed=3)
+    for n in d.variable_names():
+        v = d.get_variable(n)
+        if n.endswith("moving_mean"):
+            v = (rng.normal(size=v.shape) * 0.05).astype(np.float32)
+            d.set_variable(n, v)
+        o.p[n] = v.astype(np.float64)
+    pool = P.TilePool([tile], [lab], DEV)
+    pred, total = loops.predict_tile(d, pool, 0, S, bs, mean, std)
+    st = H.stride_for(S)
+    nh, nw = H.window_counts(40, 53, S, st)
+    assert total == nh * nw
+    batches = []
+    for i in range(-(-nh * nw // bs)):
+        p, _, pos = H.create_patches_per_map(tile, lab, S, st, i, bs)
+        p = p.copy()
+        H.normalize_images(p, mean, std)
+        batches.append((o.forward(p.astype(np.float32).astype(np.float64), False).astype(np.float32), pos))
+    prob, occur, am = H.stitch_tile(40, 53, K, S, batches)
+    avg = prob / occur
+    srt = np.sort(avg, axis=2)
+    clear = (srt[..., -1] - srt[..., -2]) > 1e-3 * np.abs(avg).max()
+    got = pred.cpu().numpy()
+    assert clear.mean() > 0.95
+    np.testing.assert_array_equal(got[clear], am[clear])
+    # scores as validate_test prints them, eroded label skipped
+    cm, maps = loops.validate_test(d, [tile], [lab], ["t0"], bs, mean, std, S, 0, pool=pool)
+    keep = lab != 6
+    want = np.zeros((K, K), dtype=np.int64)
+    np.add.at(want, (lab[keep], got[keep]), 1)
+    np.testing.assert_array_equal(cm, want)
+    np.testing.assert_array_equal(maps[0], got)
+
+
+def test_validation_confusion_is_consistent():
+    from drs_amd import loops, patches as P, sampling as SP
+    from drs_amd.net import DilatedNet
+    data, labels = _tiles()
+    random.seed(1)
+    np.random.seed(1)
+    dist = SP.create_distributions_over_classes(labels, 25, 10)
+    inst = SP.select_super_batch_instances(dist, batch_size=4, super_batch=3)
+    d = DilatedNet("dilated_icpr_original", 5, 6, 0.005, b_max=4, s_max=25, device=DEV)
+    pool = P.TilePool(data, labels, DEV)
+    cm, px = loops.validation(d, pool, inst, [0.5] * 5, [0.2] * 5, 4, 0, 25)
+    assert cm.sum() == px == 12 * 25 * 25
+    _, lab_ref, _ = H.dynamically_create_patches(data, labels, inst, 25, is_train=False)
+    np.testing.assert_array_equal(cm.sum(axis=1), np.bincount(lab_ref.reshape(-1), minlength=6))
