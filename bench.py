@@ -33,6 +33,19 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 
 
+def pmc_traffic():
+    """HBM-side bytes per conv_igemm_kernel launch from the committed rocprofv3 --pmc passes of this same command
+    (profiles/rNN/pmc_traffic.json, written by tools/pmc_summary.py); None when no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1]))["conv_igemm_kernel (all)"]["traffic_bytes_per_launch"]
+    except (KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(seconds_budget=25.0):
     """The reference step restated with PyTorch-CPU fp32 ops (oracle/torch_ref.py) + the reference's host pipeline
     (numpy crop, normalise of bands 0..2, vectorised confusion matrix), on this host's cores."""
@@ -175,8 +188,28 @@ def main():
         nl = sum(summ[k]["launches"] for k in ("conv_fwd", "conv_dgrad") if k in summ)
         ach = w / (ms * 1e-3) / 1e12
         roofline = dict(kernel="conv_igemm_kernel (fwd + dgrad launches)", bound="mfma", achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS,
-                        unit="TFLOP/s", frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                        unit="TFLOP/s", frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=pmc_traffic(),
                         launches=nl, avg_launch_ms=round(ms / nl, 4), algorithmic_gflop_per_launch=round(w / nl / 1e9, 2))
+
+    # ---- validation half of the metric: forward-only pixels/sec (eval-mode BN, arg-max, confusion), isprs:1569-1618
+    vb = 4
+    for _ in range(2):
+        P.crop_to_net(net, pool, inst[:GLOBAL_BATCH][sl], PATCH, mean, std)
+        net.forward(B_local, PATCH, want_logits=False, labels=True)
+    if comm:
+        comm.barrier()
+    torch.cuda.synchronize()
+    tv = time.perf_counter()
+    for i in range(vb):
+        P.crop_to_net(net, pool, inst[i * GLOBAL_BATCH:(i + 1) * GLOBAL_BATCH][sl], PATCH, mean, std)
+        net.forward(B_local, PATCH, want_logits=False, labels=True)
+    if comm:
+        comm.barrier()
+    torch.cuda.synchronize()
+    tv = time.perf_counter() - tv
+    if comm:
+        tv = comm.max_float(tv, dev)
+    val_pixels_per_s = vb * GLOBAL_BATCH * PATCH * PATCH / tv
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -192,7 +225,7 @@ def main():
                                    "2048x2048 tile, global batch 128 (crop+augment+normalise, fwd, loss, bwd, momentum, confusion)",
                        "global_batch": GLOBAL_BATCH, "patch": PATCH, "bands": CHANNELS, "classes": CLASSES,
                        "parallelism": "dp%d" % world, "sync_bn": True},
-            "final_loss": round(loss, 5),
+            "val_pixels_per_sec": round(val_pixels_per_s, 1), "final_loss": round(loss, 5),
             "train_tflops": round(value * 3 * 2 * net.plan.mac_per_pixel() * PATCH * PATCH / 1e12, 2),
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
         }
