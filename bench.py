@@ -103,6 +103,11 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    # rehearsal knob (one-GPU boxes): DRS_BENCH_REHEARSAL=1 runs all ranks on cuda:0 over gloo, to exercise the
+    # N > 1 code path without a second device; never set by the driver, and the JSON line says so
+    rehearsal = os.environ.get("DRS_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
 
@@ -113,7 +118,7 @@ def main():
 
     comm = None
     if world > 1:
-        comm = TorchComm("nccl")
+        comm = TorchComm("gloo" if rehearsal else "nccl")
     rank = comm.rank if comm else 0
     B_local = GLOBAL_BATCH // world
     if GLOBAL_BATCH % world:
@@ -224,7 +229,8 @@ def main():
             "config": {"workload": "dilated_grsl_rate8 (Dilated8Pooling) training step, single_fixed 64x64, 5-band synthetic "
                                    "2048x2048 tile, global batch 128 (crop+augment+normalise, fwd, loss, bwd, momentum, confusion)",
                        "global_batch": GLOBAL_BATCH, "patch": PATCH, "bands": CHANNELS, "classes": CLASSES,
-                       "parallelism": "dp%d" % world, "sync_bn": True},
+                       "parallelism": "dp%d" % world + (" (REHEARSAL: all ranks on one GPU over gloo)" if rehearsal else ""),
+                       "sync_bn": True},
             "val_pixels_per_sec": round(val_pixels_per_s, 1), "final_loss": round(loss, 5),
             "train_tflops": round(value * 3 * 2 * net.plan.mac_per_pixel() * PATCH * PATCH / 1e12, 2),
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,

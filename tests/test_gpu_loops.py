@@ -123,3 +123,41 @@ def test_validation_confusion_is_consistent():
     assert cm.sum() == px == 12 * 25 * 25
     _, lab_ref, _ = H.dynamically_create_patches(data, labels, inst, 25, is_train=False)
     np.testing.assert_array_equal(cm.sum(axis=1), np.bincount(lab_ref.reshape(-1), minlength=6))
+
+
+def test_config3_dense_multinomial_loss_update(tmp_path, capsys):
+    """BASELINE configs[3] in miniature: DenseDilated6, multinomial size distribution, update_type=loss,
+    4-band tiles, 2 classes."""
+    from drs_amd import loops, sampling as SP
+    from drs_amd.cli import init_size_scores
+    from drs_amd.synthetic import make_tile
+    a = make_tile(90, 90, 4, 2, seed=5, n_seeds=20)
+    data, labels = [a[0]], [a[1]]
+    random.seed(3)
+    np.random.seed(3)
+    dist = SP.create_distributions_over_classes(labels, 25, 10, num_classes=2)
+    rot = SP.create_rotation_distribution(dist)
+    values = [25, 30]
+    acc, occ, chosen, probs = init_size_scores("multinomial", values)
+    assert len(probs) == 6 and abs(probs.sum() - 1) < 1e-12
+    out = str(tmp_path) + "/"
+    net = loops.train(data, labels, dist, rot, data, labels, dist, ["a"], 0.01, 4, 5, 0.001, [0.5] * 4, [0.2] * 4, "loss",
+                      "multinomial", values, acc, occ, chosen, probs, 20, out, 5, "dilated_icpr_rate6_densely", "vaihingen", "none",
+                      num_classes=2, device=DEV, val_cache_dir=str(tmp_path))
+    assert net.plan.dense and net.global_step == 5
+    assert occ.sum() >= 5 and np.all(acc >= 0) and acc.sum() > 0          # loss * epoch/10 accumulated per drawn size
+    assert "Validation: Overall Accuracy=" in capsys.readouterr().out
+
+
+def test_config4_sliding_window_dilated8_at_64():
+    """BASELINE configs[4] in miniature: Dilated8Pooling, 64x64 windows at stride 32 over a 5-band mosaic."""
+    from drs_amd import loops, patches as P
+    from drs_amd.net import DilatedNet
+    from drs_amd.synthetic import make_tile
+    tile, lab = make_tile(200, 260, 5, 6, seed=9, n_seeds=40)
+    d = DilatedNet("dilated_grsl_rate8", 5, 6, 0.005, b_max=16, s_max=64, device=DEV)
+    pool = P.TilePool([tile], [lab], DEV)
+    pred, total = loops.predict_tile(d, pool, 0, 64, 16, [0.5] * 5, [0.2] * 5)
+    assert total == P.window_counts(200, 260, 64, 32)[0] * P.window_counts(200, 260, 64, 32)[1] == 6 * 8
+    got = pred.cpu().numpy()
+    assert got.shape == (200, 260) and got.max() < 6
