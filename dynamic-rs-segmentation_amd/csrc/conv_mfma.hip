@@ -400,7 +400,9 @@ int drs_conv_wgrad_splits(int B, int S, int k, int cin, int cout) {
   const int tr = pick_tile(cin), to = pick_tile(cout);
   const int ntile = (k * k * cin / tr) * (cout / to);
   const int nchunks = (int)((M + 31) / 32);
-  int want = (1536 + ntile - 1) / ntile;            // ~6 workgroups per CU in flight
+  // fill the 256 CUs evenly: the largest split count whose workgroup total stays within 6 per CU (rounding up
+  // instead would leave most CUs idle while a few run a 7th workgroup)
+  int want = 1536 / ntile;
   int maxs = (nchunks + 31) / 32;                   // at least 32 chunks (1024 pixels) per split
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
