@@ -484,7 +484,18 @@ int drs_bn_act_pool_forward(const float* z, int B, int S, int C, const float* me
 }
 
 // rows of the slab drs_bn_backward_reduce writes (partial must hold rows * C * 2 floats)
-int drs_bn_backward_rows(int B, int S) { return (B * S * S + 255) / 256; }
+// pixels per workgroup of drs_bn_backward_reduce: 256 for big batches, down to 32 so that a small per-rank batch still
+// fills the chip (>= ~2048 workgroups)
+static int bn_bwd_rows_per_block(long long M) {
+  int r = 256;
+  while (r > 32 && M / r < 2048) r >>= 1;
+  return r;
+}
+int drs_bn_backward_rows(int B, int S) {
+  const long long M = (long long)B * S * S;
+  const int r = bn_bwd_rows_per_block(M);
+  return (int)((M + r - 1) / r);
+}
 
 int drs_bn_backward_reduce(const float* ga, int ld_ga, int coff_ga, const float* z, const unsigned char* argmax, int B, int S,
                            int C, const float* mean_rstd, float alpha, int pool, float* gxhat, float* partial, void* stream) {
@@ -493,13 +504,14 @@ int drs_bn_backward_reduce(const float* ga, int ld_ga, int coff_ga, const float*
   if (CQ > 256) return DRS_ERR_ARG;
   const int PT = 256 / CQ;
   const int nblk = drs_bn_backward_rows(B, S);
+  const int rpb = bn_bwd_rows_per_block((long long)B * S * S);
   const size_t shm = (size_t)PT * C * 2 * sizeof(float);
   if (pool)
     DRS_LAUNCH(bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(CQ * PT), shm, (hipStream_t)stream, ga, ld_ga, coff_ga, z,
-                       argmax, B, S, C, mean_rstd, alpha, gxhat, partial, 256);
+                       argmax, B, S, C, mean_rstd, alpha, gxhat, partial, rpb);
   else
     DRS_LAUNCH(bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(CQ * PT), shm, (hipStream_t)stream, ga, ld_ga, coff_ga, z,
-                       argmax, B, S, C, mean_rstd, alpha, gxhat, partial, 256);
+                       argmax, B, S, C, mean_rstd, alpha, gxhat, partial, rpb);
   return DRS_LAUNCH_CHECK();
 }
 

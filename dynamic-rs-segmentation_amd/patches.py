@@ -171,40 +171,70 @@ def _shift_inside(inst_xy, pool, S):
     return inst
 
 
+class _Staging(object):
+    """Per-step index / augmentation tables go to the device in ONE asynchronous copy from a pinned ring buffer
+    (pageable uploads would block the host every step and keep it from running ahead of the GPU).
+    Layout per slot, 8-byte aligned: rot f64 [B][6] | inst i32 [B][4] | rot_on u8 [B] | noise_on u8 [B]."""
+    SLOTS = 4
+
+    def __init__(self, dev, b_max):
+        self.b_max = b_max
+        self.o_rot, self.o_inst = 0, 48 * b_max
+        self.o_ron, self.o_non = 64 * b_max, 65 * b_max
+        self.nbytes = (66 * b_max + 7) // 8 * 8
+        self.host = [torch.empty(self.nbytes, dtype=torch.uint8, pin_memory=torch.cuda.is_available()) for _ in range(self.SLOTS)]
+        self.dev = [torch.empty(self.nbytes, dtype=torch.uint8, device=dev) for _ in range(self.SLOTS)]
+        self.events = [None] * self.SLOTS
+        self.i = 0
+
+    def upload(self, inst, aug):
+        k = self.i
+        self.i = (k + 1) % self.SLOTS
+        if self.events[k] is not None:
+            self.events[k].synchronize()              # the copy issued SLOTS steps ago has long finished
+        B = len(inst)
+        h = self.host[k].numpy()
+        h[self.o_inst:self.o_inst + 16 * B].view(np.int32)[:] = inst.reshape(-1)
+        if aug is not None:
+            h[self.o_rot:self.o_rot + 48 * B].view(np.float64)[:] = aug.rot.reshape(-1)
+            h[self.o_ron:self.o_ron + B] = aug.rot_on
+            h[self.o_non:self.o_non + B] = aug.noise_on
+        self.dev[k].copy_(self.host[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+        base = self.dev[k].data_ptr()
+        return base + self.o_inst, base + self.o_rot, base + self.o_ron, base + self.o_non
+
+
 def crop_to_net(net, pool, instances, S, mean, std, aug=None):
     """dynamically_create_patches + normalize_images (isprs:1742-1745 / 1579-1583) fused on the device:
     fills net's conv1 slab, net.labels and net.acc_mask for `instances` rows (map, x, y[, rot])."""
+    import ctypes as C
     B = len(instances)
     net._check(B, S)
-    dev = net.dev
     inst = np.zeros((B, 4), dtype=np.int32)
     inst[:, :3] = _shift_inside(instances, pool, S)
-    rot = rot_on = noise = noise_on = None
-    seed = 0
     if aug is not None:
         inst[:, 3] = aug.flip
-        rot = torch.from_numpy(aug.rot).to(dev)
-        rot_on = torch.from_numpy(aug.rot_on).to(dev)
-        noise_on = torch.from_numpy(aug.noise_on).to(dev)
-        if aug.noise is not None:
-            noise = torch.from_numpy(aug.noise).to(dev)
-        seed = aug.seed
-    inst_d = torch.from_numpy(inst).to(dev)
-    m3 = torch.tensor(np.asarray(mean, dtype=np.float64)[:3].tolist() + [0.0] * max(0, 3 - len(mean)), dtype=torch.float64)
-    s3 = torch.tensor(np.asarray(std, dtype=np.float64)[:3].tolist() + [1.0] * max(0, 3 - len(std)), dtype=torch.float64)
+    stg = getattr(net, "_staging", None)
+    if stg is None:
+        stg = net._staging = _Staging(net.dev, net.b_max)
+    p_inst, p_rot, p_ron, p_non = stg.upload(inst, aug)
+    noise = None
+    if aug is not None and aug.noise is not None:
+        noise = torch.from_numpy(aug.noise).to(net.dev)          # reference-exact host noise (tests / parity runs)
+    m = list(np.asarray(mean, dtype=np.float64)[:3]) + [0.0] * max(0, 3 - len(mean))
+    sd = list(np.asarray(std, dtype=np.float64)[:3]) + [1.0] * max(0, 3 - len(std))
+    m3c, s3c = (C.c_double * 3)(*m), (C.c_double * 3)(*sd)       # HOST pointers: copied into the kernel arguments
     slab, P, ld = net.input_slab()
-    # mean/std are read on the host side of the call (copied into the kernel arguments)
-    import ctypes as C
-    m3c = (C.c_double * 3)(*m3.tolist())
-    s3c = (C.c_double * 3)(*s3.tolist())
     _lib.call("drs_crop_normalize", pool.tiles.data_ptr(), 1 if pool.f64 else 0, pool.labels.data_ptr(),
               pool.tile_off.data_ptr(), pool.lab_off.data_ptr(), pool.tile_h.data_ptr(), pool.tile_w.data_ptr(), pool.C,
-              inst_d.data_ptr(), None if rot is None else rot.data_ptr(), None if rot_on is None else rot_on.data_ptr(),
-              None if noise is None else noise.data_ptr(), None if noise_on is None else noise_on.data_ptr(), seed,
-              C.cast(m3c, C.c_void_p), C.cast(s3c, C.c_void_p), B, S, P, ld, slab.data_ptr(), net.labels.data_ptr(),
-              net.acc_mask.data_ptr(), net._stream())
-    # keep the staging tensors alive until the stream has consumed them
-    net._keep = (inst_d, rot, rot_on, noise, noise_on)
+              p_inst, p_rot if aug is not None else None, p_ron if aug is not None else None,
+              None if noise is None else noise.data_ptr(), p_non if aug is not None else None,
+              aug.seed if aug is not None else 0, C.cast(m3c, C.c_void_p), C.cast(s3c, C.c_void_p), B, S, P, ld,
+              slab.data_ptr(), net.labels.data_ptr(), net.acc_mask.data_ptr(), net._stream())
+    net._keep = noise                                            # alive until the stream has consumed it
     return inst[:, 1:3]
 
 

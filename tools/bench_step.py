@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Time the training step at a given local batch (what one rank sees under data parallelism), no collectives."""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from drs_amd.net import DilatedNet, KernelTimer
+from drs_amd import patches as P
+from drs_amd.synthetic import make_tile, grid_instances
+
+def main(B=16, S=64, steps=20):
+    dev = "cuda:0"
+    tile, lab = make_tile(1024, 1024, 5, 6, seed=1234)
+    pool = P.TilePool([tile], [lab], dev)
+    inst = grid_instances(1024, 1024, S, 25, 4096, seed=0)
+    net = DilatedNet("dilated_grsl_rate8", 5, 6, 0.005, b_max=B, s_max=S, device=dev)
+    np.random.seed(0)
+    def step(i):
+        rows = inst[(i * B) % 4000:(i * B) % 4000 + B]
+        aug = P.draw_augmentation(rows, S, 5, noise="device")
+        P.crop_to_net(net, pool, rows, S, [0.5] * 3, [0.2] * 3, aug)
+        return net.train_step(B, S, 0.01)
+    for i in range(5): step(i)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(steps): step(i)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    # host-only time per step (enqueue cost): run without waiting, measure enqueue loop
+    t1 = time.perf_counter()
+    for i in range(steps): step(i)
+    host = (time.perf_counter() - t1) / steps
+    torch.cuda.synchronize()
+    net.timer = KernelTimer()
+    for i in range(3): step(i)
+    summ = net.timer.summary(); net.timer = None
+    ksum = sum(d["ms"] for d in summ.values()) / 3
+    print("B=%d S=%d: %.2f ms/step  (%.0f patches/s; x%d ranks = %.0f)  host enqueue %.2f ms/step, timed kernels %.2f ms" % (B, S, dt * 1e3, B / dt, 128 // B, 128 / dt, host * 1e3, ksum))
+    for k, d in sorted(summ.items()): print("   %-18s %6.3f ms/step" % (k, d["ms"] / 3))
+
+if __name__ == "__main__":
+    kw = dict(a.split("=") for a in sys.argv[1:])
+    main(int(kw.get("B", 16)), int(kw.get("S", 64)), int(kw.get("steps", 20)))
