@@ -106,22 +106,46 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   const int arow = wm * WTM + li, bcolw = wn * WTN + li;
   for (int ks = 0; ks < nks; ++ks) {
     if (ks + 1 < nks) gload(ks + 1);
-    // K is consumed in the order the wide LDS reads deliver it: lane-half h of read q supplies k = 8q+4h+e at step e
+    // K is consumed in the order the wide LDS reads deliver it: lane-half h of read q supplies k = 8q+4h+e at step e.
+    // The fragments of step st+1 are read from LDS BEFORE the MFMAs of step st are issued (register double buffer,
+    // order pinned with sched_group_barrier), so an LDS round trip never sits between two MFMA groups.
+    {
+      constexpr int NST = BK / 2;             // MFMA k-steps per K-step
+      f32x4 acur[TM], anext[TM];
+      float bcur[TN], bnext[TN];
 #pragma unroll
-    for (int q = 0; q < BK / 8; ++q) {
-      f32x4 af[TM];
+      for (int mi = 0; mi < TM; ++mi) acur[mi] = *reinterpret_cast<const f32x4*>(&As[(arow + mi * 32) * LDA + h * 4]);
 #pragma unroll
-      for (int mi = 0; mi < TM; ++mi) af[mi] = *reinterpret_cast<const f32x4*>(&As[(arow + mi * 32) * LDA + q * 8 + h * 4]);
+      for (int ni = 0; ni < TN; ++ni) bcur[ni] = Bs[(h * 4) * LDB + bcolw + ni * 32];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float bf[TN];
+      for (int st = 0; st < NST; ++st) {
+        const int e = st & 3;
+        if (st + 1 < NST) {
+          const int q1 = (st + 1) >> 2, e1 = (st + 1) & 3;
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni) bf[ni] = Bs[(q * 8 + h * 4 + e) * LDB + bcolw + ni * 32];
+          for (int ni = 0; ni < TN; ++ni) bnext[ni] = Bs[(q1 * 8 + h * 4 + e1) * LDB + bcolw + ni * 32];
+          if (e1 == 0) {
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) anext[mi] = *reinterpret_cast<const f32x4*>(&As[(arow + mi * 32) * LDA + q1 * 8 + h * 4]);
+            __builtin_amdgcn_sched_group_barrier(0x100, TN + TM, 0);                  // DS reads of the next step first
+          } else {
+            __builtin_amdgcn_sched_group_barrier(0x100, TN, 0);
+          }
+        }
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
           for (int ni = 0; ni < TN; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][e], bf[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[mi][e], bcur[ni], acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, TM * TN, 0);                        // then this step's MFMAs
+        if (st + 1 < NST) {
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni) bcur[ni] = bnext[ni];
+          if (((st + 1) & 3) == 0) {
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) acur[mi] = anext[mi];
+          }
+        }
       }
     }
     __syncthreads();
@@ -200,7 +224,6 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   constexpr int XQ = TR / 4, GQ = TO / 4;     // float4 per pixel row
   constexpr int NX = BP * XQ / NT, NG = BP * GQ / NT;
   constexpr int XPS = NT / XQ, GPS = NT / GQ; // pixel stride between a thread's successive loads
-  constexpr uint32_t INVALID = 0xffffffffu;
 
   __shared__ __attribute__((aligned(16))) float lds[BP * LDX + BP * LDG];
   __shared__ uint32_t tabx[2][BP], tabg[2][BP];   // padded element offsets of the chunk's pixels (per-chunk, double-buffered)
@@ -249,21 +272,33 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
       const int p = chunk * BP + t;
       const int pc = p < a.M ? p : a.M - 1;                    // clamped X rows meet a zero G row
       tabx[chunk & 1][t] = padded_pixel_off(pc, a.S, a.Px, a.ld_x, a.rcpS, a.rcpSS, -a.pad, -a.pad);
-      tabg[chunk & 1][t] = p < a.M ? padded_pixel_off(p, a.S, a.Pg, a.ld_g, a.rcpS, a.rcpSS, 0, 0) : INVALID;
+      // bit 31 flags a pixel past the end (its G row must read as zero); the offset itself stays a valid address
+      tabg[chunk & 1][t] = padded_pixel_off(pc, a.S, a.Pg, a.ld_g, a.rcpS, a.rcpSS, 0, 0) | (p < a.M ? 0u : 0x80000000u);
     }
   };
 
   f32x4 rx[NX], rg[NG];
+  // branch-free: every offset in the tables is a valid address (rows past the end are clamped); what must be zero
+  // (G rows of pixels >= M, X rows of a ragged tile) is zeroed by a select after the load.  All table reads are
+  // issued before the first global load.
   auto gload = [&](int chunk) {
     const uint32_t* tx = tabx[chunk & 1];
     const uint32_t* tg = tabg[chunk & 1];
+    uint32_t ox[NX], og[NG];
 #pragma unroll
-    for (int i = 0; i < NX; ++i)
-      rx[i] = row_ok ? *reinterpret_cast<const f32x4*>(a.x + tx[xpix + XPS * i] + xconst) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NX; ++i) ox[i] = tx[xpix + XPS * i];
 #pragma unroll
-    for (int i = 0; i < NG; ++i) {
-      const uint32_t off = tg[gpix + GPS * i];
-      rg[i] = off != INVALID ? *reinterpret_cast<const f32x4*>(a.g + off + gconst) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NG; ++i) og[i] = tg[gpix + GPS * i];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) rx[i] = *reinterpret_cast<const f32x4*>(a.x + ox[i] + xconst);
+#pragma unroll
+    for (int i = 0; i < NG; ++i) rg[i] = *reinterpret_cast<const f32x4*>(a.g + (og[i] & 0x7fffffffu) + gconst);
+#pragma unroll
+    for (int i = 0; i < NG; ++i)
+      if (og[i] & 0x80000000u) rg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!row_ok) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) rx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   auto lstore = [&]() {
@@ -284,18 +319,35 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
     for (int ch = cbeg; ch < cend; ++ch) {
       if (ch + 1 < cend) gload(ch + 1);          // reads table slot (ch+1)&1, filled one iteration ago
       fill_tables(ch + 2);                       // overwrites slot ch&1, last read by gload(ch) one iteration ago
+      {
+        // fragments of pixel pair s+1 are read before the MFMAs of pair s are issued (see conv_igemm_kernel)
+        float acur[TMr], bcur[TNo], anext[TMr], bnext[TNo];
 #pragma unroll
-      for (int s = 0; s < BP / 2; ++s) {
-        float af[TMr], bf[TNo];
+        for (int mi = 0; mi < TMr; ++mi) acur[mi] = Xs[h * LDX + xr + mi * 32];
 #pragma unroll
-        for (int mi = 0; mi < TMr; ++mi) af[mi] = Xs[(2 * s + h) * LDX + xr + mi * 32];
+        for (int ni = 0; ni < TNo; ++ni) bcur[ni] = Gs[h * LDG + gc + ni * 32];
 #pragma unroll
-        for (int ni = 0; ni < TNo; ++ni) bf[ni] = Gs[(2 * s + h) * LDG + gc + ni * 32];
+        for (int s = 0; s < BP / 2; ++s) {
+          if (s + 1 < BP / 2) {
 #pragma unroll
-        for (int mi = 0; mi < TMr; ++mi)
+            for (int mi = 0; mi < TMr; ++mi) anext[mi] = Xs[(2 * s + 2 + h) * LDX + xr + mi * 32];
 #pragma unroll
-          for (int ni = 0; ni < TNo; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+            for (int ni = 0; ni < TNo; ++ni) bnext[ni] = Gs[(2 * s + 2 + h) * LDG + gc + ni * 32];
+            __builtin_amdgcn_sched_group_barrier(0x100, TMr + TNo, 0);
+          }
+#pragma unroll
+          for (int mi = 0; mi < TMr; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TNo; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[mi], bcur[ni], acc[mi][ni], 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x8, TMr * TNo, 0);
+          if (s + 1 < BP / 2) {
+#pragma unroll
+            for (int mi = 0; mi < TMr; ++mi) acur[mi] = anext[mi];
+#pragma unroll
+            for (int ni = 0; ni < TNo; ++ni) bcur[ni] = bnext[ni];
+          }
+        }
       }
       __syncthreads();
       if (ch + 1 < cend) { lstore(); __syncthreads(); }
