@@ -208,6 +208,174 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ ga, int ld_ga, in
   }
 }
 
+// ------------------------------------------------------------------------------------------------ pooled nets: sliding kernels
+// With the 3x3 pool every output needs a 3x3 neighbourhood.  Instead of 9 loads per output, a thread owns one image
+// column x and four channels and slides down a strip of rows, keeping what it needs of the two previous rows in
+// registers: 3 loads per output forward (one row of 3 neighbours), 3 (code, gradient) pairs backward.
+// block = TX columns x (C/4) channel quads; grid.x = column blocks, grid.y = (image, row strip).
+struct SlideCfg { int TX, ncol, nstrips, rps; };
+static SlideCfg slide_cfg(int B, int S, int C) {
+  SlideCfg c;
+  const int CQ = C / 4;
+  c.TX = 256 / CQ;
+  c.ncol = (S + c.TX - 1) / c.TX;
+  c.nstrips = 1;
+  while ((long long)B * c.ncol * c.nstrips < 2048 && S / (c.nstrips * 2) >= 8) c.nstrips *= 2;
+  c.rps = (S + c.nstrips - 1) / c.nstrips;
+  return c;
+}
+
+// zero the halo of a view (the sliding forward kernel writes interiors only)
+__global__ void zero_halo_kernel(ActView out, int B, int C) {
+  const int CQ = C >> 2;
+  const int Sp = out.S + 2 * out.P;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= Sp * CQ) return;
+  const int xx = e / CQ, cq = e - xx * CQ;
+  const int b = blockIdx.y / Sp, yy = blockIdx.y - b * Sp;
+  const int y = yy - out.P, x = xx - out.P;
+  if (y >= 0 && y < out.S && x >= 0 && x < out.S) return;
+  *reinterpret_cast<f32x4*>(out.base + ((size_t)(b * Sp + yy) * Sp + xx) * out.ld + out.coff + cq * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+__global__ void bn_act_pool_fwd_slide_kernel(const float* __restrict__ z, int B, int S, int C, const float* __restrict__ mean_rstd,
+                                             float alpha, ActView out, unsigned char* __restrict__ idx, int nstrips, int rps) {
+  const int CQ = C >> 2;
+  const int tx = threadIdx.x / CQ, cq = threadIdx.x - tx * CQ;
+  const int x = blockIdx.x * (blockDim.x / CQ) + tx;
+  if (x >= S) return;
+  const int b = blockIdx.y / nstrips, strip = blockIdx.y - b * nstrips;
+  const int y0 = strip * rps;
+  int y1 = y0 + rps;
+  y1 = y1 < S ? y1 : S;
+  const f32x4 mr0 = *reinterpret_cast<const f32x4*>(mean_rstd + cq * 8);
+  const f32x4 mr1 = *reinterpret_cast<const f32x4*>(mean_rstd + cq * 8 + 4);
+  const float mu[4] = {mr0[0], mr0[2], mr1[0], mr1[2]};
+  const float rs[4] = {mr0[1], mr0[3], mr1[1], mr1[3]};
+  const float NEG = -__builtin_inff();
+  // (max, position 0..2) over the three horizontal neighbours of row r, first maximum in scan order
+  auto row_max = [&](int r, f32x4& m, unsigned (&cd)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { m[j] = NEG; cd[j] = 0u; }
+    if (r < 0 || r >= S) return;
+    const float* zr = z + (((size_t)b * S + r) * S) * C + cq * 4;
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int nx = x + dx;
+      if (nx < 0 || nx >= S) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(zr + (size_t)nx * C);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = act((v[j] - mu[j]) * rs[j], alpha);
+        if (a > m[j]) { m[j] = a; cd[j] = (unsigned)(dx + 1); }
+      }
+    }
+  };
+  f32x4 m0, m1, m2;
+  unsigned c0[4], c1[4], c2[4];
+  row_max(y0 - 1, m0, c0);
+  row_max(y0, m1, c1);
+  const int Sp = S + 2 * out.P;
+  for (int y = y0; y < y1; ++y) {
+    row_max(y + 1, m2, c2);
+    f32x4 best;
+    unsigned code[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      best[j] = m0[j]; code[j] = c0[j];                       // row y-1 (or -inf)
+      if (m1[j] > best[j]) { best[j] = m1[j]; code[j] = 3u + c1[j]; }
+      if (m2[j] > best[j]) { best[j] = m2[j]; code[j] = 6u + c2[j]; }
+    }
+    *reinterpret_cast<f32x4*>(out.base + ((size_t)(b * Sp + y + out.P) * Sp + x + out.P) * out.ld + out.coff + cq * 4) = best;
+    if (idx) {
+      const size_t pix = ((size_t)b * S + y) * S + x;
+      *reinterpret_cast<unsigned*>(idx + pix * C + cq * 4) = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
+    }
+    m0 = m1; m1 = m2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { c0[j] = c1[j]; c1[j] = c2[j]; }
+  }
+}
+
+__global__ void bn_bwd_reduce_slide_kernel(const float* __restrict__ ga, int ld_ga, int coff_ga, const float* __restrict__ z,
+                                           const unsigned char* __restrict__ idx, int B, int S, int C,
+                                           const float* __restrict__ mean_rstd, float alpha, float* __restrict__ gxh,
+                                           float* __restrict__ partial, int nstrips, int rps) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [TX][C][2]
+  const int CQ = C >> 2;
+  const int TX = blockDim.x / CQ;
+  const int tx = threadIdx.x / CQ, cq = threadIdx.x - tx * CQ;
+  const int x = blockIdx.x * TX + tx;
+  const int b = blockIdx.y / nstrips, strip = blockIdx.y - b * nstrips;
+  const int y0 = strip * rps;
+  int y1 = y0 + rps;
+  y1 = y1 < S ? y1 : S;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (x < S) {
+    const f32x4 mr0 = *reinterpret_cast<const f32x4*>(mean_rstd + cq * 8);
+    const f32x4 mr1 = *reinterpret_cast<const f32x4*>(mean_rstd + cq * 8 + 4);
+    const float mu[4] = {mr0[0], mr0[2], mr1[0], mr1[2]};
+    const float rs[4] = {mr0[1], mr0[3], mr1[1], mr1[3]};
+    // one row of the window: arg-max codes and incoming gradients of the pooled outputs (r, x-1..x+1)
+    auto load_row = [&](int r, unsigned (&wi)[3], f32x4 (&wg)[3]) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int qx = x + k - 1;
+        if (r < 0 || r >= S || qx < 0 || qx >= S) { wi[k] = 0xffffffffu; wg[k] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
+        const size_t q = ((size_t)b * S + r) * S + qx;
+        wi[k] = *reinterpret_cast<const unsigned*>(idx + q * C + cq * 4);
+        wg[k] = *reinterpret_cast<const f32x4*>(ga + q * ld_ga + coff_ga + cq * 4);
+      }
+    };
+    unsigned i0[3], i1[3], i2[3];
+    f32x4 g0[3], g1[3], g2[3];
+    load_row(y0 - 1, i0, g0);
+    load_row(y0, i1, g1);
+    for (int y = y0; y < y1; ++y) {
+      load_row(y + 1, i2, g2);
+      f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
+      // output q = p + (dy, dx) routed its gradient to p iff its winner sits at (-dy, -dx): code (1-dy)*3 + (1-dx)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const unsigned w0 = (unsigned)(2 * 3 + (2 - k)), w1 = (unsigned)(1 * 3 + (2 - k)), w2 = (unsigned)(0 * 3 + (2 - k));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (((i0[k] >> (8 * j)) & 0xffu) == w0) g[j] += g0[k][j];
+          if (((i1[k] >> (8 * j)) & 0xffu) == w1) g[j] += g1[k][j];
+          if (((i2[k] >> (8 * j)) & 0xffu) == w2) g[j] += g2[k][j];
+        }
+      }
+      const size_t p = ((size_t)b * S + y) * S + x;
+      const f32x4 zv = *reinterpret_cast<const f32x4*>(z + p * C + cq * 4);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float xh = (zv[j] - mu[j]) * rs[j];
+        const float gx = xh > 0.f ? g[j] : g[j] * alpha;
+        o[j] = gx;
+        s1[j] += gx;
+        s2[j] += gx * xh;
+      }
+      *reinterpret_cast<f32x4*>(gxh + p * C + cq * 4) = o;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { i0[k] = i1[k]; i1[k] = i2[k]; g0[k] = g1[k]; g1[k] = g2[k]; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    red[((size_t)tx * C + cq * 4 + j) * 2] = s1[j];
+    red[((size_t)tx * C + cq * 4 + j) * 2 + 1] = s2[j];
+  }
+  __syncthreads();
+  const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float u1 = 0.f, u2 = 0.f;
+    for (int r = 0; r < TX; ++r) { u1 += red[((size_t)r * C + c) * 2]; u2 += red[((size_t)r * C + c) * 2 + 1]; }
+    partial[(blk * C + c) * 2] = u1;
+    partial[(blk * C + c) * 2 + 1] = u2;
+  }
+}
+
 // pass B: g_z = rstd * (g_xhat - mean(g_xhat) - xhat * mean(g_xhat * xhat)), written into a zero-haloed view
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ gxh, const float* __restrict__ z, int B, int S, int C,
                                     const float* __restrict__ mean_rstd, const double* __restrict__ sums, double count,
@@ -476,7 +644,12 @@ int drs_bn_act_pool_forward(const float* z, int B, int S, int C, const float* me
   const int per_row = Sp * (C / 4);
   dim3 grid((per_row + 255) / 256, B * Sp);
   ActView v = mkview(out, S, P_out, ld_out, coff_out);
-  if (pool)
+  if (pool && C / 4 <= 256) {
+    const SlideCfg c = slide_cfg(B, S, C);
+    if (P_out > 0) DRS_LAUNCH(zero_halo_kernel, grid, dim3(256), 0, (hipStream_t)stream, v, B, C);
+    DRS_LAUNCH(bn_act_pool_fwd_slide_kernel, dim3(c.ncol, B * c.nstrips), dim3(c.TX * (C / 4)), 0, (hipStream_t)stream, z, B, S, C,
+               mean_rstd, alpha, v, argmax, c.nstrips, c.rps);
+  } else if (pool)
     DRS_LAUNCH(bn_act_pool_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, z, B, S, C, mean_rstd, alpha, v, argmax);
   else
     DRS_LAUNCH(bn_act_pool_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, z, B, S, C, mean_rstd, alpha, v, argmax);
@@ -491,7 +664,11 @@ static int bn_bwd_rows_per_block(long long M) {
   while (r > 32 && M / r < 2048) r >>= 1;
   return r;
 }
-int drs_bn_backward_rows(int B, int S) {
+int drs_bn_backward_rows(int B, int S, int C, int pool) {
+  if (pool) {
+    const SlideCfg c = slide_cfg(B, S, C);
+    return c.ncol * B * c.nstrips;
+  }
   const long long M = (long long)B * S * S;
   const int r = bn_bwd_rows_per_block(M);
   return (int)((M + r - 1) / r);
@@ -502,16 +679,19 @@ int drs_bn_backward_reduce(const float* ga, int ld_ga, int coff_ga, const float*
   if (!ga || !z || !mean_rstd || !gxhat || !partial || C % 4 || (pool && !argmax)) return DRS_ERR_ARG;
   const int CQ = C / 4;
   if (CQ > 256) return DRS_ERR_ARG;
+  if (pool) {
+    const SlideCfg c = slide_cfg(B, S, C);
+    const size_t shm = (size_t)c.TX * C * 2 * sizeof(float);
+    DRS_LAUNCH(bn_bwd_reduce_slide_kernel, dim3(c.ncol, B * c.nstrips), dim3(c.TX * CQ), shm, (hipStream_t)stream, ga, ld_ga, coff_ga, z,
+               argmax, B, S, C, mean_rstd, alpha, gxhat, partial, c.nstrips, c.rps);
+    return DRS_LAUNCH_CHECK();
+  }
   const int PT = 256 / CQ;
-  const int nblk = drs_bn_backward_rows(B, S);
+  const int nblk = drs_bn_backward_rows(B, S, C, 0);
   const int rpb = bn_bwd_rows_per_block((long long)B * S * S);
   const size_t shm = (size_t)PT * C * 2 * sizeof(float);
-  if (pool)
-    DRS_LAUNCH(bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(CQ * PT), shm, (hipStream_t)stream, ga, ld_ga, coff_ga, z,
-                       argmax, B, S, C, mean_rstd, alpha, gxhat, partial, rpb);
-  else
-    DRS_LAUNCH(bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(CQ * PT), shm, (hipStream_t)stream, ga, ld_ga, coff_ga, z,
-                       argmax, B, S, C, mean_rstd, alpha, gxhat, partial, rpb);
+  DRS_LAUNCH(bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(CQ * PT), shm, (hipStream_t)stream, ga, ld_ga, coff_ga, z,
+             argmax, B, S, C, mean_rstd, alpha, gxhat, partial, rpb);
   return DRS_LAUNCH_CHECK();
 }
 

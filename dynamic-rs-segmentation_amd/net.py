@@ -177,8 +177,11 @@ class DilatedNet(object):
         self.colsum_scratch = torch.zeros(_lib.query("drs_colsum_scratch_doubles", max(2 * cmax, p.c_last * p.K)), **f64)
         rows_fwd = max((M + _lib.query("drs_conv_mtile", L.cout) - 1) // _lib.query("drs_conv_mtile", L.cout)
                        for L in p.layers)
-        rows_bwd = _lib.query("drs_bn_backward_rows", B, S)
-        self.partial = torch.zeros(max(rows_fwd, rows_bwd) * cmax * 2, **f32)
+        pool = 1 if p.pool else 0
+        # the slab's row count depends on the patch size through the kernel's tiling: size it for every S up to s_max
+        part = max(max(_lib.query("drs_bn_backward_rows", B, s, L.cout, pool) * L.cout * 2 for L in p.layers)
+                   for s in range(1, S + 1))
+        self.partial = torch.zeros(max(rows_fwd * cmax * 2, part), **f32)
         self.gA = torch.zeros(M * cmax, **f32)
         self.gB = torch.zeros(M * cmax, **f32)
         self.gxh = torch.zeros(M * cmax, **f32)
@@ -379,7 +382,7 @@ class DilatedNet(object):
             self._k("bn_bwd_reduce", M * L.cout * (13.0 if p.pool else 12.0), "drs_bn_backward_reduce", _ptr(gcur), ldc, cc,
                     _ptr(self.z[i]), _ptr(self.idx[i]), B, S, L.cout, _ptr(self.mean_rstd[i]), p.alpha, 1 if p.pool else 0,
                     _ptr(self.gxh), _ptr(self.partial), st)
-            _lib.call("drs_stats_reduce", _ptr(self.partial), _lib.query("drs_bn_backward_rows", B, S), L.cout, _ptr(self.sums),
+            _lib.call("drs_stats_reduce", _ptr(self.partial), _lib.query("drs_bn_backward_rows", B, S, L.cout, 1 if p.pool else 0), L.cout, _ptr(self.sums),
                       _ptr(self.colsum_scratch), st)
             self.comm.all_reduce_sum(self.sums[:2 * L.cout])
             self._k("bn_bwd_apply", M * L.cout * 12.0, "drs_bn_backward_apply", _ptr(self.gxh), _ptr(self.z[i]), B, S, L.cout,

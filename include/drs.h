@@ -82,9 +82,9 @@ int drs_bn_act_pool_forward(const float* z, int B, int S, int C, const float* me
 
 /* ---- backward of the block above ----------------------------------------------------------------------
  * reduce: ga [B*S*S][ld_ga]+coff_ga = gradient wrt the block output -> gxhat [B*S*S][C] (gradient wrt the
- *         normalised activation) and partial[drs_bn_backward_rows(B,S)][C][2] = (sum g, sum g*xhat);
+ *         normalised activation) and partial[drs_bn_backward_rows(B,S,C,pool)][C][2] = (sum g, sum g*xhat);
  * apply : gz = rstd * (gxhat - sum_g/count - xhat * sum_gx/count) into a haloed view (halo zeroed). */
-int drs_bn_backward_rows(int B, int S);
+int drs_bn_backward_rows(int B, int S, int C, int pool);
 int drs_bn_backward_reduce(const float* ga, int ld_ga, int coff_ga, const float* z, const unsigned char* argmax, int B,
                            int S, int C, const float* mean_rstd, float alpha, int pool, float* gxhat, float* partial,
                            void* stream);

@@ -170,7 +170,7 @@ def test_bn_act_pool_forward_backward(lib, C, pool, alpha, B, S, P):
     gad = torch.zeros(M, C + 16, dtype=torch.float32, device=DEV)
     gad[:, 16:] = dev(ga.reshape(M, C))
     gxh = torch.zeros(M * C, dtype=torch.float32, device=DEV)
-    rows = lib.query("drs_bn_backward_rows", B, S)
+    rows = lib.query("drs_bn_backward_rows", B, S, C, pool)
     partial = torch.zeros(rows * C * 2, dtype=torch.float32, device=DEV)
     lib.call("drs_bn_backward_reduce", gad.data_ptr(), C + 16, 16, zd.data_ptr(), idx.data_ptr() if pool else None, B, S, C,
              mr.data_ptr(), alpha, pool, gxh.data_ptr(), partial.data_ptr(), stream())
