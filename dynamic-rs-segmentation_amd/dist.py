@@ -32,6 +32,20 @@ class TorchComm(object):
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t
 
+    def all_reduce_sum_async(self, t):
+        """start a sum all-reduce on the collective's own stream (overlaps the kernels enqueued afterwards);
+        returns a handle for wait()."""
+        if self.world > 1:
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+        return None
+
+    @staticmethod
+    def wait(handles):
+        """make the current stream wait for the collectives started by all_reduce_sum_async (no host block on nccl)."""
+        for h in handles:
+            if h is not None:
+                h.wait()
+
     def barrier(self):
         if self.world > 1:
             dist.barrier()

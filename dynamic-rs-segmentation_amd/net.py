@@ -60,6 +60,13 @@ class NoComm(object):
     def all_reduce_sum(self, t):
         return t
 
+    def all_reduce_sum_async(self, t):
+        return None
+
+    @staticmethod
+    def wait(handles):
+        pass
+
 
 class DilatedNet(object):
     def __init__(self, net_type, channels, num_classes, weight_decay, b_max, s_max, device="cuda:0", seed=42,
@@ -372,6 +379,16 @@ class DilatedNet(object):
         _lib.call("drs_rows_reduce_f32", _ptr(self.db_partial), crow, p.K, self.grads[boff:].data_ptr(), _ptr(self.colsum_scratch), st)
         _lib.call("drs_sum_f64", _ptr(self.loss_partial), crow, _ptr(self.scalars), st)
         _lib.call("drs_l2_loss", _ptr(self.params), p.n_decay, _ptr(self.l2_scratch), self.scalars[1:].data_ptr(), st)
+        # conv biases sit in front of a mean-subtracting batch norm: their gradient is identically zero
+        b0, _ = p.offsets[p.layers[0].name + "/biases"]
+        self.grads[b0:boff].zero_()
+        # gradient all-reduce in buckets that overlap the rest of the backward pass (collectives run on RCCL's own
+        # stream): the classifier + bias tail is final now; kernel gradients follow as their layers finish, last
+        # layers first (they hold most of the bytes: conv7+conv8 = 49 % of Dilated8Pooling)
+        pending = []
+        bucket_hi = woff                       # kernels [bucket_lo, bucket_hi) of the flat buffer are still to be sent
+        if self.comm.world > 1:
+            pending.append(self.comm.all_reduce_sum_async(self.grads[woff:]))
         # reverse loop over the conv blocks
         gcur, ldc, cc = gfeat, ldg, cg
         gnext = self.gB
@@ -395,6 +412,9 @@ class DilatedNet(object):
             self._k("conv_wgrad", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_wgrad", _ptr(xin), B, S, Pin, ldin, cin_off,
                     _ptr(self.gz), L.halo, L.cout, 0, L.k, L.rate, L.pad_b, L.cin_k, L.cin, L.cout, _ptr(self.slab),
                     self.grads[goff:].data_ptr(), st)
+            if self.comm.world > 1 and i > 0 and (nL - i) % 2 == 0:                   # every second layer: one bucket
+                pending.append(self.comm.all_reduce_sum_async(self.grads[goff:bucket_hi]))
+                bucket_hi = goff
             if i > 0:
                 if p.dense:
                     out, ldo, co, acc = self.gconcat, p.c_last, 0, 1
@@ -405,13 +425,11 @@ class DilatedNet(object):
                 if not p.dense:
                     gcur, ldc, cc = gnext, L.cin, 0
                     gnext = self.gA if gnext is self.gB else self.gB
-        # conv biases sit in front of a mean-subtracting batch norm: their gradient is identically zero
-        b0, _ = p.offsets[p.layers[0].name + "/biases"]
-        self.grads[b0:boff].zero_()
         if self.comm.world > 1:
-            self.comm.all_reduce_sum(self.grads)
+            pending.append(self.comm.all_reduce_sum_async(self.grads[0:bucket_hi]))      # the remaining (earliest) layers
             self.comm.all_reduce_sum(self.scalars[:1])
             self.comm.all_reduce_sum(self.conf)
+            self.comm.wait(pending)
         self.scalars[0:1].mul_(1.0 / n_glob)
         if apply_update:
             self.apply_update(lr0)
