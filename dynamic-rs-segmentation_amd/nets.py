@@ -18,6 +18,22 @@ _TABLES = {
     "dilated_grsl_rate8": ("lrelu", True, False, 256, [
         ("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2), ("conv3", 4, 64, 128, 3), ("conv4", 4, 128, 128, 4),
         ("conv5", 3, 128, 192, 5), ("conv6", 3, 192, 192, 6), ("conv7", 3, 192, 256, 7), ("conv8", 3, 256, 256, 8)]),
+    # plain-chain variants outside BASELINE.json's configs: same block, other tables
+    "dilated_icpr_rate6": ("relu", False, False, 256, [                       # isprs:890-911, coffee:693-707
+        ("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2), ("conv3", 4, 64, 128, 3),
+        ("conv4", 4, 128, 128, 4), ("conv5", 3, 128, 256, 5), ("conv6", 3, 256, 256, 6)]),
+    "dilated_icpr_rate6_small": ("relu", False, False, 128, [                 # isprs:791-815, coffee:665-679
+        ("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2), ("conv3", 4, 64, 64, 3),
+        ("conv4", 4, 64, 128, 4), ("conv5", 3, 128, 128, 5), ("conv6", 3, 128, 128, 6)]),
+    "dilated_icpr_rate6_nodilation": ("relu", False, False, 256, [            # isprs:857-887 (is_normal_conv=True)
+        ("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 1), ("conv3", 4, 64, 128, 1),
+        ("conv4", 4, 128, 128, 1), ("conv5", 3, 128, 256, 1), ("conv6", 3, 256, 256, 1)]),
+    "dilated_icpr_rate1": ("relu", False, False, 256, [                       # coffee:788-802
+        ("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 1), ("conv3", 4, 64, 128, 1),
+        ("conv4", 4, 128, 128, 1), ("conv5", 3, 128, 256, 1), ("conv6", 3, 256, 256, 1)]),
+    "dilated_icpr_vary_rate": ("relu", False, False, 256, [                   # coffee:816-830
+        ("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2), ("conv3", 4, 64, 128, 4),
+        ("conv4", 4, 128, 128, 1), ("conv5", 3, 128, 256, 2), ("conv6", 3, 256, 256, 4)]),
     "dilated_icpr_rate6_densely": ("relu", False, True, 448, [
         ("conv1", 5, -1, 32, 1), ("conv2", 5, 32, 32, 2), ("conv3", 4, 64, 64, 3),
         ("conv4", 4, 128, 64, 4), ("conv5", 3, 192, 128, 5), ("conv6", 3, 320, 128, 6)]),

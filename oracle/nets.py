@@ -29,6 +29,27 @@ NETS = {
                ("conv5", 3, 128, 192, 5), ("conv6", 3, 192, 192, 6),
                ("conv7", 3, 192, 256, 7), ("conv8", 3, 256, 256, 8)],
         c_last=256),
+    # plain-chain variants (isprs:791-815, 857-911; coffee_dilated_random.py:665-707, 788-830)
+    "dilated_icpr_rate6": dict(
+        act="relu", pool=False, dense=False,
+        convs=[("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2), ("conv3", 4, 64, 128, 3),
+               ("conv4", 4, 128, 128, 4), ("conv5", 3, 128, 256, 5), ("conv6", 3, 256, 256, 6)], c_last=256),
+    "dilated_icpr_rate6_small": dict(
+        act="relu", pool=False, dense=False,
+        convs=[("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2), ("conv3", 4, 64, 64, 3),
+               ("conv4", 4, 64, 128, 4), ("conv5", 3, 128, 128, 5), ("conv6", 3, 128, 128, 6)], c_last=128),
+    "dilated_icpr_rate6_nodilation": dict(
+        act="relu", pool=False, dense=False,
+        convs=[("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 1), ("conv3", 4, 64, 128, 1),
+               ("conv4", 4, 128, 128, 1), ("conv5", 3, 128, 256, 1), ("conv6", 3, 256, 256, 1)], c_last=256),
+    "dilated_icpr_rate1": dict(
+        act="relu", pool=False, dense=False,
+        convs=[("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 1), ("conv3", 4, 64, 128, 1),
+               ("conv4", 4, 128, 128, 1), ("conv5", 3, 128, 256, 1), ("conv6", 3, 256, 256, 1)], c_last=256),
+    "dilated_icpr_vary_rate": dict(
+        act="relu", pool=False, dense=False,
+        convs=[("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2), ("conv3", 4, 64, 128, 4),
+               ("conv4", 4, 128, 128, 1), ("conv5", 3, 128, 256, 2), ("conv6", 3, 256, 256, 4)], c_last=256),
     "dilated_icpr_rate6_densely": dict(
         act="relu", pool=False, dense=True,
         convs=[("conv1", 5, -1, 32, 1), ("conv2", 5, 32, 32, 2),

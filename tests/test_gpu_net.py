@@ -13,7 +13,10 @@ pytestmark = pytest.mark.gpu
 from gpu_util import DEV, rel_err   # noqa: E402
 
 CASES = [("dilated_icpr_original", 3, 6, 2, 25), ("dilated_grsl", 5, 6, 3, 19), ("dilated8_grsl", 5, 6, 2, 26),
-         ("dilated_icpr_rate6_densely", 4, 2, 2, 21), ("dilated_grsl_rate8", 5, 6, 1, 45)]
+         ("dilated_icpr_rate6_densely", 4, 2, 2, 21), ("dilated_grsl_rate8", 5, 6, 1, 45),
+         # plain-chain variants beyond BASELINE's configs
+         ("dilated_icpr_rate6", 3, 6, 2, 17), ("dilated_icpr_rate6_small", 4, 6, 2, 16),
+         ("dilated_icpr_rate6_nodilation", 3, 2, 2, 14), ("dilated_icpr_vary_rate", 3, 7, 1, 19)]
 
 
 def _mk(net, ch, K, B, S, seed):
