@@ -37,6 +37,7 @@ SIGNATURES = {
                                 _p, _p]),
     "drs_stitch_accumulate": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "drs_stitch_finalize": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "drs_softmax_accumulate": (_i, [_p, _p, _i, _i, _i, _p, _p]),
 }
 
 

@@ -174,6 +174,20 @@ __global__ void stitch_finalize_kernel(const float* __restrict__ prob, const uns
   }
 }
 
+// multi-scale evaluation (isprs:1347-1474): per scale, softmax over classes of the averaged logits, summed over scales
+__global__ void softmax_accumulate_kernel(const float* __restrict__ prob, const unsigned int* __restrict__ occur, size_t npix, int K,
+                                          float* __restrict__ acc) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+    const double oc = (double)(occur[i] ? occur[i] : 1u);
+    float e[8], sum = 0.f;
+    for (int k = 0; k < K; ++k) {
+      e[k] = expf((float)((double)prob[i * K + k] / oc));     // the reference's softmax() has no max subtraction (isprs:38-43)
+      sum += e[k];
+    }
+    for (int k = 0; k < K; ++k) acc[i * K + k] += e[k] / sum;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -222,6 +236,14 @@ int drs_stitch_finalize(const float* prob, const unsigned int* occur, int h, int
   const size_t nb = (n + 255) / 256;
   DRS_LAUNCH(stitch_finalize_kernel, dim3(nb < 4096 ? (unsigned)nb : 4096u), dim3(256), 0, (hipStream_t)stream, prob, occur,
                      n, K, out);
+  return DRS_LAUNCH_CHECK();
+}
+
+int drs_softmax_accumulate(const float* prob, const unsigned int* occur, int h, int w, int K, float* acc, void* stream) {
+  if (!prob || !occur || !acc || K < 1 || K > 8) return DRS_ERR_ARG;
+  const size_t n = (size_t)h * w;
+  const size_t nb = (n + 255) / 256;
+  DRS_LAUNCH(softmax_accumulate_kernel, dim3(nb < 4096 ? (unsigned)nb : 4096u), dim3(256), 0, (hipStream_t)stream, prob, occur, n, K, acc);
   return DRS_LAUNCH_CHECK();
 }
 

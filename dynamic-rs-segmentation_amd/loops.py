@@ -278,7 +278,7 @@ def train(training_data, training_labels, training_class_distribution, training_
 
 
 # ------------------------------------------------------------------------------------------------- whole tiles
-def predict_tile(net, pool, map_index, crop_size, batch_size, mean_full, std_full, comm=None):
+def predict_tile(net, pool, map_index, crop_size, batch_size, mean_full, std_full, comm=None, return_sums=False):
     """The inner loop of validate_test / generate_final_maps (isprs:1261-1284, 1925-1949) for one tile: windows at
     stride floor(s/2) (isprs:1243), logits overlap-added in window order, arg-max of the average.  Returns the
     uint8 label map as a DEVICE tensor [h, w].  Under data parallelism batches of windows go round-robin over the
@@ -307,13 +307,46 @@ def predict_tile(net, pool, map_index, crop_size, batch_size, mean_full, std_ful
     if comm.world > 1:
         comm.all_reduce_sum(prob)
         comm.all_reduce_sum(occur)
+    if return_sums:
+        return prob, occur, total
     out = torch.zeros(h * w, dtype=torch.uint8, device=net.dev)
     _lib.call("drs_stitch_finalize", prob.data_ptr(), occur.data_ptr(), h, w, K, out.data_ptr(), st)
     return out.view(h, w), total
 
 
+def predict_tile_multiscale(net, pool, map_index, crop_sizes, batch_size, mean_full, std_full, comm=None):
+    """isprs:1347-1474 inner part: for every scale the averaged-logit map, softmax over classes, summed; arg-max."""
+    from . import _lib
+    h, w = pool.h[map_index], pool.w[map_index]
+    K = net.plan.K
+    acc = torch.zeros(h * w * K, dtype=torch.float32, device=net.dev)
+    for s_ in crop_sizes:
+        prob, occur, _ = predict_tile(net, pool, map_index, int(s_), batch_size, mean_full, std_full, comm, return_sums=True)
+        _lib.call("drs_softmax_accumulate", prob.data_ptr(), occur.data_ptr(), h, w, K, acc.data_ptr(), net._stream())
+    ones = torch.ones(h * w, dtype=torch.int32, device=net.dev)
+    out = torch.zeros(h * w, dtype=torch.uint8, device=net.dev)
+    _lib.call("drs_stitch_finalize", acc.data_ptr(), ones.data_ptr(), h, w, K, out.data_ptr(), net._stream())
+    return out.view(h, w)
+
+
+def best_sizes(distribution_type, values, patch_acc_loss, patch_occur, update_type, num_scales):
+    """The reference picks the best size, removes it from the candidates and repeats (isprs:1370-1420)."""
+    values = np.asarray(values).copy()
+    acc, occ = np.asarray(patch_acc_loss).copy(), np.asarray(patch_occur).copy()
+    chosen = []
+    for _ in range(num_scales):
+        if distribution_type not in ("multi_fixed", "uniform", "multinomial"):
+            chosen.append(int(values[0]))
+            continue
+        crop = select_best_patch_size(distribution_type, values, acc, occ, update_type)
+        chosen.append(int(crop))
+        ind = np.where(values == crop)
+        values, acc, occ = np.delete(values, ind), np.delete(acc, ind), np.delete(occ, ind)
+    return chosen
+
+
 def validate_test(net, testing_data, testing_labels, testing_instances, batch_size, mean_full, std_full, crop_size, step,
-                  output_path=None, comm=None, pool=None, ignore_label=6):
+                  output_path=None, comm=None, pool=None, ignore_label=6, crop_sizes=None):
     """isprs:1241-1344: per tile, sliding-window prediction and scores (label 6 = eroded boundary is skipped,
     isprs:1294).  Returns (all-maps confusion matrix, list of label maps as numpy)."""
     from . import _lib
@@ -326,7 +359,10 @@ def validate_test(net, testing_data, testing_labels, testing_instances, batch_si
     all_f1_per_class = np.zeros(K, dtype=np.float32)
     maps = []
     for k in range(len(testing_data)):
-        pred, _ = predict_tile(net, pool, k, crop_size, batch_size, mean_full, std_full, comm)
+        if crop_sizes:      # validate_test_multiscale (isprs:1347-1474): several sizes, softmax maps summed
+            pred = predict_tile_multiscale(net, pool, k, crop_sizes, batch_size, mean_full, std_full, comm)
+        else:
+            pred, _ = predict_tile(net, pool, k, crop_size, batch_size, mean_full, std_full, comm)
         h, w = pool.h[k], pool.w[k]
         conf = torch.zeros(K * K, dtype=torch.int32, device=net.dev)
         lab = pool.labels[int(pool.lab_off[k].item()):int(pool.lab_off[k].item()) + h * w]

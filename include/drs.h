@@ -143,6 +143,9 @@ int drs_stitch_accumulate(float* prob, unsigned int* occur, const float* logits,
                           int first_window, int n_windows, void* stream);
 int drs_stitch_finalize(const float* prob, const unsigned int* occur, int h, int w, int K, unsigned char* out,
                         void* stream);
+/* multi-scale evaluation (isprs:1347-1474, softmax isprs:38-43): acc[h][w][K] += softmax_k(prob / max(occur, 1));
+ * the label map of the summed scales is drs_stitch_finalize(acc, ones, ...). */
+int drs_softmax_accumulate(const float* prob, const unsigned int* occur, int h, int w, int K, float* acc, void* stream);
 
 #ifdef __cplusplus
 }

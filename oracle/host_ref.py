@@ -201,3 +201,18 @@ def stitch_tile(h, w, num_classes, crop_size, batches):
 def stride_for(crop_size):
     """isprs:1243."""
     return int(math.floor(crop_size / 2.0))
+
+
+def softmax_lastaxis(array):
+    """isprs:38-43 (no max subtraction; dtype of the input)."""
+    expa = np.exp(array)
+    return expa / np.sum(expa, axis=-1, keepdims=True)
+
+
+def multiscale_argmax(mean_logit_maps):
+    """isprs:1416-1424: per-scale softmax of the averaged logits (float32), summed over scales, arg-max."""
+    mean_prob = np.zeros((len(mean_logit_maps),) + mean_logit_maps[0].shape, dtype=np.float32)
+    for i, m in enumerate(mean_logit_maps):
+        mean_prob[i] = m
+        mean_prob[i] = softmax_lastaxis(mean_prob[i])
+    return np.argmax(np.sum(mean_prob, axis=0), axis=2)

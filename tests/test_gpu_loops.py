@@ -161,3 +161,42 @@ def test_config4_sliding_window_dilated8_at_64():
     assert total == P.window_counts(200, 260, 64, 32)[0] * P.window_counts(200, 260, 64, 32)[1] == 6 * 8
     got = pred.cpu().numpy()
     assert got.shape == (200, 260) and got.max() < 6
+
+
+def test_multiscale_evaluation_matches_oracle():
+    """validate_test_multiscale (isprs:1347-1474): per-size softmax maps summed."""
+    from drs_amd import loops, patches as P
+    from drs_amd.net import DilatedNet
+    rng = np.random.default_rng(8)
+    net_type, ch, K, bs = "dilated_grsl", 5, 6, 6
+    tile = rng.uniform(size=(44, 50, ch))
+    lab = rng.integers(0, 6, size=(44, 50)).astype(np.uint8)
+    mean, std = np.array([0.5, 0.5, 0.5, 0, 0]), np.array([0.25, 0.25, 0.25, 1, 1])
+    d = DilatedNet(net_type, ch, K, 0.005, b_max=bs, s_max=25, device=DEV, seed=5)
+    o = T.OracleNet(net_type, ch, K, seed=5)
+    for n in d.variable_names():
+        o.p[n] = d.get_variable(n).astype(np.float64)
+    sizes = loops.best_sizes("multi_fixed", [13, 25, 18], np.array([0.5, 0.9, 0.7], dtype=np.float32), np.array([1, 1, 1]), "acc", 2)
+    assert sizes == [25, 18]
+    pool = P.TilePool([tile], [lab], DEV)
+    pred = loops.predict_tile_multiscale(d, pool, 0, sizes, bs, mean, std).cpu().numpy()
+    maps = []
+    for S in sizes:
+        st = H.stride_for(S)
+        nh, nw = H.window_counts(44, 50, S, st)
+        batches = []
+        for i in range(-(-nh * nw // bs)):
+            p, _, pos = H.create_patches_per_map(tile, lab, S, st, i, bs)
+            p = p.copy()
+            H.normalize_images(p, mean, std)
+            batches.append((o.forward(p.astype(np.float32).astype(np.float64), False).astype(np.float32), pos))
+        prob, occur, _ = H.stitch_tile(44, 50, K, S, batches)
+        maps.append(prob / occur.astype(float))
+    want = H.multiscale_argmax(maps)
+    sm = np.sum([H.softmax_lastaxis(m.astype(np.float32)) for m in maps], axis=0)
+    srt = np.sort(sm, axis=2)
+    clear = (srt[..., -1] - srt[..., -2]) > 1e-3
+    assert clear.mean() > 0.9
+    np.testing.assert_array_equal(pred[clear], want[clear])
+    cm, _ = loops.validate_test(d, [tile], [lab], ["t"], bs, mean, std, None, 0, pool=pool, crop_sizes=sizes)
+    assert cm.sum() == 44 * 50
