@@ -7,9 +7,9 @@ coffee / contest flavours (coffee_dilated_random.py:1106-1150, contest_dilated_r
     path_train path_test output_path currentModelPath lr wd batch niter ref_crop ref_stride net_type distribution_type
     probValues update_type [operation]
 
-Dataset readers (TIFF/JPG through gdal / scipy.misc / skimage, torch-ASCII dumps, PGM) are outside the hot path
-(SURVEY.md section 8f-2).  Tiles are read from `<input_path><instance>.npz` (arrays `image` [H,W,C] float in [0,1],
-`label` [H,W] uint8) or generated when input_path is `synthetic:<H>x<W>x<C>/<dataset-name>/`.
+Tiles come from the ISPRS Vaihingen / Potsdam directory layouts (datasets.py: Pillow in place of the reference's
+gdal / scipy.misc / skimage), from `<input_path><instance>.npz` (arrays `image` [H,W,C] float in [0,1], `label` [H,W]
+uint8), or are generated when input_path is `synthetic:<H>x<W>x<C>/<dataset-name>/`.
 """
 import os
 import sys
@@ -36,8 +36,12 @@ def print_params(list_params, argv):
     print("+" * 97)
 
 
-def load_images(path, instances, process, num_classes=6):
-    """Stand-in for isprs:187-242 (see module docstring)."""
+def load_images(path, instances, process, num_classes=6, dataset=None):
+    """isprs:187-242.  The ISPRS directory layouts go through datasets.load_images (Pillow instead of
+    scipy.misc / gdal); `<instance>.npz` tiles and `synthetic:` paths are this build's additions."""
+    from . import datasets
+    if not path.startswith("synthetic:") and (os.path.isdir(os.path.join(path, "top")) or os.path.isdir(os.path.join(path, "4_Ortho_RGBIR"))):
+        return datasets.load_images(path, instances, process, image_type=dataset)
     images, masks = [], []
     for f in instances:
         print(loops.BatchColors.OKBLUE + "Reading instance " + str(f) + loops.BatchColors.ENDC)
@@ -97,8 +101,8 @@ def main(argv=None, device="cuda:0", comm=None):
     patch_acc_loss, patch_occur, patch_chosen_values, probs = init_size_scores(distribution_type, values)
 
     print(loops.BatchColors.WARNING + "Reading images..." + loops.BatchColors.ENDC)
-    training_data, training_labels = load_images(input_path, training_instances, process)
-    testing_data, testing_labels = load_images(input_path, testing_instances, process)
+    training_data, training_labels = load_images(input_path, training_instances, process, dataset=dataset)
+    testing_data, testing_labels = load_images(input_path, testing_instances, process, dataset=dataset)
     tag = os.path.join(os.getcwd(), "dataset_" + dataset + "_crop_" + str(reference_crop_size) + "_stride_" + str(reference_stride_crop))
     train_dist = test_dist = None
     if process == "training":
