@@ -200,3 +200,27 @@ def test_multiscale_evaluation_matches_oracle():
     np.testing.assert_array_equal(pred[clear], want[clear])
     cm, _ = loops.validate_test(d, [tile], [lab], ["t"], bs, mean, std, None, 0, pool=pool, crop_sizes=sizes)
     assert cm.sum() == 44 * 50
+
+
+def test_cli_training_then_validate_test_then_final_maps(tmp_path, monkeypatch, capsys):
+    """The reference's three `process` values through the same 16 positional arguments (isprs:1987-2042)."""
+    from drs_amd import cli
+    monkeypatch.chdir(tmp_path)           # the reference keeps its .npy caches in the cwd (isprs:2087-2115)
+    out = str(tmp_path) + "/out_"
+    common = ["isprs_dilated_random.py", "synthetic:70x80x5/vaihingen/", out]
+    tail = ["a,b", "c", "0.01", "0.005", "4", "3", "25", "10", "dilated8_grsl", "multi_fixed", "9,13", "acc"]
+    random.seed(0)
+    np.random.seed(0)
+    net = cli.main(common + ["none"] + tail + ["training"], device=DEV)
+    assert net.global_step == 3 and os.path.isfile(out + "model-3.npz")
+    for f in ("_rotation.npy", "_mean.npy", "_std.npy"):
+        assert os.path.isfile(os.path.join(str(tmp_path), "dataset_vaihingen_crop_25_stride_10" + f))
+    cm, maps = cli.main(common + [out + "model-3"] + tail + ["validate_test"], device=DEV)
+    assert cm.sum() > 0 and maps[0].shape == (70, 80)
+    maps2 = cli.main(common + [out + "model-3"] + tail + ["generate_final_maps"], device=DEV)
+    np.testing.assert_array_equal(maps2[0], maps[0])
+    assert os.path.isfile(out + "top_mosaic_09cm_areac_class.npy")
+    text = capsys.readouterr().out
+    assert "Test ALL MAPS" in text and "net_type" in text
+    with pytest.raises(SystemExit):
+        cli.main(["isprs_dilated_random.py", "too", "few"], device=DEV)
