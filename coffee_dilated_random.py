@@ -1,0 +1,10 @@
+#!/usr/bin/env python3
+"""Same command line as the reference's coffee_dilated_random.py; the work runs on the MI355X path (drs_amd.cli)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+if __name__ == "__main__":
+    from drs_amd.cli import main_coffee
+    main_coffee(sys.argv)

@@ -144,5 +144,83 @@ def main(argv=None, device="cuda:0", comm=None):
     print(loops.BatchColors.FAIL + "Process " + process + "not found!" + loops.BatchColors.ENDC)
 
 
+COFFEE_PARAMS = ["path_train", "path_test", "output_path(for model, images, etc)", "currentModelPath", "learningRate",
+                 "weight_decay", "batch_size", "niter", "reference_crop_size", "reference_stride_crop", "net_type",
+                 "distribution_type[single_fixed|multi_fixed|uniform|multinomial]", "probValues", "update_type [acc|loss]"]
+CONTEST_PARAMS = ["path", "output_path(for model, images, etc)", "currentModelPath", "learningRate", "weight_decay", "batch_size",
+                  "niter", "crop_size", "stride_crop", "net_type", "distribution_type[single_fixed|multi_fixed|uniform|multinomial]",
+                  "probValues", "update_type [acc|loss]", "operation [train|test]"]
+
+
+def _load_stack(path, num_classes, seed0):
+    """coffee `load_images_torch` (coffee:116-125) on a directory of Torch-ASCII dumps; `synthetic:<n>x<H>x<W>x<C>/` generates."""
+    from . import datasets
+    if path.startswith("synthetic:"):
+        n, h, w, c = [int(v) for v in path[len("synthetic:"):].split("/")[0].split("x")]
+        tl = [make_tile(h, w, c, num_classes, seed=seed0 + i) for i in range(n)]
+        return [t[0].astype(np.float32) for t in tl], [t[1] for t in tl]
+    imgs, masks = datasets.load_images_torch(path)
+    return list(imgs), [np.squeeze(m).astype(np.uint8) for m in masks]
+
+
+def main_coffee(argv=None, device="cuda:0", comm=None):
+    """coffee_dilated_random.py:1105-1150: 2 classes, 3 bands, errorAcc_/errorOccur_/chosenValues_ side files."""
+    from . import loops_indexed as LI
+    argv = list(sys.argv if argv is None else argv)
+    if len(argv) < len(COFFEE_PARAMS) + 1:
+        sys.exit("Usage: " + argv[0] + " " + " ".join(COFFEE_PARAMS))
+    print_params(COFFEE_PARAMS, argv)
+    path_train, path_test, output_path, current_model, lr, wd, bs, niter, ref_crop, ref_stride, net_type, dist, pv, update_type = argv[1:15]
+    values = [int(i) for i in pv.split(",")]
+    resolve(net_type)
+    acc, occ, chosen, probs = init_size_scores(dist, values)
+    train_x, train_y = _load_stack(path_train, 2, 100)
+    test_x, test_y = _load_stack(path_test, 2, 200)
+    cd = LI.create_distributions_over_classes(train_y, int(ref_crop), int(ref_stride), 2)
+    mean_full, std_full = LI.create_mean_and_std(train_x, int(ref_crop), int(ref_stride))
+    return LI.train(train_x, train_y, test_x, test_y, cd, mean_full, std_full, output_path, current_model, float(lr), float(wd),
+                    int(bs), int(niter), net_type, dist, update_type, acc, occ, chosen, probs, values, num_classes=2,
+                    side_names=("errorAcc_step_", "errorOccur_step_", "chosenValues_step_"), device=device, comm=comm)
+
+
+def main_contest(argv=None, device="cuda:0", comm=None):
+    """contest_dilated_random.py:1228-1313: 7 classes + void label 7, 3 bands, operation train | test."""
+    from . import datasets, loops_indexed as LI
+    argv = list(sys.argv if argv is None else argv)
+    if len(argv) < len(CONTEST_PARAMS) + 1:
+        sys.exit("Usage: " + argv[0] + " " + " ".join(CONTEST_PARAMS))
+    print_params(CONTEST_PARAMS, argv)
+    path, output_path, current_model, lr, wd, bs, niter, crop, stride, net_type, dist, pv, update_type, operation = argv[1:15]
+    values = [int(i) for i in pv.split(",")]
+    resolve(net_type)
+    acc, occ, chosen, probs = init_size_scores(dist, values, occur_init=1)            # contest:1275
+    if path.startswith("synthetic:"):
+        h, w, c = [int(v) for v in path[len("synthetic:"):].split("/")[0].split("x")]
+        (tx, ty), (ex, ey) = make_tile(h, w, c, 8, seed=11), make_tile(h, w, c, 8, seed=12)   # label 7 plays the void role
+        train_x, train_y, test_x, test_y = [tx.astype(np.float32)], [ty], [ex.astype(np.float32)], [ey]
+    else:
+        train_x = [datasets.read_torch_ascii(path + "TelopsDatasetCityVisible_20cm_Subset.txt")]
+        test_x = [datasets.read_torch_ascii(path + "TelopsDatasetCityVisible.txt")]
+        train_y, test_y = [datasets.read_pgm(path + "gt8.pgm").astype(np.uint8)], [datasets.read_pgm(path + "gt_ult8.pgm").astype(np.uint8)]
+    cd = LI.create_distributions_over_classes(train_y, int(crop), int(stride), 7)
+    mean_full, std_full = LI.create_mean_and_std(train_x, int(crop), int(stride))
+    if operation == "train":
+        return LI.train(train_x, train_y, test_x, test_y, cd, mean_full, std_full, output_path, current_model, float(lr), float(wd),
+                        int(bs), int(niter), net_type, dist, update_type, acc, occ, chosen, probs, values, num_classes=7,
+                        void_label=7, device=device, comm=comm)
+    if operation == "test":
+        from .net import DilatedNet
+        step = loops.step_from_model_path(current_model)
+        sized = dist in ("multi_fixed", "uniform", "multinomial")
+        if sized:
+            acc = np.load(output_path + "patch_acc_loss_step_" + str(step) + ".npy")
+            occ = np.load(output_path + "patch_occur_step_" + str(step) + ".npy")
+        net = DilatedNet(net_type, train_x[0].shape[-1], 7, float(wd), b_max=int(bs), s_max=max(values), device=device, comm=comm)
+        loops.load_checkpoint(net, current_model)
+        cs = loops.select_best_patch_size(dist, values, acc, occ, update_type, debug=True) if sized else int(values[0])
+        return loops.validate_test(net, test_x, test_y, ["test"], int(bs), mean_full, std_full, cs, step, output_path, comm, ignore_label=7)
+    print(loops.BatchColors.FAIL + "Process " + operation + "not found!" + loops.BatchColors.ENDC)
+
+
 if __name__ == "__main__":
     main()

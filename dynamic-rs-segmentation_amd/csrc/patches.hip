@@ -26,6 +26,7 @@ struct CropArgs {
   const double* noise;          // [B][S][S][C] additive noise (pre-flip coordinates) or null
   const unsigned char* noise_on;  // [B] or null
   unsigned long long seed;      // device noise (Philox) when noise == null and noise_on[b]
+  int void_label;               // pixels carrying this label are masked out too (contest:235-239); -1 = none
   double mean[3], stdv[3];
   float* out; int S, P, ld;     // conv1 input slab [B][S+2P][S+2P][ld]
   unsigned char* out_lab;       // [B][S][S]
@@ -100,7 +101,7 @@ __global__ void crop_kernel(const CropArgs a) {
       v[c] = (float)e;
     }
     if (a.out_lab) a.out_lab[opix] = lab;
-    if (a.out_mask) a.out_mask[opix] = valid ? 1 : 0;
+    if (a.out_mask) a.out_mask[opix] = (valid && (int)lab != a.void_label) ? 1 : 0;
   }
   // one pixel = ld floats: the real channels, then zero padding up to the conv1 K-step
   for (int c4 = 0; c4 < a.ld; c4 += 4) {
@@ -196,14 +197,14 @@ int drs_crop_normalize(const void* tiles, int tiles_are_f64, const unsigned char
                        const long long* lab_off, const int* tile_h, const int* tile_w, int C, const int* inst,
                        const double* rot, const unsigned char* rot_on, const double* noise, const unsigned char* noise_on,
                        unsigned long long seed, const double* mean3, const double* std3, int B, int S, int P, int ld,
-                       float* out, unsigned char* out_lab, unsigned char* out_mask, void* stream) {
+                       float* out, unsigned char* out_lab, unsigned char* out_mask, int void_label, void* stream) {
   if (!tiles || !labels || !tile_off || !lab_off || !tile_h || !tile_w || !inst || !out || !mean3 || !std3) return DRS_ERR_ARG;
   if (C < 1 || C > 8 || ld < C || ld % 4) return DRS_ERR_ARG;
   const int Sp = S + 2 * P;
   if ((long long)B * Sp > 65535) return DRS_ERR_ARG;
   CropArgs a;
   a.tiles = tiles; a.labels = labels; a.tile_off = tile_off; a.lab_off = lab_off; a.tile_h = tile_h; a.tile_w = tile_w; a.C = C;
-  a.inst = inst; a.rot = rot; a.rot_on = rot ? rot_on : nullptr; a.noise = noise; a.noise_on = noise_on; a.seed = seed;
+  a.inst = inst; a.rot = rot; a.rot_on = rot ? rot_on : nullptr; a.noise = noise; a.noise_on = noise_on; a.seed = seed; a.void_label = void_label;
   for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.stdv[c] = std3[c]; }
   a.out = out; a.S = S; a.P = P; a.ld = ld; a.out_lab = out_lab; a.out_mask = out_mask;
   dim3 grid((Sp + 63) / 64, B * Sp);

@@ -207,7 +207,7 @@ class _Staging(object):
         return base + self.o_inst, base + self.o_rot, base + self.o_ron, base + self.o_non
 
 
-def crop_to_net(net, pool, instances, S, mean, std, aug=None):
+def crop_to_net(net, pool, instances, S, mean, std, aug=None, void_label=-1):
     """dynamically_create_patches + normalize_images (isprs:1742-1745 / 1579-1583) fused on the device:
     fills net's conv1 slab, net.labels and net.acc_mask for `instances` rows (map, x, y[, rot])."""
     import ctypes as C
@@ -233,7 +233,7 @@ def crop_to_net(net, pool, instances, S, mean, std, aug=None):
               p_inst, p_rot if aug is not None else None, p_ron if aug is not None else None,
               None if noise is None else noise.data_ptr(), p_non if aug is not None else None,
               aug.seed if aug is not None else 0, C.cast(m3c, C.c_void_p), C.cast(s3c, C.c_void_p), B, S, P, ld,
-              slab.data_ptr(), net.labels.data_ptr(), net.acc_mask.data_ptr(), net._stream())
+              slab.data_ptr(), net.labels.data_ptr(), net.acc_mask.data_ptr(), int(void_label), net._stream())
     net._keep = noise                                            # alive until the stream has consumed it
     return inst[:, 1:3]
 

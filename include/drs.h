@@ -127,14 +127,15 @@ int drs_confusion(const unsigned char* labels, const unsigned char* pred, const 
  * rot [B][6] = (m00 m01 m10 m11 off0 off1) of scipy.ndimage.rotate(order=0, reshape=False) when rot_on[b];
  * noise [B][S][S][C] (fp64, reference-exact) or NULL (device Philox N(0, 0.01)) when noise_on[b];
  * out: conv1 input slab [B][S+2P][S+2P][ld] (channels C..ld-1 and the halo are zeroed);
- * out_lab / out_mask [B][S][S] (uint8).  Normalisation touches channels 0,1,2 only.
+ * out_lab / out_mask [B][S][S] (uint8); out_mask is 0 where the rotation pulled in fill or the label equals
+ * void_label (contest_dilated_random.py:235-239; -1 = none).  Normalisation touches channels 0,1,2 only.
  * mean3 / std3 are HOST pointers to 3 doubles each (copied into the kernel arguments). */
 int drs_crop_normalize(const void* tiles, int tiles_are_f64, const unsigned char* labels, const long long* tile_off,
                        const long long* lab_off, const int* tile_h, const int* tile_w, int C, const int* inst,
                        const double* rot, const unsigned char* rot_on, const double* noise,
                        const unsigned char* noise_on, unsigned long long seed, const double* mean3, const double* std3,
                        int B, int S, int P, int ld, float* out, unsigned char* out_lab, unsigned char* out_mask,
-                       void* stream);
+                       int void_label, void* stream);
 
 /* ---- overlap-add of window logits and arg-max of the average  (isprs:1261-1284, 1925-1949) ---------------
  * windows [first_window, first_window + n_windows) of the row-major window grid at `stride` (last row/col

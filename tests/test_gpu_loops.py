@@ -224,3 +224,43 @@ def test_cli_training_then_validate_test_then_final_maps(tmp_path, monkeypatch, 
     assert "Test ALL MAPS" in text and "net_type" in text
     with pytest.raises(SystemExit):
         cli.main(["isprs_dilated_random.py", "too", "few"], device=DEV)
+
+
+def test_coffee_and_contest_command_lines(tmp_path, capsys):
+    """coffee_dilated_random.py:1106-1150 (14 arguments) and contest_dilated_random.py:1229-1271 (14 incl. operation)."""
+    from drs_amd import cli
+    out = str(tmp_path) + "/"
+    random.seed(1)
+    np.random.seed(1)
+    net = cli.main_coffee(["coffee_dilated_random.py", "synthetic:2x60x60x3/", "synthetic:1x60x60x3/", out, "none", "0.01", "0.001", "6",
+                           "4", "25", "10", "dilated_icpr_rate6_small", "multi_fixed", "9,13", "loss"], device=DEV)
+    assert net.plan.K == 2 and net.global_step == 4 and net.lr_decay_factor == 0.1
+    for f in ("model-4.npz", "errorAcc_step_4.npy", "errorOccur_step_4.npy", "chosenValues_step_4.npy"):     # coffee:1341-1343
+        assert os.path.isfile(out + f), f
+    net = cli.main_contest(["contest_dilated_random.py", "synthetic:80x70x3/", out, "none", "0.01", "0.001", "4", "3", "25", "10",
+                            "dilated_grsl", "multi_fixed", "9,13", "acc", "train"], device=DEV)
+    assert net.plan.K == 7 and net.global_step == 3
+    assert np.load(out + "patch_occur_step_3.npy").sum() == 2 + 3                   # starts at ones (contest:1275)
+    cm, maps = cli.main_contest(["contest_dilated_random.py", "synthetic:80x70x3/", out, out + "model-3", "0.01", "0.001", "4", "3", "25",
+                                 "10", "dilated_grsl", "multi_fixed", "9,13", "acc", "test"], device=DEV)
+    assert cm.shape == (7, 7) and maps[0].shape == (80, 70)
+    assert "Test ALL MAPS" in capsys.readouterr().out
+
+
+def test_void_label_is_masked_out_of_loss_and_accuracy():
+    from drs_amd import patches as P
+    from drs_amd.net import DilatedNet
+    rng = np.random.default_rng(0)
+    tile = rng.uniform(size=(40, 40, 3)).astype(np.float32)
+    lab = rng.integers(0, 8, size=(40, 40)).astype(np.uint8)
+    pool = P.TilePool([tile], [lab], DEV, dtype=np.float32)
+    d = DilatedNet("dilated_grsl", 3, 7, 0.0, b_max=2, s_max=16, device=DEV)
+    inst = np.array([[0, 0, 0], [0, 20, 24]])
+    P.crop_to_net(d, pool, inst, 16, [0, 0, 0], [1, 1, 1], void_label=7)
+    M = 2 * 16 * 16
+    want = np.stack([lab[0:16, 0:16], lab[20:36, 24:40]]) != 7
+    np.testing.assert_array_equal(d.acc_mask[:M].cpu().numpy().reshape(2, 16, 16).astype(bool), want)
+    d.loss_mask[:M].copy_(d.acc_mask[:M])
+    out = d.train_step(2, 16, 0.01, use_loss_mask=True, global_pixels=int(want.sum()), apply_update=False)
+    assert int(out["conf"].sum().item()) == int(want.sum())
+    assert np.isfinite(d.loss_value(out["loss_parts"]))
