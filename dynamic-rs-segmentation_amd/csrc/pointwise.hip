@@ -376,6 +376,50 @@ __global__ void bn_bwd_reduce_slide_kernel(const float* __restrict__ ga, int ld_
   }
 }
 
+// ------------------------------------------------------------------------------------------------ average pool (k x k, stride 1, SAME)
+// tf.nn.avg_pool(..., 'SAME') of the `_avgpool` net variant (isprs:818-854): the divisor counts only the pixels inside
+// the image.  Forward: in [B*S*S][C] -> interior of a haloed view; backward: every output hands g/count to each pixel of
+// its window, gathered here per input pixel (odd k: p is in q's window iff q is in p's).
+__device__ __forceinline__ int win_count(int c, int S, int r) {       // valid positions of a (2r+1)-window centred at c
+  const int lo = c - r < 0 ? 0 : c - r, hi = c + r > S - 1 ? S - 1 : c + r;
+  return hi - lo + 1;
+}
+
+template <bool BWD>
+__global__ void avg_pool_kernel(const float* __restrict__ in, int ld_in, int coff_in, int B, int S, int C, int k, ActView out) {
+  const int CQ = C >> 2;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= S * CQ) return;
+  const int x = e / CQ, cq = e - x * CQ;
+  const int b = blockIdx.y / S, y = blockIdx.y - b * S;
+  const int r = k >> 1;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int dy = -r; dy <= r; ++dy) {
+    const int qy = y + dy;
+    if (qy < 0 || qy >= S) continue;
+    for (int dx = -r; dx <= r; ++dx) {
+      const int qx = x + dx;
+      if (qx < 0 || qx >= S) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(in + (((size_t)b * S + qy) * S + qx) * ld_in + coff_in + cq * 4);
+      if (BWD) {
+        const float w = 1.0f / (float)(win_count(qy, S, r) * win_count(qx, S, r));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += v[j] * w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += v[j];
+      }
+    }
+  }
+  if (!BWD) {
+    const float w = 1.0f / (float)(win_count(y, S, r) * win_count(x, S, r));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] *= w;
+  }
+  const int Sp = S + 2 * out.P;
+  *reinterpret_cast<f32x4*>(out.base + ((size_t)(b * Sp + y + out.P) * Sp + x + out.P) * out.ld + out.coff + cq * 4) = acc;
+}
+
 // pass B: g_z = rstd * (g_xhat - mean(g_xhat) - xhat * mean(g_xhat * xhat)), written into a zero-haloed view
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ gxh, const float* __restrict__ z, int B, int S, int C,
                                     const float* __restrict__ mean_rstd, const double* __restrict__ sums, double count,
@@ -775,6 +819,24 @@ int drs_confusion(const unsigned char* labels, const unsigned char* pred, const 
   const size_t nb = (n + 255) / 256;
   DRS_LAUNCH(confusion_kernel, dim3(nb < 1024 ? (unsigned)nb : 1024u), dim3(256), 0, (hipStream_t)stream, labels, pred, mask,
                      n, K, ignore_label, conf);
+  return DRS_LAUNCH_CHECK();
+}
+
+int drs_avg_pool_forward(const float* in, int B, int S, int C, int k, float* out, int P_out, int ld_out, int coff_out, void* stream) {
+  if (!in || !out || C % 4 || k < 1 || !(k & 1) || (long long)B * (S + 2 * P_out) > 65535) return DRS_ERR_ARG;
+  ActView v = mkview(out, S, P_out, ld_out, coff_out);
+  if (P_out > 0) {
+    const int Sp = S + 2 * P_out;
+    DRS_LAUNCH(zero_halo_kernel, dim3((Sp * (C / 4) + 255) / 256, B * Sp), dim3(256), 0, (hipStream_t)stream, v, B, C);
+  }
+  DRS_LAUNCH(avg_pool_kernel<false>, dim3((S * (C / 4) + 255) / 256, B * S), dim3(256), 0, (hipStream_t)stream, in, C, 0, B, S, C, k, v);
+  return DRS_LAUNCH_CHECK();
+}
+
+int drs_avg_pool_backward(const float* gout, int ld_g, int coff_g, int B, int S, int C, int k, float* gin, void* stream) {
+  if (!gout || !gin || C % 4 || k < 1 || !(k & 1) || (long long)B * S > 65535) return DRS_ERR_ARG;
+  DRS_LAUNCH(avg_pool_kernel<true>, dim3((S * (C / 4) + 255) / 256, B * S), dim3(256), 0, (hipStream_t)stream, gout, ld_g, coff_g, B, S, C,
+             k, mkview(gin, S, 0, C, 0));
   return DRS_LAUNCH_CHECK();
 }
 

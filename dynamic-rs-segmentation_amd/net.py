@@ -176,7 +176,7 @@ class DilatedNet(object):
                     self.xin[i] = torch.zeros(B * (S + 2 * L.halo) ** 2 * L.cin_k, **f32)
             self.feat = torch.zeros(M * p.c_last, **f32)
         self.z = [torch.zeros(M * L.cout, **f32) for L in p.layers]
-        self.idx = [torch.zeros(M * L.cout, **u8) if p.pool else None for L in p.layers]
+        self.idx = [torch.zeros(M * L.cout, **u8) if self._is_max(i) else None for i, L in enumerate(p.layers)]
         self.mean_rstd = [torch.zeros(L.cout * 2, **f32) for L in p.layers]
         cmax = max(max(L.cout for L in p.layers), max(L.cin_k for L in p.layers[1:]))
         hmax = max(L.halo for L in p.layers)
@@ -184,11 +184,13 @@ class DilatedNet(object):
         self.colsum_scratch = torch.zeros(_lib.query("drs_colsum_scratch_doubles", max(2 * cmax, p.c_last * p.K)), **f64)
         rows_fwd = max((M + _lib.query("drs_conv_mtile", L.cout) - 1) // _lib.query("drs_conv_mtile", L.cout)
                        for L in p.layers)
-        pool = 1 if p.pool else 0
         # the slab's row count depends on the patch size through the kernel's tiling: size it for every S up to s_max
-        part = max(max(_lib.query("drs_bn_backward_rows", B, s, L.cout, pool) * L.cout * 2 for L in p.layers)
-                   for s in range(1, S + 1))
+        part = max(max(_lib.query("drs_bn_backward_rows", B, s, L.cout, 1 if self._is_max(i) else 0) * L.cout * 2
+                       for i, L in enumerate(p.layers)) for s in range(1, S + 1))
         self.partial = torch.zeros(max(rows_fwd * cmax * 2, part), **f32)
+        if any(q is not None and q[0] == "avg" for q in p.pools):
+            self.act = torch.zeros(M * cmax, **f32)        # activated, not yet averaged output of a layer
+            self.gpool = torch.zeros(M * cmax, **f32)      # gradient wrt it
         self.gA = torch.zeros(M * cmax, **f32)
         self.gB = torch.zeros(M * cmax, **f32)
         self.gxh = torch.zeros(M * cmax, **f32)
@@ -220,6 +222,14 @@ class DilatedNet(object):
         return tot
 
     # ------------------------------------------------------------------ views
+    def _is_max(self, i):
+        q = self.plan.pools[i]
+        return q is not None and q[0] == "max"
+
+    def _avg_k(self, i):
+        q = self.plan.pools[i]
+        return q[1] if q is not None and q[0] == "avg" else 0
+
     def _stream(self):
         return torch.cuda.current_stream(self.dev).cuda_stream
 
@@ -313,9 +323,16 @@ class DilatedNet(object):
             else:
                 _lib.call("drs_bn_eval_coeffs", _ptr(mm), _ptr(mv), L.cout, _ptr(self.mean_rstd[i]), st)
             out, Pout, ldout, coff = self._out_view(i)
-            self._k("bn_act_pool_fwd", M * L.cout * (9.0 if (training and p.pool) else 8.0), "drs_bn_act_pool_forward",
-                    _ptr(self.z[i]), B, S, L.cout, _ptr(self.mean_rstd[i]), p.alpha, 1 if p.pool else 0, _ptr(out), Pout, ldout,
-                    coff, _ptr(self.idx[i]) if (training and p.pool) else None, st)
+            mx, ak = self._is_max(i), self._avg_k(i)
+            if ak:      # activation into a plain [M][C] buffer, then the k x k average into the next layer's slab
+                self._k("bn_act_pool_fwd", M * L.cout * 8.0, "drs_bn_act_pool_forward", _ptr(self.z[i]), B, S, L.cout,
+                        _ptr(self.mean_rstd[i]), p.alpha, 0, _ptr(self.act), 0, L.cout, 0, None, st)
+                self._k("avg_pool_fwd", M * L.cout * 8.0, "drs_avg_pool_forward", _ptr(self.act), B, S, L.cout, ak, _ptr(out), Pout,
+                        ldout, coff, st)
+            else:
+                self._k("bn_act_pool_fwd", M * L.cout * (9.0 if (training and mx) else 8.0), "drs_bn_act_pool_forward",
+                        _ptr(self.z[i]), B, S, L.cout, _ptr(self.mean_rstd[i]), p.alpha, 1 if mx else 0, _ptr(out), Pout, ldout,
+                        coff, _ptr(self.idx[i]) if (training and mx) else None, st)
 
     def forward(self, B, S, want_logits=True, labels=False, acc_mask=False, ignore_label=-1):
         """is_training=False pass over the slab filled by crop/feed: returns (pred uint8 [B,S,S] device,
@@ -396,11 +413,18 @@ class DilatedNet(object):
             L = p.layers[i]
             if p.dense:
                 gcur, ldc, cc = self.gconcat, p.c_last, p.concat_off[i]
-            self._k("bn_bwd_reduce", M * L.cout * (13.0 if p.pool else 12.0), "drs_bn_backward_reduce", _ptr(gcur), ldc, cc,
-                    _ptr(self.z[i]), _ptr(self.idx[i]), B, S, L.cout, _ptr(self.mean_rstd[i]), p.alpha, 1 if p.pool else 0,
+            mx, ak = self._is_max(i), self._avg_k(i)
+            if ak:
+                self._k("avg_pool_bwd", M * L.cout * 8.0, "drs_avg_pool_backward", _ptr(gcur), ldc, cc, B, S, L.cout, ak,
+                        _ptr(self.gpool), st)
+                gsrc, lds_, cs_ = self.gpool, L.cout, 0
+            else:
+                gsrc, lds_, cs_ = gcur, ldc, cc
+            self._k("bn_bwd_reduce", M * L.cout * (13.0 if mx else 12.0), "drs_bn_backward_reduce", _ptr(gsrc), lds_, cs_,
+                    _ptr(self.z[i]), _ptr(self.idx[i]), B, S, L.cout, _ptr(self.mean_rstd[i]), p.alpha, 1 if mx else 0,
                     _ptr(self.gxh), _ptr(self.partial), st)
-            _lib.call("drs_stats_reduce", _ptr(self.partial), _lib.query("drs_bn_backward_rows", B, S, L.cout, 1 if p.pool else 0), L.cout, _ptr(self.sums),
-                      _ptr(self.colsum_scratch), st)
+            _lib.call("drs_stats_reduce", _ptr(self.partial), _lib.query("drs_bn_backward_rows", B, S, L.cout, 1 if mx else 0), L.cout,
+                      _ptr(self.sums), _ptr(self.colsum_scratch), st)
             self.comm.all_reduce_sum(self.sums[:2 * L.cout])
             self._k("bn_bwd_apply", M * L.cout * 12.0, "drs_bn_backward_apply", _ptr(self.gxh), _ptr(self.z[i]), B, S, L.cout,
                     _ptr(self.mean_rstd[i]), _ptr(self.sums), n_bn, _ptr(self.gz), L.halo, L.cout, 0, st)

@@ -34,6 +34,10 @@ _TABLES = {
     "dilated_icpr_vary_rate": ("relu", False, False, 256, [                   # coffee:816-830
         ("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2), ("conv3", 4, 64, 128, 4),
         ("conv4", 4, 128, 128, 1), ("conv5", 3, 128, 256, 2), ("conv6", 3, 256, 256, 4)]),
+    # average-pooled variant (isprs:818-854, coffee:721-740): 5x5 / 7x7 stride-1 SAME average pools, none after conv6
+    "dilated_icpr_rate6_avgpool": ("relu", [("avg", 5), ("avg", 5), ("avg", 5), ("avg", 7), ("avg", 7), None], False, 256, [
+        ("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2), ("conv3", 4, 64, 128, 3),
+        ("conv4", 4, 128, 128, 4), ("conv5", 3, 128, 256, 5), ("conv6", 3, 256, 256, 6)]),
     "dilated_icpr_rate6_densely": ("relu", False, True, 448, [
         ("conv1", 5, -1, 32, 1), ("conv2", 5, 32, 32, 2), ("conv3", 4, 64, 64, 3),
         ("conv4", 4, 128, 64, 4), ("conv5", 3, 192, 128, 5), ("conv6", 3, 320, 128, 6)]),
@@ -71,7 +75,10 @@ class Plan(object):
 
     def __init__(self, net_type, channels, num_classes):
         self.net_type = resolve(net_type)
-        act, self.pool, self.dense, self.c_last, convs = _TABLES[self.net_type]
+        act, pool, self.dense, self.c_last, convs = _TABLES[self.net_type]
+        # per-layer pooling after the activation: None | ("max", 3) | ("avg", k)
+        self.pools = list(pool) if isinstance(pool, list) else [("max", 3) if pool else None] * len(convs)
+        self.pool = any(q is not None and q[0] == "max" for q in self.pools)
         self.alpha = 0.0 if act == "relu" else 0.1      # max(alpha*x, x): ReLU / leaky ReLU (isprs:620-621)
         self.channels = channels
         self.K = num_classes

@@ -92,6 +92,13 @@ int drs_bn_backward_apply(const float* gxhat, const float* z, int B, int S, int 
                           const double* sums, double count, float* gz, int P_out, int ld_out, int coff_out,
                           void* stream);
 
+/* ---- tf.nn.avg_pool(k x k, stride 1, SAME) of the `_avgpool` variant (isprs:753-758, 818-854) ------------------
+ * forward: in [B*S*S][C] -> interior of a haloed view (halo zeroed), divisor = pixels of the window inside the image;
+ * backward: gout [B*S*S][ld_g]+coff_g -> gin [B*S*S][C].  k odd. */
+int drs_avg_pool_forward(const float* in, int B, int S, int C, int k, float* out, int P_out, int ld_out, int coff_out,
+                         void* stream);
+int drs_avg_pool_backward(const float* gout, int ld_g, int coff_g, int B, int S, int C, int k, float* gin, void* stream);
+
 /* ---- 1x1 classifier + sparse softmax cross-entropy + tf.argmax (+ their gradients) ----------------------
  * (isprs:1024-1031, 1089-1099, 1690; masked loss: contest_dilated_random.py:881-901; confusion matrix:
  * calc_accuracy_by_crop isprs:510-531).  feat: haloed view with C channels (multiple of 64, <= 448);

@@ -50,6 +50,11 @@ NETS = {
         act="relu", pool=False, dense=False,
         convs=[("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2), ("conv3", 4, 64, 128, 4),
                ("conv4", 4, 128, 128, 1), ("conv5", 3, 128, 256, 2), ("conv6", 3, 256, 256, 4)], c_last=256),
+    # isprs:818-854 / coffee:721-740: average pools (5,5,5,7,7) after conv1..5, none after conv6
+    "dilated_icpr_rate6_avgpool": dict(
+        act="relu", pool=False, dense=False, pools=[5, 5, 5, 7, 7, 0],
+        convs=[("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2), ("conv3", 4, 64, 128, 3),
+               ("conv4", 4, 128, 128, 4), ("conv5", 3, 128, 256, 5), ("conv6", 3, 256, 256, 6)], c_last=256),
     "dilated_icpr_rate6_densely": dict(
         act="relu", pool=False, dense=True,
         convs=[("conv1", 5, -1, 32, 1), ("conv2", 5, 32, 32, 2),

@@ -127,6 +127,34 @@ def max_pool_3x3_bwd(idx, g):
     return gp[:, 1:-1, 1:-1, :]
 
 
+def avg_pool_same(x, k):
+    """tf.nn.avg_pool(ksize k x k, strides 1, SAME) (isprs:753-758): the divisor counts only in-image pixels."""
+    B, H, W, C = x.shape
+    r = k // 2
+    xp = np.zeros((B, H + 2 * r, W + 2 * r, C), dtype=x.dtype)
+    xp[:, r:r + H, r:r + W, :] = x
+    ones = np.zeros((H + 2 * r, W + 2 * r), dtype=x.dtype)
+    ones[r:r + H, r:r + W] = 1
+    tot = np.zeros_like(x)
+    cnt = np.zeros((H, W), dtype=x.dtype)
+    for dy in range(k):
+        for dx in range(k):
+            tot += xp[:, dy:dy + H, dx:dx + W, :]
+            cnt += ones[dy:dy + H, dx:dx + W]
+    return tot / cnt[None, :, :, None], cnt
+
+
+def avg_pool_same_bwd(g, k, cnt):
+    B, H, W, C = g.shape
+    r = k // 2
+    gp = np.zeros((B, H + 2 * r, W + 2 * r, C), dtype=g.dtype)
+    gq = g / cnt[None, :, :, None]
+    for dy in range(k):
+        for dx in range(k):
+            gp[:, dy:dy + H, dx:dx + W, :] += gq
+    return gp[:, r:r + H, r:r + W, :]
+
+
 # --------------------------------------------------------------------------- loss
 def softmax_ce(logits, labels, mask=None):
     """loss_def (isprs:1089-1099): mean over ALL pixels of sparse softmax-CE.
@@ -226,8 +254,11 @@ class OracleNet(object):
                 mean = var = None
             a = act_fwd(xh, self.spec["act"])
             dec = decisions[li] if decisions is not None else {}
+            ak = self.spec.get("pools", [0] * len(self.convs))[li]
             if self.spec["pool"]:
                 out, idx = max_pool_3x3(a, dec.get("idx"))
+            elif ak:
+                out, idx = avg_pool_same(a, ak)          # idx slot carries the divisor map
             else:
                 out, idx = a, None
             cache.append((inp, z, mean, var, xh, idx, dec.get("pos")))
@@ -263,7 +294,8 @@ class OracleNet(object):
                 grest = gcur[..., :gcur.shape[-1] - co]
             else:
                 gout = gcur
-            ga = max_pool_3x3_bwd(idx, gout) if self.spec["pool"] else gout
+            ak = self.spec.get("pools", [0] * len(self.convs))[li]
+            ga = max_pool_3x3_bwd(idx, gout) if self.spec["pool"] else (avg_pool_same_bwd(gout, ak, idx) if ak else gout)
             gxh = act_bwd(xh, self.spec["act"], ga, pos)
             gz = batch_norm_train_bwd(z, mean, var, gxh)
             gin, gw = conv2d_same_bwd(inp, self.p[name + "/weights"], r, gz)

@@ -71,8 +71,11 @@ class TorchNet(object):
             y = F.batch_norm(z, self.mm[name], self.mv[name], None, None, training=is_training,
                              momentum=1.0 - BN_DECAY, eps=BN_EPS)
             y = F.relu(y) if self.spec["act"] == "relu" else torch.maximum(0.1 * y, y)
+            ak = self.spec.get("pools", [0] * len(self.convs))[li]
             if self.spec["pool"]:
                 y = F.max_pool2d(y, 3, 1, 1)
+            elif ak:
+                y = F.avg_pool2d(y, ak, 1, ak // 2, count_include_pad=False)
             if dense:
                 concat = y if li == 0 else torch.cat([concat, y], dim=1)
                 cur = concat

@@ -16,7 +16,8 @@ CASES = [("dilated_icpr_original", 3, 6, 2, 25), ("dilated_grsl", 5, 6, 3, 19), 
          ("dilated_icpr_rate6_densely", 4, 2, 2, 21), ("dilated_grsl_rate8", 5, 6, 1, 45),
          # plain-chain variants beyond BASELINE's configs
          ("dilated_icpr_rate6", 3, 6, 2, 17), ("dilated_icpr_rate6_small", 4, 6, 2, 16),
-         ("dilated_icpr_rate6_nodilation", 3, 2, 2, 14), ("dilated_icpr_vary_rate", 3, 7, 1, 19)]
+         ("dilated_icpr_rate6_nodilation", 3, 2, 2, 14), ("dilated_icpr_vary_rate", 3, 7, 1, 19),
+         ("dilated_icpr_rate6_avgpool", 3, 6, 2, 13), ("dilated_icpr_rate6_avgpool", 3, 2, 1, 5)]
 
 
 def _mk(net, ch, K, B, S, seed):
@@ -46,7 +47,7 @@ def _decisions(d, B, S):
         mr = d.mean_rstd[i].cpu().numpy().reshape(L.cout, 2)
         xh = (z - mr[:, 0]) * mr[:, 1]                       # float32, the kernel's own expression
         dec = {"pos": xh > 0}
-        if d.plan.pool:
+        if d._is_max(i):
             dec["idx"] = d.idx[i][:M * L.cout].cpu().numpy().reshape(B, S, S, L.cout)
         out.append(dec)
     return out
