@@ -73,6 +73,14 @@ def save_checkpoint(net, output_path, step, patch_acc_loss=None, patch_occur=Non
 
 
 def load_checkpoint(net, former_model_path):
+    """`saver_restore.restore(sess, former_model_path)` (isprs:1715): a TensorFlow V2 checkpoint written by the reference
+    (`<path>.index` + `.data-*`, read by tf_checkpoint.py) or this build's own `<path>.npz`."""
+    import os
+    if os.path.isfile(former_model_path + ".index"):
+        from . import tf_checkpoint
+        tf_checkpoint.load_tf_checkpoint(net, former_model_path)
+        print(BatchColors.OKBLUE + "Model restored from " + former_model_path + " (TensorFlow bundle)" + BatchColors.ENDC)
+        return
     path = former_model_path if former_model_path.endswith(".npz") else former_model_path + ".npz"
     with np.load(path) as d:
         net.load_state_dict({k: d[k] for k in d.files})

@@ -264,3 +264,26 @@ def test_void_label_is_masked_out_of_loss_and_accuracy():
     out = d.train_step(2, 16, 0.01, use_loss_mask=True, global_pixels=int(want.sum()), apply_update=False)
     assert int(out["conf"].sum().item()) == int(want.sum())
     assert np.isfinite(d.loss_value(out["loss_parts"]))
+
+
+def test_tensorflow_bundle_checkpoint_roundtrip(tmp_path):
+    """A net saved in the reference's checkpoint format (tf.train.Saver V2 bundle) restores to identical logits."""
+    from drs_amd import loops, tf_checkpoint
+    from drs_amd.net import DilatedNet
+    rng = np.random.default_rng(1)
+    B, S = 2, 15
+    a = DilatedNet("dilated8_grsl", 5, 6, 0.005, b_max=B, s_max=S, device=DEV, seed=9)
+    x = rng.normal(size=(B, S * S * 5)).astype(np.float32)
+    y = rng.integers(0, 6, size=(B, S * S))
+    a.feed(x, y, S)
+    a.train_step(B, S, 0.01)                      # non-trivial momentum, moving statistics and step counter
+    prefix = str(tmp_path / "model-1")
+    tf_checkpoint.save_tf_checkpoint(a, prefix)
+    assert os.path.isfile(prefix + ".index") and os.path.isfile(prefix + ".data-00000-of-00001")
+    b = DilatedNet("dilated8_grsl", 5, 6, 0.005, b_max=B, s_max=S, device=DEV, seed=123)
+    loops.load_checkpoint(b, prefix)              # picks the bundle because <prefix>.index exists
+    assert b.global_step == 1
+    assert torch.equal(a.params, b.params) and torch.equal(a.mom, b.mom) and torch.equal(a.bn, b.bn)
+    a.feed(x, None, S)
+    b.feed(x, None, S)
+    assert torch.equal(a.forward(B, S)[1], b.forward(B, S)[1])
