@@ -164,21 +164,14 @@ class DilatedNet(object):
         u8 = dict(dtype=torch.uint8, device=self.dev)
         f64 = dict(dtype=torch.float64, device=self.dev)
         L0 = p.layers[0]
-        self.x0 = torch.zeros(B * (S + 2 * L0.halo) ** 2 * L0.cin_k, **f32)      # conv1 input slab (crop target)
-        self.xin = [None] * len(p.layers)
-        if p.dense:
-            Pc = p.concat_halo
-            self.concat = torch.zeros(B * (S + 2 * Pc) ** 2 * p.c_last, **f32)
-            self.gconcat = torch.zeros(M * p.c_last, **f32)
-        else:
-            for i, L in enumerate(p.layers):
-                if i > 0:
-                    self.xin[i] = torch.zeros(B * (S + 2 * L.halo) ** 2 * L.cin_k, **f32)
-            self.feat = torch.zeros(M * p.c_last, **f32)
+        # activation slabs (zero-haloed, see Plan.buffers) and, for every slab but the input, the gradient wrt it [M][C]
+        self.abuf = {n: torch.zeros(B * (S + 2 * P) ** 2 * C, **f32) for n, (C, P) in p.buffers.items()}
+        self.gbuf = {n: torch.zeros(M * C, **f32) for n, (C, P) in p.buffers.items() if n != "x0"}
+        self.x0 = self.abuf["x0"]                     # conv1 input slab (crop target)
         self.z = [torch.zeros(M * L.cout, **f32) for L in p.layers]
         self.idx = [torch.zeros(M * L.cout, **u8) if self._is_max(i) else None for i, L in enumerate(p.layers)]
         self.mean_rstd = [torch.zeros(L.cout * 2, **f32) for L in p.layers]
-        cmax = max(max(L.cout for L in p.layers), max(L.cin_k for L in p.layers[1:]))
+        cmax = max(L.cout for L in p.layers)
         hmax = max(L.halo for L in p.layers)
         self.sums = torch.zeros(cmax * 2, **f64)
         self.colsum_scratch = torch.zeros(_lib.query("drs_colsum_scratch_doubles", max(2 * cmax, p.c_last * p.K)), **f64)
@@ -191,8 +184,6 @@ class DilatedNet(object):
         if any(q is not None and q[0] == "avg" for q in p.pools):
             self.act = torch.zeros(M * cmax, **f32)        # activated, not yet averaged output of a layer
             self.gpool = torch.zeros(M * cmax, **f32)      # gradient wrt it
-        self.gA = torch.zeros(M * cmax, **f32)
-        self.gB = torch.zeros(M * cmax, **f32)
         self.gxh = torch.zeros(M * cmax, **f32)
         self.gz = torch.zeros(B * (S + 2 * hmax) ** 2 * cmax, **f32)
         slab = max(_lib.query("drs_conv_wgrad_splits", B, S, L.k, L.cin_k, L.cout) * L.k * L.k * L.cin_k * L.cout
@@ -234,35 +225,25 @@ class DilatedNet(object):
         return torch.cuda.current_stream(self.dev).cuda_stream
 
     def _in_view(self, i):
-        """(tensor, halo, ld, coff) of the input of conv i."""
-        p = self.plan
-        L = p.layers[i]
-        if i == 0:
-            return self.x0, L.halo, L.cin_k, 0
-        if p.dense:
-            return self.concat, p.concat_halo, p.c_last, 0
-        return self.xin[i], L.halo, L.cin_k, 0
+        """(tensor, halo, ld, coff) of the input of conv block i: channels [0, cin) of its source slab."""
+        L = self.plan.layers[i]
+        C, P = self.plan.buffers[L.src]
+        return self.abuf[L.src], P, C, 0
 
     def _out_view(self, i):
-        """where the activated (pooled) output of conv i goes."""
-        p = self.plan
-        if p.dense:
-            return self.concat, p.concat_halo, p.c_last, p.concat_off[i]
-        if i + 1 < len(p.layers):
-            n = p.layers[i + 1]
-            return self.xin[i + 1], n.halo, n.cin_k, 0
-        return self.feat, 0, p.c_last, 0
+        """where the activated (pooled) output of conv block i goes: a channel slice of its destination slab."""
+        L = self.plan.layers[i]
+        C, P = self.plan.buffers[L.dst]
+        return self.abuf[L.dst], P, C, L.dst_coff
 
     def _feat_view(self):
-        p = self.plan
-        if p.dense:
-            return self.concat, p.concat_halo, p.c_last, 0
-        return self.feat, 0, p.c_last, 0
+        C, P = self.plan.buffers[self.plan.feat]
+        return self.abuf[self.plan.feat], P, C, 0
 
     def input_slab(self):
         """(tensor, halo, ld) of the conv1 input slab that drs_crop_normalize fills."""
-        L = self.plan.layers[0]
-        return self.x0, L.halo, L.cin_k
+        C, P = self.plan.buffers["x0"]
+        return self.x0, P, C
 
     def _k(self, kind, work, name, *args):
         """enqueue one library call; with a KernelTimer attached, bracket it with HIP events."""
@@ -381,10 +362,7 @@ class DilatedNet(object):
         feat, Pf, ldf, cf = self._feat_view()
         woff, _ = p.offsets["conv_classifier/weights"]
         boff, _ = p.offsets["conv_classifier/biases"]
-        if p.dense:
-            gfeat, ldg, cg = self.gconcat, p.c_last, 0
-        else:
-            gfeat, ldg, cg = self.gA, p.c_last, 0
+        gfeat, ldg, cg = self.gbuf[p.feat], p.buffers[p.feat][0], 0
         self.conf.zero_()
         self._k("classifier_loss", M * p.c_last * 8.0, "drs_classifier_loss", _ptr(feat), B, S, Pf, ldf, cf, p.c_last, p.K,
                 self.params[woff:].data_ptr(), self.params[boff:].data_ptr(), _ptr(self.labels), _ptr(self.loss_mask) if use_loss_mask else None,
@@ -406,13 +384,12 @@ class DilatedNet(object):
         bucket_hi = woff                       # kernels [bucket_lo, bucket_hi) of the flat buffer are still to be sent
         if self.comm.world > 1:
             pending.append(self.comm.all_reduce_sum_async(self.grads[woff:]))
-        # reverse loop over the conv blocks
-        gcur, ldc, cc = gfeat, ldg, cg
-        gnext = self.gB
+        # reverse loop over the conv blocks.  The gradient wrt a slab is first SET (by the classifier, or by the first block
+        # that propagates into it) and then ACCUMULATED into by every further reader of that slab (dense / squeeze nets)
+        written = {p.feat}
         for i in reversed(range(nL)):
             L = p.layers[i]
-            if p.dense:
-                gcur, ldc, cc = self.gconcat, p.c_last, p.concat_off[i]
+            gcur, ldc, cc = self.gbuf[L.dst], p.buffers[L.dst][0], L.dst_coff
             mx, ak = self._is_max(i), self._avg_k(i)
             if ak:
                 self._k("avg_pool_bwd", M * L.cout * 8.0, "drs_avg_pool_backward", _ptr(gcur), ldc, cc, B, S, L.cout, ak,
@@ -439,16 +416,12 @@ class DilatedNet(object):
             if self.comm.world > 1 and i > 0 and (nL - i) % 2 == 0:                   # every second layer: one bucket
                 pending.append(self.comm.all_reduce_sum_async(self.grads[goff:bucket_hi]))
                 bucket_hi = goff
-            if i > 0:
-                if p.dense:
-                    out, ldo, co, acc = self.gconcat, p.c_last, 0, 1
-                else:
-                    out, ldo, co, acc = gnext, L.cin, 0, 0
+            if L.src != "x0":
+                acc = 1 if L.src in written else 0
+                written.add(L.src)
                 self._k("conv_dgrad", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_forward", _ptr(self.gz), B, S, L.halo, L.cout,
-                        0, _ptr(self.wt[i]), None, L.k, L.rate, L.pad_a, L.cout, L.cin, _ptr(out), ldo, co, acc, None, st)
-                if not p.dense:
-                    gcur, ldc, cc = gnext, L.cin, 0
-                    gnext = self.gA if gnext is self.gB else self.gB
+                        0, _ptr(self.wt[i]), None, L.k, L.rate, L.pad_a, L.cout, L.cin, _ptr(self.gbuf[L.src]), p.buffers[L.src][0], 0,
+                        acc, None, st)
         if self.comm.world > 1:
             pending.append(self.comm.all_reduce_sum_async(self.grads[0:bucket_hi]))      # the remaining (earliest) layers
             self.comm.all_reduce_sum(self.scalars[:1])

@@ -38,6 +38,12 @@ _TABLES = {
     "dilated_icpr_rate6_avgpool": ("relu", [("avg", 5), ("avg", 5), ("avg", 5), ("avg", 7), ("avg", 7), None], False, 256, [
         ("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2), ("conv3", 4, 64, 128, 3),
         ("conv4", 4, 128, 128, 4), ("conv5", 3, 128, 256, 5), ("conv6", 3, 256, 256, 6)]),
+    # squeeze variant (isprs:1064-1086 with _squeeze_conv_layer :726-742): conv1, then per layer a 1x1 squeeze to k_dim and
+    # two parallel expands (1x1 and k x k dilated, out_dim/2 channels each) whose outputs are concatenated.
+    # entries: (scope, k, in_dim, out_dim, rate, k_dim)
+    "dilated_icpr_rate6_squeeze": ("relu", False, "squeeze", 256, [
+        ("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2, 32), ("conv3", 4, 64, 128, 3, 64),
+        ("conv4", 4, 128, 128, 4, 64), ("conv5", 3, 128, 256, 5, 64), ("conv6", 3, 256, 256, 6, 128)]),
     "dilated_icpr_rate6_densely": ("relu", False, True, 448, [
         ("conv1", 5, -1, 32, 1), ("conv2", 5, 32, 32, 2), ("conv3", 4, 64, 64, 3),
         ("conv4", 4, 128, 64, 4), ("conv5", 3, 192, 128, 5), ("conv6", 3, 320, 128, 6)]),
@@ -45,7 +51,9 @@ _TABLES = {
 # isprs:1672 spells Dilated8Pooling 'dilated8_grsl'; coffee:1203, contest:1004 and README:33 'dilated_grsl_rate8'
 _ALIASES = {"dilated8_grsl": "dilated_grsl_rate8"}
 
-Layer = namedtuple("Layer", "name k cin cin_k cout rate pad_b pad_a halo")
+# one conv block (conv + bias + BN + activation [+ pool]); it reads channels [0, cin) of activation buffer `src` and writes its
+# output into channels [dst_coff, dst_coff + cout) of buffer `dst`
+Layer = namedtuple("Layer", "name k cin cin_k cout rate pad_b pad_a halo src dst dst_coff")
 
 
 def known_net_types():
@@ -75,18 +83,50 @@ class Plan(object):
 
     def __init__(self, net_type, channels, num_classes):
         self.net_type = resolve(net_type)
-        act, pool, self.dense, self.c_last, convs = _TABLES[self.net_type]
-        # per-layer pooling after the activation: None | ("max", 3) | ("avg", k)
-        self.pools = list(pool) if isinstance(pool, list) else [("max", 3) if pool else None] * len(convs)
-        self.pool = any(q is not None and q[0] == "max" for q in self.pools)
+        act, pool, topo, self.c_last, convs = _TABLES[self.net_type]
+        self.dense = topo is True
         self.alpha = 0.0 if act == "relu" else 0.1      # max(alpha*x, x): ReLU / leaky ReLU (isprs:620-621)
         self.channels = channels
         self.K = num_classes
+        # ---- wiring: blocks in execution order + the activation buffers they read / write (name -> [channels, halo]).
+        # A chain gives every block its own output slab; the dense net (isprs:921-948) and the squeeze net (isprs:737-742)
+        # concatenate by writing channel slices of a shared slab, so no concat copy exists.
+        blocks = []        # (name, k, cin, cout, rate, src, dst, dst_coff)
+        chan = {"x0": round_up(channels, 32)}
+        if topo == "squeeze":
+            name, k, _, co, r = convs[0]
+            blocks.append((name, k, channels, co, r, "x0", "c1", 0))
+            chan["c1"] = co
+            for j, (name, k, ind, outd, r, kd) in enumerate(convs[1:], start=2):
+                a, c, prev = "a%d" % j, "c%d" % j, "c%d" % (j - 1)
+                chan[a], chan[c] = kd, outd
+                blocks.append((name + "_s1", 1, ind, kd, r, prev, a, 0))
+                blocks.append((name + "_s2_1", 1, kd, outd // 2, r, a, c, 0))
+                blocks.append((name + "_s2_2", k, kd, outd // 2, r, a, c, outd // 2))
+            self.feat = "c%d" % len(convs)
+        elif self.dense:
+            off = 0
+            chan["concat"] = self.c_last
+            for i, (name, k, ci, co, r) in enumerate(convs):
+                blocks.append((name, k, channels if ci < 0 else ci, co, r, "x0" if i == 0 else "concat", "concat", off))
+                off += co
+            self.feat = "concat"
+        else:
+            for i, (name, k, ci, co, r) in enumerate(convs):
+                dst = "x%d" % (i + 1) if i + 1 < len(convs) else "feat"
+                blocks.append((name, k, channels if ci < 0 else ci, co, r, "x%d" % i, dst, 0))
+                chan[dst] = co
+            self.feat = "feat"
+        # per-block pooling after the activation: None | ("max", 3) | ("avg", k)
+        self.pools = list(pool) if isinstance(pool, list) else [("max", 3) if pool else None] * len(blocks)
+        self.pool = any(q is not None and q[0] == "max" for q in self.pools)
         self.layers = []
-        for (name, k, ci, co, r) in convs:
-            ci = channels if ci < 0 else ci
+        halo = {n: 0 for n in chan}
+        for (name, k, ci, co, r, src, dst, coff) in blocks:
             pb, pa = same_pad(k, r)
-            self.layers.append(Layer(name, k, ci, round_up(ci, 32), co, r, pb, pa, max(pb, pa)))
+            halo[src] = max(halo[src], pb, pa)          # a slab's halo must cover every conv that reads it
+            self.layers.append(Layer(name, k, ci, round_up(ci, 32), co, r, pb, pa, max(pb, pa), src, dst, coff))
+        self.buffers = {n: (chan[n], halo[n]) for n in chan}
         # flat parameter layout: every kernel (HWIO), then every bias; the classifier last in both groups
         self.offsets = {}
         off = 0
@@ -102,21 +142,16 @@ class Plan(object):
         self.offsets["conv_classifier/biases"] = (off, (num_classes,))
         off += num_classes
         self.n_params = off
-        # batch-norm moving statistics: per layer mean[C] then variance[C]
+        # batch-norm moving statistics: per block mean[C] then variance[C]
         self.bn_offsets = {}
         off = 0
         for L in self.layers:
             self.bn_offsets[L.name] = off
             off += 2 * L.cout
         self.n_bn = off
-        # dense net: channel offset of each layer's output inside the concat slab (isprs:921-948)
-        self.concat_off = []
-        if self.dense:
-            o = 0
-            for L in self.layers:
-                self.concat_off.append(o)
-                o += L.cout
-            self.concat_halo = max(L.halo for L in self.layers[1:])
+        if self.dense:      # kept for callers that want the slice table (isprs:921-948)
+            self.concat_off = [L.dst_coff for L in self.layers]
+            self.concat_halo = self.buffers["concat"][1]
 
     def mac_per_pixel(self):
         return sum(L.k * L.k * L.cin * L.cout for L in self.layers) + self.c_last * self.K
