@@ -55,6 +55,11 @@ NETS = {
         act="relu", pool=False, dense=False, pools=[5, 5, 5, 7, 7, 0],
         convs=[("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2), ("conv3", 4, 64, 128, 3),
                ("conv4", 4, 128, 128, 4), ("conv5", 3, 128, 256, 5), ("conv6", 3, 256, 256, 6)], c_last=256),
+    # isprs:1064-1086 with _squeeze_conv_layer :726-742.  squeezes: (scope, k, in_dim, out_dim, rate, k_dim)
+    "dilated_icpr_rate6_squeeze": dict(
+        act="relu", pool=False, dense=False, convs=[("conv1", 5, -1, 64, 1)],
+        squeezes=[("conv2", 5, 64, 64, 2, 32), ("conv3", 4, 64, 128, 3, 64), ("conv4", 4, 128, 128, 4, 64),
+                  ("conv5", 3, 128, 256, 5, 64), ("conv6", 3, 256, 256, 6, 128)], c_last=256),
     "dilated_icpr_rate6_densely": dict(
         act="relu", pool=False, dense=True,
         convs=[("conv1", 5, -1, 32, 1), ("conv2", 5, 32, 32, 2),
@@ -71,8 +76,13 @@ def resolve(net_type):
 
 
 def conv_specs(net_type, channels):
+    """every conv block (scope, k, c_in, c_out, rate) in execution order; a squeeze layer contributes three
+    (`_s1` 1x1 squeeze, `_s2_1` 1x1 expand, `_s2_2` k x k expand: isprs:729-735)."""
     spec = NETS[resolve(net_type)]
-    return [(n, k, channels if ci < 0 else ci, co, r) for (n, k, ci, co, r) in spec["convs"]]
+    out = [(n, k, channels if ci < 0 else ci, co, r) for (n, k, ci, co, r) in spec["convs"]]
+    for (n, k, ind, outd, r, kd) in spec.get("squeezes", []):
+        out += [(n + "_s1", 1, ind, kd, r), (n + "_s2_1", 1, kd, outd // 2, r), (n + "_s2_2", k, kd, outd // 2, r)]
+    return out
 
 
 def same_pad(k, rate):

@@ -232,44 +232,66 @@ class OracleNet(object):
     def trainable(name):
         return name.endswith("/weights") or name.endswith("/biases")
 
-    # ---- forward; keeps what backward needs in self.cache when is_training
-    def forward(self, x, is_training, decisions=None):
+    # ---- one conv block (isprs:700-723): conv -> +bias -> BN -> activation [-> pool]
+    def _block_fwd(self, li, inp, is_training, decisions):
         dt = self.dtype.type
+        name, k, ci, co, r = self.convs[li]
+        z = conv2d_same(inp, self.p[name + "/weights"], r) + self.p[name + "/biases"]
+        if is_training:
+            xh, mean, var = batch_norm_train(z)
+            n = z.shape[0] * z.shape[1] * z.shape[2]
+            self.p[name + "/moving_mean"] = moving_update(self.p[name + "/moving_mean"], mean)
+            mv_in = var * dt(n / (n - 1.0)) if self.bessel else var
+            self.p[name + "/moving_variance"] = moving_update(self.p[name + "/moving_variance"], mv_in)
+        else:
+            xh = batch_norm_eval(z, self.p[name + "/moving_mean"], self.p[name + "/moving_variance"])
+            mean = var = None
+        a = act_fwd(xh, self.spec["act"])
+        dec = decisions[li] if decisions is not None else {}
+        ak = self.spec.get("pools", [0] * len(self.convs))[li]
+        if self.spec["pool"]:
+            out, idx = max_pool_3x3(a, dec.get("idx"))
+        elif ak:
+            out, idx = avg_pool_same(a, ak)          # idx slot carries the divisor map
+        else:
+            out, idx = a, None
+        self._cache[li] = (inp, z, mean, var, xh, idx, dec.get("pos"))
+        return out
+
+    def _block_bwd(self, li, gout, g):
+        name, k, ci, co, r = self.convs[li]
+        inp, z, mean, var, xh, idx, pos = self._cache[li]
+        ak = self.spec.get("pools", [0] * len(self.convs))[li]
+        ga = max_pool_3x3_bwd(idx, gout) if self.spec["pool"] else (avg_pool_same_bwd(gout, ak, idx) if ak else gout)
+        gxh = act_bwd(xh, self.spec["act"], ga, pos)
+        gz = batch_norm_train_bwd(z, mean, var, gxh)
+        gin, gw = conv2d_same_bwd(inp, self.p[name + "/weights"], r, gz)
+        g[name + "/weights"] = gw
+        g[name + "/biases"] = gz.sum(axis=(0, 1, 2))
+        return gin
+
+    # ---- forward; keeps what backward needs in self._cache
+    def forward(self, x, is_training, decisions=None):
         x = x.astype(self.dtype)
-        cache = []
-        cur = x
-        dense = self.spec["dense"]
-        concat = None
-        for li, (name, k, ci, co, r) in enumerate(self.convs):
-            inp = cur if not dense or li == 0 else concat
-            z = conv2d_same(inp, self.p[name + "/weights"], r) + self.p[name + "/biases"]
-            if is_training:
-                xh, mean, var = batch_norm_train(z)
-                n = z.shape[0] * z.shape[1] * z.shape[2]
-                self.p[name + "/moving_mean"] = moving_update(self.p[name + "/moving_mean"], mean)
-                mv_in = var * dt(n / (n - 1.0)) if self.bessel else var
-                self.p[name + "/moving_variance"] = moving_update(self.p[name + "/moving_variance"], mv_in)
-            else:
-                xh = batch_norm_eval(z, self.p[name + "/moving_mean"], self.p[name + "/moving_variance"])
-                mean = var = None
-            a = act_fwd(xh, self.spec["act"])
-            dec = decisions[li] if decisions is not None else {}
-            ak = self.spec.get("pools", [0] * len(self.convs))[li]
-            if self.spec["pool"]:
-                out, idx = max_pool_3x3(a, dec.get("idx"))
-            elif ak:
-                out, idx = avg_pool_same(a, ak)          # idx slot carries the divisor map
-            else:
-                out, idx = a, None
-            cache.append((inp, z, mean, var, xh, idx, dec.get("pos")))
-            if dense:
-                concat = out if li == 0 else np.concatenate([concat, out], axis=3)   # isprs:921-948
-                cur = concat
-            else:
-                cur = out
+        self._cache = {}
+        n = len(self.convs)
+        if self.spec.get("squeezes"):                       # isprs:1064-1086
+            cur = self._block_fwd(0, x, is_training, decisions)
+            for li in range(1, n, 3):
+                s1 = self._block_fwd(li, cur, is_training, decisions)
+                cur = np.concatenate([self._block_fwd(li + 1, s1, is_training, decisions),
+                                      self._block_fwd(li + 2, s1, is_training, decisions)], axis=3)      # isprs:737-740
+        elif self.spec["dense"]:                            # isprs:921-948
+            cur = self._block_fwd(0, x, is_training, decisions)
+            for li in range(1, n):
+                cur = np.concatenate([cur, self._block_fwd(li, cur, is_training, decisions)], axis=3)
+        else:
+            cur = x
+            for li in range(n):
+                cur = self._block_fwd(li, cur, is_training, decisions)
         feat = cur
         logits = feat @ self.p["conv_classifier/weights"][0, 0] + self.p["conv_classifier/biases"]
-        self.cache = (cache, feat)
+        self.cache = (self._cache, feat)
         return logits
 
     def loss_and_grads(self, x, y, weight_decay, mask=None, decisions=None):
@@ -279,35 +301,30 @@ class OracleNet(object):
         ce, gl = softmax_ce(logits, y, mask)
         l2 = sum(0.5 * (self.p[n] ** 2).sum() for n in self.p if n.endswith("/weights"))   # tf.nn.l2_loss
         loss = ce + weight_decay * l2
-        cache, feat = self.cache
+        feat = self.cache[1]
         g = {}
         C = feat.shape[-1]
         g["conv_classifier/weights"] = (feat.reshape(-1, C).T @ gl.reshape(-1, self.K)).reshape(1, 1, C, self.K)
         g["conv_classifier/biases"] = gl.reshape(-1, self.K).sum(axis=0)
         gcur = gl @ self.p["conv_classifier/weights"][0, 0].T
-        dense = self.spec["dense"]
-        for li in reversed(range(len(self.convs))):
-            name, k, ci, co, r = self.convs[li]
-            inp, z, mean, var, xh, idx, pos = cache[li]
-            if dense:
-                gout = gcur[..., gcur.shape[-1] - co:]
-                grest = gcur[..., :gcur.shape[-1] - co]
-            else:
-                gout = gcur
-            ak = self.spec.get("pools", [0] * len(self.convs))[li]
-            ga = max_pool_3x3_bwd(idx, gout) if self.spec["pool"] else (avg_pool_same_bwd(gout, ak, idx) if ak else gout)
-            gxh = act_bwd(xh, self.spec["act"], ga, pos)
-            gz = batch_norm_train_bwd(z, mean, var, gxh)
-            gin, gw = conv2d_same_bwd(inp, self.p[name + "/weights"], r, gz)
-            g[name + "/weights"] = gw
-            g[name + "/biases"] = gz.sum(axis=(0, 1, 2))
-            if dense:
-                gcur = (grest + gin) if li > 0 else None
-            else:
-                gcur = gin
-        for n in g:
-            if n.endswith("/weights"):
-                g[n] = g[n] + dt(weight_decay) * self.p[n]
+        n = len(self.convs)
+        if self.spec.get("squeezes"):
+            for li in reversed(range(1, n, 3)):
+                c1 = self.convs[li + 1][3]
+                gs1 = self._block_bwd(li + 2, gcur[..., c1:], g) + self._block_bwd(li + 1, gcur[..., :c1], g)
+                gcur = self._block_bwd(li, gs1, g)
+            self._block_bwd(0, gcur, g)
+        elif self.spec["dense"]:
+            for li in reversed(range(1, n)):
+                co = self.convs[li][3]
+                gcur = gcur[..., :gcur.shape[-1] - co] + self._block_bwd(li, gcur[..., gcur.shape[-1] - co:], g)
+            self._block_bwd(0, gcur, g)
+        else:
+            for li in reversed(range(n)):
+                gcur = self._block_bwd(li, gcur, g)
+        for nm in g:
+            if nm.endswith("/weights"):
+                g[nm] = g[nm] + dt(weight_decay) * self.p[nm]
         pred = logits.argmax(axis=3)
         return loss, pred, g, logits
 

@@ -58,29 +58,37 @@ class TorchNet(object):
             out[n + "/moving_variance"] = self.mv[n].numpy().copy()
         return out
 
+    def _block(self, li, inp, is_training):
+        name, k, ci, co, r = self.convs[li]
+        pb, pa = _nets.same_pad(k, r)
+        z = F.conv2d(F.pad(inp, (pb, pa, pb, pa)), self.w[name], self.b[name], dilation=r)
+        # torch's running_var update uses the unbiased batch variance, as TF's fused kernel does
+        y = F.batch_norm(z, self.mm[name], self.mv[name], None, None, training=is_training,
+                         momentum=1.0 - BN_DECAY, eps=BN_EPS)
+        y = F.relu(y) if self.spec["act"] == "relu" else torch.maximum(0.1 * y, y)
+        ak = self.spec.get("pools", [0] * len(self.convs))[li]
+        if self.spec["pool"]:
+            y = F.max_pool2d(y, 3, 1, 1)
+        elif ak:
+            y = F.avg_pool2d(y, ak, 1, ak // 2, count_include_pad=False)
+        return y
+
     def forward(self, x_nhwc, is_training):
         x = torch.as_tensor(x_nhwc, dtype=self.dtype).permute(0, 3, 1, 2)
-        dense = self.spec["dense"]
-        cur = x
-        concat = None
-        for li, (name, k, ci, co, r) in enumerate(self.convs):
-            inp = cur if not dense or li == 0 else concat
-            pb, pa = _nets.same_pad(k, r)
-            z = F.conv2d(F.pad(inp, (pb, pa, pb, pa)), self.w[name], self.b[name], dilation=r)
-            # torch's running_var update uses the unbiased batch variance, as TF's fused kernel does
-            y = F.batch_norm(z, self.mm[name], self.mv[name], None, None, training=is_training,
-                             momentum=1.0 - BN_DECAY, eps=BN_EPS)
-            y = F.relu(y) if self.spec["act"] == "relu" else torch.maximum(0.1 * y, y)
-            ak = self.spec.get("pools", [0] * len(self.convs))[li]
-            if self.spec["pool"]:
-                y = F.max_pool2d(y, 3, 1, 1)
-            elif ak:
-                y = F.avg_pool2d(y, ak, 1, ak // 2, count_include_pad=False)
-            if dense:
-                concat = y if li == 0 else torch.cat([concat, y], dim=1)
-                cur = concat
-            else:
-                cur = y
+        n = len(self.convs)
+        if self.spec.get("squeezes"):
+            cur = self._block(0, x, is_training)
+            for li in range(1, n, 3):
+                s1 = self._block(li, cur, is_training)
+                cur = torch.cat([self._block(li + 1, s1, is_training), self._block(li + 2, s1, is_training)], dim=1)
+        elif self.spec["dense"]:
+            cur = self._block(0, x, is_training)
+            for li in range(1, n):
+                cur = torch.cat([cur, self._block(li, cur, is_training)], dim=1)
+        else:
+            cur = x
+            for li in range(n):
+                cur = self._block(li, cur, is_training)
         logits = F.conv2d(cur, self.w["conv_classifier"], self.b["conv_classifier"])
         return logits.permute(0, 2, 3, 1)
 

@@ -17,7 +17,8 @@ CASES = [("dilated_icpr_original", 3, 6, 2, 25), ("dilated_grsl", 5, 6, 3, 19), 
          # plain-chain variants beyond BASELINE's configs
          ("dilated_icpr_rate6", 3, 6, 2, 17), ("dilated_icpr_rate6_small", 4, 6, 2, 16),
          ("dilated_icpr_rate6_nodilation", 3, 2, 2, 14), ("dilated_icpr_vary_rate", 3, 7, 1, 19),
-         ("dilated_icpr_rate6_avgpool", 3, 6, 2, 13), ("dilated_icpr_rate6_avgpool", 3, 2, 1, 5)]
+         ("dilated_icpr_rate6_avgpool", 3, 6, 2, 13), ("dilated_icpr_rate6_avgpool", 3, 2, 1, 5),
+         ("dilated_icpr_rate6_squeeze", 3, 6, 2, 15), ("dilated_icpr_rate6_squeeze", 5, 6, 1, 22)]
 
 
 def _mk(net, ch, K, B, S, seed):
