@@ -27,6 +27,8 @@ SIGNATURES = {
     "drs_bn_backward_apply": (_i, [_p, _p, _i, _i, _i, _p, _p, _d, _p, _i, _i, _i, _p]),
     "drs_avg_pool_forward": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _p]),
     "drs_avg_pool_backward": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "drs_se_forward": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "drs_se_backward": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "drs_classifier_rows": (_i, [_i, _i]),
     "drs_classifier_loss": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p, _i, _i, _p, _p, _p,
                                  _p, _p]),

@@ -420,6 +420,121 @@ __global__ void avg_pool_kernel(const float* __restrict__ in, int ld_in, int cof
   *reinterpret_cast<f32x4*>(out.base + ((size_t)(b * Sp + y + out.P) * Sp + x + out.P) * out.ld + out.coff + cq * 4) = acc;
 }
 
+// ------------------------------------------------------------------------------------------------ squeeze-and-excitation
+// _squeeze_excitation_layer (isprs:682-697) of the `_SE` variant: s = mean_hw(x); e1 = relu(s W1 + b1); e2 = sigmoid(e1 W2 + b2);
+// y = x * e2 (per image and channel).  The spatial reductions run in a fixed order (4 pixel lanes per channel, then lanes in
+// order); the two tiny fully connected layers run one workgroup per image.
+// out2 == nullptr: s[b][c] = scale * sum_p a[p][c];   else: s[b][c] = scale * sum_p a[p][c] * out2... (see callers)
+template <bool DOT>
+__global__ void se_spatial_reduce_kernel(const float* __restrict__ a, int ld_a, int coff_a, const float* __restrict__ b2, int S, int C,
+                                         float scale, float* __restrict__ out) {
+  __shared__ float sh[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const int b = blockIdx.y;
+  const int npix = S * S;
+  float acc = 0.f;
+  if (c < C)
+    for (int p = ty; p < npix; p += 4) {
+      const size_t q = (size_t)b * npix + p;
+      const float v = a[q * ld_a + coff_a + c];
+      acc += DOT ? v * b2[q * C + c] : v;
+    }
+  sh[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && c < C) out[(size_t)b * C + c] = (((sh[0][tx] + sh[1][tx]) + sh[2][tx]) + sh[3][tx]) * scale;
+}
+
+__global__ void se_excite_kernel(const float* __restrict__ s, const float* __restrict__ w1, const float* __restrict__ b1,
+                                 const float* __restrict__ w2, const float* __restrict__ b2, int C, int R, float* __restrict__ e1,
+                                 float* __restrict__ e2) {
+  extern __shared__ float sm[];           // s[C] then e1[R]
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) sm[c] = s[(size_t)b * C + c];
+  __syncthreads();
+  for (int j = threadIdx.x; j < R; j += blockDim.x) {
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a += sm[c] * w1[(size_t)c * R + j];
+    a = fmaxf(a + b1[j], 0.f);
+    sm[C + j] = a;
+    e1[(size_t)b * R + j] = a;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float a = 0.f;
+    for (int j = 0; j < R; ++j) a += sm[C + j] * w2[(size_t)j * C + c];
+    e2[(size_t)b * C + c] = 1.0f / (1.0f + expf(-(a + b2[c])));
+  }
+}
+
+// y = x * e2 into the interior of a view (FWD), or gx = gy * e2 + gs (BWD, plain [M][C] output)
+template <bool BWD>
+__global__ void se_scale_kernel(const float* __restrict__ x, int ld_x, int coff_x, const float* __restrict__ e2,
+                                const float* __restrict__ gs, int B, int S, int C, ActView out) {
+  const int CQ = C >> 2;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= S * CQ) return;
+  const int xx = e / CQ, cq = e - xx * CQ;
+  const int b = blockIdx.y / S, y = blockIdx.y - b * S;
+  const size_t p = ((size_t)b * S + y) * S + xx;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(x + p * ld_x + coff_x + cq * 4);
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(e2 + (size_t)b * C + cq * 4);
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = v[j] * sc[j];
+  if (BWD) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gs + (size_t)b * C + cq * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] += g[j];
+  }
+  const int Sp = S + 2 * out.P;
+  *reinterpret_cast<f32x4*>(out.base + ((size_t)(b * Sp + y + out.P) * Sp + xx + out.P) * out.ld + out.coff + cq * 4) = o;
+}
+
+// per image: back through sigmoid, FC2, ReLU, FC1; gs already carries the 1/(S*S) of the spatial mean
+__global__ void se_excite_bwd_kernel(const float* __restrict__ ge2, const float* __restrict__ e1, const float* __restrict__ e2,
+                                     const float* __restrict__ w1, const float* __restrict__ w2, int C, int R, float inv_hw,
+                                     float* __restrict__ gpre2, float* __restrict__ gpre1, float* __restrict__ gs) {
+  extern __shared__ float sm[];           // gpre2[C] then gpre1[R]
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float ev = e2[(size_t)b * C + c];
+    const float g = ge2[(size_t)b * C + c] * ev * (1.0f - ev);
+    sm[c] = g;
+    gpre2[(size_t)b * C + c] = g;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < R; j += blockDim.x) {
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a += sm[c] * w2[(size_t)j * C + c];
+    a = e1[(size_t)b * R + j] > 0.f ? a : 0.f;
+    sm[C + j] = a;
+    gpre1[(size_t)b * R + j] = a;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float a = 0.f;
+    for (int j = 0; j < R; ++j) a += sm[C + j] * w1[(size_t)c * R + j];
+    gs[(size_t)b * C + c] = a * inv_hw;
+  }
+}
+
+// dW[i][j] = sum_b u[b][i] * v[b][j] (fixed order over b); i == rows -> the bias row: sum_b v[b][j]
+__global__ void se_fc_wgrad_kernel(const float* __restrict__ u, const float* __restrict__ v, int B, int rows, int cols,
+                                   float* __restrict__ dw, float* __restrict__ db) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (rows + 1) * cols) return;
+  const int i = e / cols, j = e - i * cols;
+  float a = 0.f;
+  if (i < rows) {
+    for (int b = 0; b < B; ++b) a += u[(size_t)b * rows + i] * v[(size_t)b * cols + j];
+    dw[e] = a;
+  } else {
+    for (int b = 0; b < B; ++b) a += v[(size_t)b * cols + j];
+    db[j] = a;
+  }
+}
+
 // pass B: g_z = rstd * (g_xhat - mean(g_xhat) - xhat * mean(g_xhat * xhat)), written into a zero-haloed view
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ gxh, const float* __restrict__ z, int B, int S, int C,
                                     const float* __restrict__ mean_rstd, const double* __restrict__ sums, double count,
@@ -837,6 +952,44 @@ int drs_avg_pool_backward(const float* gout, int ld_g, int coff_g, int B, int S,
   if (!gout || !gin || C % 4 || k < 1 || !(k & 1) || (long long)B * S > 65535) return DRS_ERR_ARG;
   DRS_LAUNCH(avg_pool_kernel<true>, dim3((S * (C / 4) + 255) / 256, B * S), dim3(256), 0, (hipStream_t)stream, gout, ld_g, coff_g, B, S, C,
              k, mkview(gin, S, 0, C, 0));
+  return DRS_LAUNCH_CHECK();
+}
+
+// state: s [B][C], e1 [B][R], e2 [B][C] (kept for the backward pass)
+int drs_se_forward(const float* act, int B, int S, int C, int R, const float* w1, const float* b1, const float* w2, const float* b2,
+                   float* s, float* e1, float* e2, float* out, int P_out, int ld_out, int coff_out, void* stream) {
+  if (!act || !w1 || !b1 || !w2 || !b2 || !s || !e1 || !e2 || !out || C % 4 || R < 1 || (long long)B * (S + 2 * P_out) > 65535)
+    return DRS_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  DRS_LAUNCH(se_spatial_reduce_kernel<false>, dim3((C + 63) / 64, B), dim3(256), 0, st, act, C, 0, nullptr, S, C, 1.0f / (float)(S * S), s);
+  DRS_LAUNCH(se_excite_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), st, s, w1, b1, w2, b2, C, R, e1, e2);
+  ActView v = mkview(out, S, P_out, ld_out, coff_out);
+  if (P_out > 0) {
+    const int Sp = S + 2 * P_out;
+    DRS_LAUNCH(zero_halo_kernel, dim3((Sp * (C / 4) + 255) / 256, B * Sp), dim3(256), 0, st, v, B, C);
+  }
+  DRS_LAUNCH(se_scale_kernel<false>, dim3((S * (C / 4) + 255) / 256, B * S), dim3(256), 0, st, act, C, 0, e2, nullptr, B, S, C, v);
+  return DRS_LAUNCH_CHECK();
+}
+
+// gy [B*S*S][ld_g]+coff_g -> gact [B*S*S][C]; dw1 [C][R], db1 [R], dw2 [R][C], db2 [C]; scratch: B*(3*C + R) floats
+int drs_se_backward(const float* gy, int ld_g, int coff_g, const float* act, const float* s, const float* e1, const float* e2,
+                    const float* w1, const float* w2, int B, int S, int C, int R, float* gact, float* dw1, float* db1, float* dw2,
+                    float* db2, float* scratch, void* stream) {
+  if (!gy || !act || !s || !e1 || !e2 || !w1 || !w2 || !gact || !dw1 || !db1 || !dw2 || !db2 || !scratch || C % 4 || (long long)B * S > 65535)
+    return DRS_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  float* ge2 = scratch;                       // [B][C]
+  float* gpre2 = ge2 + (size_t)B * C;         // [B][C]
+  float* gs = gpre2 + (size_t)B * C;          // [B][C]
+  float* gpre1 = gs + (size_t)B * C;          // [B][R]
+  DRS_LAUNCH(se_spatial_reduce_kernel<true>, dim3((C + 63) / 64, B), dim3(256), 0, st, gy, ld_g, coff_g, act, S, C, 1.0f, ge2);
+  DRS_LAUNCH(se_excite_bwd_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), st, ge2, e1, e2, w1, w2, C, R, 1.0f / (float)(S * S), gpre2,
+             gpre1, gs);
+  DRS_LAUNCH(se_fc_wgrad_kernel, dim3(((R + 1) * C + 255) / 256), dim3(256), 0, st, e1, gpre2, B, R, C, dw2, db2);
+  DRS_LAUNCH(se_fc_wgrad_kernel, dim3(((C + 1) * R + 255) / 256), dim3(256), 0, st, s, gpre1, B, C, R, dw1, db1);
+  DRS_LAUNCH(se_scale_kernel<true>, dim3((S * (C / 4) + 255) / 256, B * S), dim3(256), 0, st, gy, ld_g, coff_g, e2, gs, B, S, C,
+             mkview(gact, S, 0, C, 0));
   return DRS_LAUNCH_CHECK();
 }
 

@@ -101,7 +101,13 @@ class DilatedNet(object):
         host = np.zeros(self.plan.n_params, dtype=np.float32)
         for name, (off, shape) in self.plan.offsets.items():
             n = int(np.prod(shape))
-            if name.endswith("/weights"):
+            if name.endswith("/weights") and len(shape) == 2:         # _fc_layer: truncated normal, stddev 0.005 (isprs:669)
+                v = rng.normal(0.0, 0.005, size=n)
+                while np.any(np.abs(v) > 0.01):
+                    bad = np.abs(v) > 0.01
+                    v[bad] = rng.normal(0.0, 0.005, size=int(bad.sum()))
+                host[off:off + n] = v.astype(np.float32)
+            elif name.endswith("/weights"):
                 k1, k2, ci, co = shape
                 lim = math.sqrt(6.0 / (k1 * k2 * ci + k1 * k2 * co))
                 host[off:off + n] = rng.uniform(-lim, lim, size=n).astype(np.float32)
@@ -181,7 +187,14 @@ class DilatedNet(object):
         part = max(max(_lib.query("drs_bn_backward_rows", B, s, L.cout, 1 if self._is_max(i) else 0) * L.cout * 2
                        for i, L in enumerate(p.layers)) for s in range(1, S + 1))
         self.partial = torch.zeros(max(rows_fwd * cmax * 2, part), **f32)
-        if any(q is not None and q[0] == "avg" for q in p.pools):
+        if p.se:        # per SE block: the activated input, its spatial mean and the two excitation vectors (kept for backward)
+            self.se_state = {}
+            for i in p.se:
+                C = p.layers[i].cout
+                self.se_state[i] = dict(act=torch.zeros(M * C, **f32), s=torch.zeros(B * C, **f32),
+                                        e1=torch.zeros(B * (C // 4), **f32), e2=torch.zeros(B * C, **f32))
+            self.se_scratch = torch.zeros(B * (3 * cmax + cmax // 4), **f32)
+        if p.se or any(q is not None and q[0] == "avg" for q in p.pools):
             self.act = torch.zeros(M * cmax, **f32)        # activated, not yet averaged output of a layer
             self.gpool = torch.zeros(M * cmax, **f32)      # gradient wrt it
         self.gxh = torch.zeros(M * cmax, **f32)
@@ -279,6 +292,10 @@ class DilatedNet(object):
         off, _ = self.plan.offsets[self.plan.layers[i].name + "/weights"]
         return self.params[off:].data_ptr()
 
+    def _pptr(self, name, flat=None):
+        off, _ = self.plan.offsets[name]
+        return (self.params if flat is None else flat)[off:].data_ptr()
+
     def _bias_ptr(self, name):
         off, _ = self.plan.offsets[name + "/biases"]
         return self.params[off:].data_ptr()
@@ -305,7 +322,14 @@ class DilatedNet(object):
                 _lib.call("drs_bn_eval_coeffs", _ptr(mm), _ptr(mv), L.cout, _ptr(self.mean_rstd[i]), st)
             out, Pout, ldout, coff = self._out_view(i)
             mx, ak = self._is_max(i), self._avg_k(i)
-            if ak:      # activation into a plain [M][C] buffer, then the k x k average into the next layer's slab
+            if i in p.se:   # activation into a plain [M][C] buffer, then squeeze-and-excitation scaling into the next slab
+                stt, sc = self.se_state[i], p.se[i]
+                self._k("bn_act_pool_fwd", M * L.cout * 8.0, "drs_bn_act_pool_forward", _ptr(self.z[i]), B, S, L.cout,
+                        _ptr(self.mean_rstd[i]), p.alpha, 0, _ptr(stt["act"]), 0, L.cout, 0, None, st)
+                self._k("se_fwd", M * L.cout * 12.0, "drs_se_forward", _ptr(stt["act"]), B, S, L.cout, L.cout // 4,
+                        self._pptr(sc + "_fc1/weights"), self._pptr(sc + "_fc1/biases"), self._pptr(sc + "_fc2/weights"),
+                        self._pptr(sc + "_fc2/biases"), _ptr(stt["s"]), _ptr(stt["e1"]), _ptr(stt["e2"]), _ptr(out), Pout, ldout, coff, st)
+            elif ak:    # activation into a plain [M][C] buffer, then the k x k average into the next layer's slab
                 self._k("bn_act_pool_fwd", M * L.cout * 8.0, "drs_bn_act_pool_forward", _ptr(self.z[i]), B, S, L.cout,
                         _ptr(self.mean_rstd[i]), p.alpha, 0, _ptr(self.act), 0, L.cout, 0, None, st)
                 self._k("avg_pool_fwd", M * L.cout * 8.0, "drs_avg_pool_forward", _ptr(self.act), B, S, L.cout, ak, _ptr(out), Pout,
@@ -378,12 +402,10 @@ class DilatedNet(object):
         b0, _ = p.offsets[p.layers[0].name + "/biases"]
         self.grads[b0:boff].zero_()
         # gradient all-reduce in buckets that overlap the rest of the backward pass (collectives run on RCCL's own
-        # stream): the classifier + bias tail is final now; kernel gradients follow as their layers finish, last
-        # layers first (they hold most of the bytes: conv7+conv8 = 49 % of Dilated8Pooling)
+        # stream): kernel gradients go as their layers finish, last layers first (they hold most of the bytes: conv7+conv8
+        # = 49 % of Dilated8Pooling); the small classifier / SE / bias tail goes last
         pending = []
         bucket_hi = woff                       # kernels [bucket_lo, bucket_hi) of the flat buffer are still to be sent
-        if self.comm.world > 1:
-            pending.append(self.comm.all_reduce_sum_async(self.grads[woff:]))
         # reverse loop over the conv blocks.  The gradient wrt a slab is first SET (by the classifier, or by the first block
         # that propagates into it) and then ACCUMULATED into by every further reader of that slab (dense / squeeze nets)
         written = {p.feat}
@@ -391,7 +413,14 @@ class DilatedNet(object):
             L = p.layers[i]
             gcur, ldc, cc = self.gbuf[L.dst], p.buffers[L.dst][0], L.dst_coff
             mx, ak = self._is_max(i), self._avg_k(i)
-            if ak:
+            if i in p.se:
+                stt, sc = self.se_state[i], p.se[i]
+                self._k("se_bwd", M * L.cout * 16.0, "drs_se_backward", _ptr(gcur), ldc, cc, _ptr(stt["act"]), _ptr(stt["s"]),
+                        _ptr(stt["e1"]), _ptr(stt["e2"]), self._pptr(sc + "_fc1/weights"), self._pptr(sc + "_fc2/weights"), B, S, L.cout,
+                        L.cout // 4, _ptr(self.gpool), self._pptr(sc + "_fc1/weights", self.grads), self._pptr(sc + "_fc1/biases", self.grads),
+                        self._pptr(sc + "_fc2/weights", self.grads), self._pptr(sc + "_fc2/biases", self.grads), _ptr(self.se_scratch), st)
+                gsrc, lds_, cs_ = self.gpool, L.cout, 0
+            elif ak:
                 self._k("avg_pool_bwd", M * L.cout * 8.0, "drs_avg_pool_backward", _ptr(gcur), ldc, cc, B, S, L.cout, ak,
                         _ptr(self.gpool), st)
                 gsrc, lds_, cs_ = self.gpool, L.cout, 0
@@ -424,6 +453,7 @@ class DilatedNet(object):
                         acc, None, st)
         if self.comm.world > 1:
             pending.append(self.comm.all_reduce_sum_async(self.grads[0:bucket_hi]))      # the remaining (earliest) layers
+            pending.append(self.comm.all_reduce_sum_async(self.grads[woff:]))            # classifier, SE layers and every bias (small)
             self.comm.all_reduce_sum(self.scalars[:1])
             self.comm.all_reduce_sum(self.conf)
             self.comm.wait(pending)

@@ -44,12 +44,19 @@ _TABLES = {
     "dilated_icpr_rate6_squeeze": ("relu", False, "squeeze", 256, [
         ("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2, 32), ("conv3", 4, 64, 128, 3, 64),
         ("conv4", 4, 128, 128, 4, 64), ("conv5", 3, 128, 256, 5, 64), ("conv6", 3, 256, 256, 6, 128)]),
+    # squeeze-and-excitation variant (isprs:1036-1061): rate6 with an SE block (ratio 4) after conv2, conv4 and conv6
+    "dilated_icpr_rate6_SE": ("relu", False, False, 256, [
+        ("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2), ("conv3", 4, 64, 128, 3),
+        ("conv4", 4, 128, 128, 4), ("conv5", 3, 128, 256, 5), ("conv6", 3, 256, 256, 6)]),
     "dilated_icpr_rate6_densely": ("relu", False, True, 448, [
         ("conv1", 5, -1, 32, 1), ("conv2", 5, 32, 32, 2), ("conv3", 4, 64, 64, 3),
         ("conv4", 4, 128, 64, 4), ("conv5", 3, 192, 128, 5), ("conv6", 3, 320, 128, 6)]),
 }
 # isprs:1672 spells Dilated8Pooling 'dilated8_grsl'; coffee:1203, contest:1004 and README:33 'dilated_grsl_rate8'
 _ALIASES = {"dilated8_grsl": "dilated_grsl_rate8"}
+# block index -> SE scope placed after that block (isprs:1042, 1046, 1050); ratio 4
+_SE = {"dilated_icpr_rate6_SE": {1: "se1", 3: "se2", 5: "se3"}}
+SE_RATIO = 4
 
 # one conv block (conv + bias + BN + activation [+ pool]); it reads channels [0, cin) of activation buffer `src` and writes its
 # output into channels [dst_coff, dst_coff + cout) of buffer `dst`
@@ -135,12 +142,24 @@ class Plan(object):
             off += L.k * L.k * L.cin * L.cout
         self.offsets["conv_classifier/weights"] = (off, (1, 1, self.c_last, num_classes))
         off += self.c_last * num_classes
+        # squeeze-and-excitation FC layers (_fc_layer isprs:666-679: weights decayed, biases 0.1)
+        self.se = dict(_SE.get(self.net_type, {}))
+        for i, scope in sorted(self.se.items()):
+            C = self.layers[i].cout
+            for fc, shape in (("_fc1", (C, C // SE_RATIO)), ("_fc2", (C // SE_RATIO, C))):
+                self.offsets[scope + fc + "/weights"] = (off, shape)
+                off += shape[0] * shape[1]
         self.n_decay = off                              # weight decay applies to kernels only (isprs:640-652)
         for L in self.layers:
             self.offsets[L.name + "/biases"] = (off, (L.cout,))
             off += L.cout
         self.offsets["conv_classifier/biases"] = (off, (num_classes,))
         off += num_classes
+        for i, scope in sorted(self.se.items()):
+            C = self.layers[i].cout
+            for fc, n in (("_fc1", C // SE_RATIO), ("_fc2", C)):
+                self.offsets[scope + fc + "/biases"] = (off, (n,))
+                off += n
         self.n_params = off
         # batch-norm moving statistics: per block mean[C] then variance[C]
         self.bn_offsets = {}

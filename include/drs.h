@@ -99,6 +99,17 @@ int drs_avg_pool_forward(const float* in, int B, int S, int C, int k, float* out
                          void* stream);
 int drs_avg_pool_backward(const float* gout, int ld_g, int coff_g, int B, int S, int C, int k, float* gin, void* stream);
 
+/* ---- _squeeze_excitation_layer of the `_SE` variant (isprs:682-697, _fc_layer :666-679) -------------------------
+ * forward : act [B*S*S][C] (activated block output) -> s = spatial mean, e1 = relu(s w1 + b1) [B][R], e2 = sigmoid(e1 w2 + b2)
+ *           [B][C] (all three kept for the backward pass), out view = act * e2 (halo zeroed);  w1 [C][R], w2 [R][C].
+ * backward: gy (gradient wrt the scaled output) -> gact [B*S*S][C] and the four parameter gradients (sums over this rank's
+ *           images, fixed order); scratch: B*(3*C + R) floats. */
+int drs_se_forward(const float* act, int B, int S, int C, int R, const float* w1, const float* b1, const float* w2, const float* b2,
+                   float* s, float* e1, float* e2, float* out, int P_out, int ld_out, int coff_out, void* stream);
+int drs_se_backward(const float* gy, int ld_g, int coff_g, const float* act, const float* s, const float* e1, const float* e2,
+                    const float* w1, const float* w2, int B, int S, int C, int R, float* gact, float* dw1, float* db1, float* dw2,
+                    float* db2, float* scratch, void* stream);
+
 /* ---- 1x1 classifier + sparse softmax cross-entropy + tf.argmax (+ their gradients) ----------------------
  * (isprs:1024-1031, 1089-1099, 1690; masked loss: contest_dilated_random.py:881-901; confusion matrix:
  * calc_accuracy_by_crop isprs:510-531).  feat: haloed view with C channels (multiple of 64, <= 448);

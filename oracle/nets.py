@@ -60,6 +60,11 @@ NETS = {
         act="relu", pool=False, dense=False, convs=[("conv1", 5, -1, 64, 1)],
         squeezes=[("conv2", 5, 64, 64, 2, 32), ("conv3", 4, 64, 128, 3, 64), ("conv4", 4, 128, 128, 4, 64),
                   ("conv5", 3, 128, 256, 5, 64), ("conv6", 3, 256, 256, 6, 128)], c_last=256),
+    # isprs:1036-1061: SE blocks (ratio 4) after conv2 / conv4 / conv6; se: block index -> scope
+    "dilated_icpr_rate6_SE": dict(
+        act="relu", pool=False, dense=False, se={1: "se1", 3: "se2", 5: "se3"},
+        convs=[("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2), ("conv3", 4, 64, 128, 3),
+               ("conv4", 4, 128, 128, 4), ("conv5", 3, 128, 256, 5), ("conv6", 3, 256, 256, 6)], c_last=256),
     "dilated_icpr_rate6_densely": dict(
         act="relu", pool=False, dense=True,
         convs=[("conv1", 5, -1, 32, 1), ("conv2", 5, 32, 32, 2),

@@ -155,6 +155,27 @@ def avg_pool_same_bwd(g, k, cnt):
     return gp[:, r:r + H, r:r + W, :]
 
 
+# --------------------------------------------------------------------------- squeeze-and-excitation
+def se_forward(x, w1, b1, w2, b2):
+    """_squeeze_excitation_layer (isprs:682-697): reduce_mean over H,W -> _fc_layer -> relu -> _fc_layer -> sigmoid -> scale."""
+    s = x.mean(axis=(1, 2))
+    pre1 = s @ w1 + b1
+    e1 = np.maximum(pre1, 0)
+    e2 = 1.0 / (1.0 + np.exp(-(e1 @ w2 + b2)))
+    return x * e2[:, None, None, :], (s, e1, e2)
+
+
+def se_backward(x, state, w1, w2, gy):
+    s, e1, e2 = state
+    hw = x.shape[1] * x.shape[2]
+    ge2 = (gy * x).sum(axis=(1, 2))
+    gpre2 = ge2 * e2 * (1 - e2)
+    gpre1 = (gpre2 @ w2.T) * (e1 > 0)
+    gs = gpre1 @ w1.T
+    gx = gy * e2[:, None, None, :] + gs[:, None, None, :] / hw
+    return gx, dict(w1=s.T @ gpre1, b1=gpre1.sum(axis=0), w2=e1.T @ gpre2, b2=gpre2.sum(axis=0))
+
+
 # --------------------------------------------------------------------------- loss
 def softmax_ce(logits, labels, mask=None):
     """loss_def (isprs:1089-1099): mean over ALL pixels of sparse softmax-CE.
@@ -222,6 +243,12 @@ class OracleNet(object):
             self.p[name + "/biases"] = np.full((co,), 0.1, dtype=dtype)          # isprs:707
             self.p[name + "/moving_mean"] = np.zeros((co,), dtype=dtype)
             self.p[name + "/moving_variance"] = np.ones((co,), dtype=dtype)
+        for li, scope in sorted(self.spec.get("se", {}).items()):          # _fc_layer isprs:666-679, ratio 4 isprs:1042
+            C = self.convs[li][3]
+            self.p[scope + "_fc1/weights"] = (rng.normal(size=(C, C // 4)) * 0.005).astype(dtype)
+            self.p[scope + "_fc1/biases"] = np.full((C // 4,), 0.1, dtype=dtype)
+            self.p[scope + "_fc2/weights"] = (rng.normal(size=(C // 4, C)) * 0.005).astype(dtype)
+            self.p[scope + "_fc2/biases"] = np.full((C,), 0.1, dtype=dtype)
         cl = self.spec["c_last"]
         self.p["conv_classifier/weights"] = xavier_uniform(rng, (1, 1, cl, num_classes)).astype(dtype)
         self.p["conv_classifier/biases"] = np.zeros((num_classes,), dtype=dtype)  # isprs:1028
@@ -287,8 +314,15 @@ class OracleNet(object):
                 cur = np.concatenate([cur, self._block_fwd(li, cur, is_training, decisions)], axis=3)
         else:
             cur = x
+            self._se_cache = {}
             for li in range(n):
                 cur = self._block_fwd(li, cur, is_training, decisions)
+                if li in self.spec.get("se", {}):
+                    sc = self.spec["se"][li]
+                    xin = cur
+                    cur, state = se_forward(xin, self.p[sc + "_fc1/weights"], self.p[sc + "_fc1/biases"],
+                                            self.p[sc + "_fc2/weights"], self.p[sc + "_fc2/biases"])
+                    self._se_cache[li] = (xin, state)
         feat = cur
         logits = feat @ self.p["conv_classifier/weights"][0, 0] + self.p["conv_classifier/biases"]
         self.cache = (self._cache, feat)
@@ -321,6 +355,12 @@ class OracleNet(object):
             self._block_bwd(0, gcur, g)
         else:
             for li in reversed(range(n)):
+                if li in self.spec.get("se", {}):
+                    sc = self.spec["se"][li]
+                    xin, state = self._se_cache[li]
+                    gcur, gp = se_backward(xin, state, self.p[sc + "_fc1/weights"], self.p[sc + "_fc2/weights"], gcur)
+                    g[sc + "_fc1/weights"], g[sc + "_fc1/biases"] = gp["w1"], gp["b1"]
+                    g[sc + "_fc2/weights"], g[sc + "_fc2/biases"] = gp["w2"], gp["b2"]
                 gcur = self._block_bwd(li, gcur, g)
         for nm in g:
             if nm.endswith("/weights"):

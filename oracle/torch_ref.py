@@ -30,6 +30,12 @@ class TorchNet(object):
             self.b[name] = torch.full((co,), 0.1, dtype=dtype, requires_grad=True)
             self.mm[name] = torch.zeros(co, dtype=dtype)
             self.mv[name] = torch.ones(co, dtype=dtype)
+        self.fcw, self.fcb = {}, {}
+        for li, scope in sorted(self.spec.get("se", {}).items()):
+            C = self.convs[li][3]
+            for fc, (a, b_) in (("_fc1", (C, C // 4)), ("_fc2", (C // 4, C))):
+                self.fcw[scope + fc] = torch.zeros(a, b_, dtype=dtype, requires_grad=True)
+                self.fcb[scope + fc] = torch.zeros(b_, dtype=dtype, requires_grad=True)
         cl = self.spec["c_last"]
         self.w["conv_classifier"] = torch.zeros(num_classes, cl, 1, 1, dtype=dtype, requires_grad=True)
         self.b["conv_classifier"] = torch.zeros(num_classes, dtype=dtype, requires_grad=True)
@@ -44,6 +50,9 @@ class TorchNet(object):
                 self.w[n].copy_(torch.from_numpy(np.ascontiguousarray(
                     np.transpose(params[n + "/weights"], (3, 2, 0, 1)))).to(self.dtype))
                 self.b[n].copy_(torch.from_numpy(np.asarray(params[n + "/biases"])).to(self.dtype))
+            for n in self.fcw:
+                self.fcw[n].copy_(torch.from_numpy(np.asarray(params[n + "/weights"])).to(self.dtype))
+                self.fcb[n].copy_(torch.from_numpy(np.asarray(params[n + "/biases"])).to(self.dtype))
             for n in self.mm:
                 self.mm[n].copy_(torch.from_numpy(np.asarray(params[n + "/moving_mean"])).to(self.dtype))
                 self.mv[n].copy_(torch.from_numpy(np.asarray(params[n + "/moving_variance"])).to(self.dtype))
@@ -53,6 +62,9 @@ class TorchNet(object):
         for n in self.w:
             out[n + "/weights"] = np.transpose(self.w[n].detach().numpy(), (2, 3, 1, 0)).copy()
             out[n + "/biases"] = self.b[n].detach().numpy().copy()
+        for n in self.fcw:
+            out[n + "/weights"] = self.fcw[n].detach().numpy().copy()
+            out[n + "/biases"] = self.fcb[n].detach().numpy().copy()
         for n in self.mm:
             out[n + "/moving_mean"] = self.mm[n].numpy().copy()
             out[n + "/moving_variance"] = self.mv[n].numpy().copy()
@@ -89,6 +101,11 @@ class TorchNet(object):
             cur = x
             for li in range(n):
                 cur = self._block(li, cur, is_training)
+                if li in self.spec.get("se", {}):                           # isprs:682-697
+                    sc = self.spec["se"][li]
+                    sq = cur.mean(dim=(2, 3))
+                    ex = torch.sigmoid(F.relu(sq @ self.fcw[sc + "_fc1"] + self.fcb[sc + "_fc1"]) @ self.fcw[sc + "_fc2"] + self.fcb[sc + "_fc2"])
+                    cur = cur * ex[:, :, None, None]
         logits = F.conv2d(cur, self.w["conv_classifier"], self.b["conv_classifier"])
         return logits.permute(0, 2, 3, 1)
 
@@ -99,11 +116,11 @@ class TorchNet(object):
             m = torch.as_tensor(np.asarray(mask).reshape(-1).astype(bool))
             lg, yy = lg[m], yy[m]
         ce = F.cross_entropy(lg, yy, reduction="mean")
-        l2 = sum(0.5 * (w ** 2).sum() for w in self.w.values())
+        l2 = sum(0.5 * (w ** 2).sum() for w in list(self.w.values()) + list(self.fcw.values()))
         return ce + weight_decay * l2
 
     def params_list(self):
-        return list(self.w.values()) + list(self.b.values())
+        return list(self.w.values()) + list(self.b.values()) + list(self.fcw.values()) + list(self.fcb.values())
 
     def grads(self, x, y, weight_decay, mask=None):
         for p in self.params_list():
@@ -115,6 +132,9 @@ class TorchNet(object):
         for n in self.w:
             g[n + "/weights"] = np.transpose(self.w[n].grad.numpy(), (2, 3, 1, 0)).copy()
             g[n + "/biases"] = self.b[n].grad.numpy().copy()
+        for n in self.fcw:
+            g[n + "/weights"] = self.fcw[n].grad.numpy().copy()
+            g[n + "/biases"] = self.fcb[n].grad.numpy().copy()
         return float(loss.detach()), logits.detach().numpy(), g
 
     def train_step(self, x, y, lr0, weight_decay, lr_factor=0.5, mask=None):

@@ -11,7 +11,8 @@ from oracle import nets
 CASES = [("dilated_icpr_original", 3, 6, 2, 9), ("dilated_grsl", 5, 6, 2, 10),
          ("dilated8_grsl", 5, 6, 2, 11), ("dilated_icpr_rate6_densely", 4, 2, 3, 8),
          ("dilated_icpr_rate6_small", 3, 6, 2, 8), ("dilated_icpr_vary_rate", 3, 2, 2, 9),
-         ("dilated_icpr_rate6_avgpool", 3, 6, 2, 9), ("dilated_icpr_rate6_squeeze", 3, 6, 2, 8)]
+         ("dilated_icpr_rate6_avgpool", 3, 6, 2, 9), ("dilated_icpr_rate6_squeeze", 3, 6, 2, 8),
+         ("dilated_icpr_rate6_SE", 3, 6, 3, 8)]
 
 
 def test_same_pad_table():
