@@ -34,6 +34,9 @@ _TABLES = {
     "dilated_icpr_vary_rate": ("relu", False, False, 256, [                   # coffee:816-830
         ("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2), ("conv3", 4, 64, 128, 4),
         ("conv4", 4, 128, 128, 1), ("conv5", 3, 128, 256, 2), ("conv6", 3, 256, 256, 4)]),
+    # contest's shallow net (contest_dilated_random.py:574-601): conv1, conv3, conv5 only
+    "dilated_icpr_old": ("relu", False, False, 256, [
+        ("conv1", 5, -1, 64, 1), ("conv3", 4, 64, 128, 2), ("conv5", 3, 128, 256, 4)]),
     # average-pooled variant (isprs:818-854, coffee:721-740): 5x5 / 7x7 stride-1 SAME average pools, none after conv6
     "dilated_icpr_rate6_avgpool": ("relu", [("avg", 5), ("avg", 5), ("avg", 5), ("avg", 7), ("avg", 7), None], False, 256, [
         ("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2), ("conv3", 4, 64, 128, 3),
@@ -53,7 +56,8 @@ _TABLES = {
         ("conv4", 4, 128, 64, 4), ("conv5", 3, 192, 128, 5), ("conv6", 3, 320, 128, 6)]),
 }
 # isprs:1672 spells Dilated8Pooling 'dilated8_grsl'; coffee:1203, contest:1004 and README:33 'dilated_grsl_rate8'
-_ALIASES = {"dilated8_grsl": "dilated_grsl_rate8"}
+# contest's 'dilated_grsl_old' (contest:604-641) is layer for layer dilated_grsl
+_ALIASES = {"dilated8_grsl": "dilated_grsl_rate8", "dilated_grsl_old": "dilated_grsl"}
 # block index -> SE scope placed after that block (isprs:1042, 1046, 1050); ratio 4
 _SE = {"dilated_icpr_rate6_SE": {1: "se1", 3: "se2", 5: "se3"}}
 SE_RATIO = 4

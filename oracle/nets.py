@@ -50,6 +50,10 @@ NETS = {
         act="relu", pool=False, dense=False,
         convs=[("conv1", 5, -1, 64, 1), ("conv2", 5, 64, 64, 2), ("conv3", 4, 64, 128, 4),
                ("conv4", 4, 128, 128, 1), ("conv5", 3, 128, 256, 2), ("conv6", 3, 256, 256, 4)], c_last=256),
+    # contest_dilated_random.py:574-601
+    "dilated_icpr_old": dict(
+        act="relu", pool=False, dense=False,
+        convs=[("conv1", 5, -1, 64, 1), ("conv3", 4, 64, 128, 2), ("conv5", 3, 128, 256, 4)], c_last=256),
     # isprs:818-854 / coffee:721-740: average pools (5,5,5,7,7) after conv1..5, none after conv6
     "dilated_icpr_rate6_avgpool": dict(
         act="relu", pool=False, dense=False, pools=[5, 5, 5, 7, 7, 0],
@@ -73,7 +77,7 @@ NETS = {
         c_last=448),
 }
 # isprs:1672 spells Dilated8Pooling 'dilated8_grsl'; coffee/contest/README spell it 'dilated_grsl_rate8'
-ALIASES = {"dilated8_grsl": "dilated_grsl_rate8"}
+ALIASES = {"dilated8_grsl": "dilated_grsl_rate8", "dilated_grsl_old": "dilated_grsl"}
 
 
 def resolve(net_type):

@@ -19,7 +19,8 @@ CASES = [("dilated_icpr_original", 3, 6, 2, 25), ("dilated_grsl", 5, 6, 3, 19), 
          ("dilated_icpr_rate6_nodilation", 3, 2, 2, 14), ("dilated_icpr_vary_rate", 3, 7, 1, 19),
          ("dilated_icpr_rate6_avgpool", 3, 6, 2, 13), ("dilated_icpr_rate6_avgpool", 3, 2, 1, 5),
          ("dilated_icpr_rate6_squeeze", 3, 6, 2, 15), ("dilated_icpr_rate6_squeeze", 5, 6, 1, 22),
-         ("dilated_icpr_rate6_SE", 3, 6, 3, 14), ("dilated_icpr_rate6_SE", 5, 2, 1, 21)]
+         ("dilated_icpr_rate6_SE", 3, 6, 3, 14), ("dilated_icpr_rate6_SE", 5, 2, 1, 21),
+         ("dilated_icpr_old", 3, 7, 2, 18), ("dilated_grsl_old", 3, 7, 1, 16)]
 
 
 def _mk(net, ch, K, B, S, seed):
