@@ -9,7 +9,9 @@ import scipy.ndimage
 from scipy.spatial import cKDTree
 
 
-def make_tile(h, w, channels=5, num_classes=6, seed=1234, n_seeds=400, dtype=np.float64):
+def make_tile(h, w, channels=5, num_classes=6, seed=1234, n_seeds=400, dtype=np.float64, class_signal=0.0, signal_seed=99):
+    """class_signal > 0 adds a per-class offset to every band (the same offsets for every tile that shares
+    `signal_seed`), so that the labels can be learnt from the pixels: accuracy-parity runs need that."""
     rng = np.random.default_rng(seed)
     img = rng.uniform(0.0, 1.0, size=(h, w, channels))
     for c in range(min(3, channels)):
@@ -25,6 +27,9 @@ def make_tile(h, w, channels=5, num_classes=6, seed=1234, n_seeds=400, dtype=np.
     _, nearest = cKDTree(pts).query(np.stack([yy.ravel(), xx.ravel()], axis=1))
     lab = cls[nearest].reshape(hc, wc).astype(np.uint8)
     lab = np.repeat(np.repeat(lab, f, axis=0), f, axis=1)[:h, :w]
+    if class_signal:
+        means = np.random.default_rng(signal_seed).uniform(-1.0, 1.0, size=(num_classes, channels))
+        img = np.clip(img + class_signal * means[lab], 0.0, 1.0)
     return img.astype(dtype), np.ascontiguousarray(lab)
 
 
