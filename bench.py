@@ -151,6 +151,8 @@ def main():
         epoch_cm.add_(out["conf"])
         return out
 
+    if args.warmup == 0:
+        one_step()          # with W = 0 still load the code objects / create the communicators outside the timed region
     for _ in range(args.warmup):
         one_step()
     if comm:
@@ -232,6 +234,7 @@ def main():
                        "parallelism": "dp%d" % world + (" (REHEARSAL: all ranks on one GPU over gloo)" if rehearsal else ""),
                        "sync_bn": True},
             "val_pixels_per_sec": round(val_pixels_per_s, 1), "final_loss": round(loss, 5),
+            "workspace_gb_per_gpu": round(net.workspace_bytes() / 1e9, 2),
             "train_tflops": round(value * 3 * 2 * net.plan.mac_per_pixel() * PATCH * PATCH / 1e12, 2),
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
         }

@@ -116,3 +116,15 @@ def test_augmentation_draw_order_and_crop_algebra(golden_dir):
         np.testing.assert_array_equal(p, g["train_p_%d" % s])
         np.testing.assert_array_equal(c, g["train_c_%d" % s])
         np.testing.assert_array_equal(m, g["train_m_%d" % s])
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    """There is no CPU fallback: without libdrs_hip.so the binding raises, and so does everything built on it."""
+    import pytest
+    from drs_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libdrs_hip.so")
+    with pytest.raises(_lib.DrsError):
+        _lib.load()
+    with pytest.raises(_lib.DrsError):
+        _lib.call("drs_conv_mtile", 64)
