@@ -1,0 +1,584 @@
+// Dilated stride-1 SAME convolution on gfx950 with fp32 operands carried as sums of bf16 terms ("split-bf16").
+//
+// Same operator as conv_mfma.hip (tf.nn.atrous_conv2d / tf.nn.conv2d + bias_add and their gradients,
+// /root/reference/isprs_dilated_random.py:710-713); what differs is the arithmetic.  Every fp32 operand x is stored
+// as NS bf16 planes x = x_0 + x_1 (+ x_2) (+ residual), each plane the round-to-nearest bf16 of what the previous
+// ones left, and a product a*b is evaluated on the bf16 MFMA pipe (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA
+// rate) as the partial products a_i*b_j with i + j < NS, accumulated in fp32:
+//   NS = 2 ("bf16x3"):  a0 b0 + a0 b1 + a1 b0                         relative error of a product <= ~2^-16
+//   NS = 3 ("bf16x6"):  a0 b0 + a0 b1 + a1 b0 + a0 b2 + a2 b0 + a1 b1  relative error <= ~2^-25 (below one fp32 ulp)
+// Each bf16 x bf16 product is exact in fp32, so with NS = 3 the only roundings left are those of the fp32
+// accumulation, as in the exact-fp32 kernel.  The fp32 path (conv_mfma.hip) stays the default arithmetic.
+//
+// Layouts: activation planes use the element indexing of the fp32 slab they were split from (padded NHWC view
+// (S, P, ld, coff)), 2 bytes per element, `plane_stride` elements between planes.  Filters are split into the
+// K-contiguous form the MFMA B operand wants: forward [NS][Cout][k*k*Cin], input gradient [NS][Cin][k*k*Cout] (taps
+// reversed), so both operands of the implicit GEMM are rows of 16-byte K-chunks.
+#include "drs_common.hpp"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float x) {
+  const __bf16 h = (__bf16)x;                       // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+  return (uint32_t)__builtin_bit_cast(unsigned short, h);
+}
+
+// x -> NS bf16 terms, term s = rne_bf16(x - sum of the earlier terms)   (the subtraction is exact in fp32)
+template <int NS>
+__device__ __forceinline__ void split_terms(float x, uint32_t (&t)[NS]) {
+  float r = x;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    t[s] = f32_to_bf16_bits(r);
+    r -= bf16_bits_to_f32(t[s]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ splitting
+// planes[s][i] = term s of src[i], i < n (n a multiple of 8; slabs are)
+template <int NS>
+__global__ void split_planes_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n8, size_t plane_stride) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 a = reinterpret_cast<const f32x4*>(src)[2 * i];
+    const f32x4 b = reinterpret_cast<const f32x4*>(src)[2 * i + 1];
+    uint32_t t[8][NS];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { split_terms<NS>(a[e], t[e]); split_terms<NS>(b[e], t[4 + e]); }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = t[2 * e][s] | (t[2 * e + 1][s] << 16);
+      *reinterpret_cast<u32x4*>(dst + s * plane_stride + 8 * i) = o;
+    }
+  }
+}
+
+// forward filter planes:  wf[s][o][tap*cin_pad + c] = term s of (c < cin ? w[tap][c][o] : 0)
+// gradient filter planes: wd[s][c][(taps-1-tap)*cout + o] = term s of w[tap][c][o]        (c < cin)
+template <int NS>
+__global__ void filter_split_kernel(const float* __restrict__ w, int taps, int cin, int cin_pad, int cout,
+                                    uint16_t* __restrict__ wf, uint16_t* __restrict__ wd) {
+  const int nf = cout * taps * cin_pad;
+  const int nd = wd ? cin * taps * cout : 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nf + nd; i += gridDim.x * blockDim.x) {
+    float v;
+    uint16_t* dst;
+    size_t stride;
+    if (i < nf) {
+      const int c = i % cin_pad;
+      const int rest = i / cin_pad;
+      const int tap = rest % taps, o = rest / taps;
+      v = c < cin ? w[((size_t)tap * cin + c) * cout + o] : 0.f;
+      dst = wf + i;
+      stride = (size_t)nf;
+    } else {
+      const int j = i - nf;
+      const int o = j % cout;
+      const int rest = j / cout;
+      const int tapr = rest % taps, c = rest / taps;
+      v = w[((size_t)(taps - 1 - tapr) * cin + c) * cout + o];
+      dst = wd + j;
+      stride = (size_t)nd;
+    }
+    uint32_t t[NS];
+    split_terms<NS>(v, t);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) dst[s * stride] = (uint16_t)t[s];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ forward / dgrad
+constexpr int BK = 32;          // channels per K-step (one filter tap x 32 channels = two MFMA k-steps of 16)
+constexpr int LDR = BK + 8;     // LDS row stride in bf16 elements: 80 B -> 16 consecutive rows hit 16 distinct 16-B slots
+
+struct SplitConvArgs {
+  const uint16_t* in; size_t in_stride; int S, P, ld_in, coff_in;
+  int M;
+  const uint16_t* w; size_t w_stride;   // [NS][Cout][k*k*Cin]
+  const float* bias;
+  float* out; int ld_out, coff_out;
+  float* stats;
+  int k, rate, pad, Cin, Cout;
+  int accumulate;
+  float rcpS, rcpSS;
+};
+
+template <int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(256) void conv_split_kernel(const SplitConvArgs a) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int NA = BM / 64, NB = BN / 64;     // 16-byte loads per thread per plane per K-step
+  static_assert(BN >= 64, "B tile rows are loaded 64 at a time");
+
+  __shared__ __attribute__((aligned(16))) uint16_t lds[NS * (BM + BN) * LDR];
+  uint16_t* As = lds;                           // [NS][BM][LDR]
+  uint16_t* Bs = lds + NS * BM * LDR;           // [NS][BN][LDR]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int ntn = a.Cout / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / ntn) * BM;
+  const int n0 = (tile % ntn) * BN;
+
+  const int Sp = a.S + 2 * a.P;
+  const int Ktot = a.k * a.k * a.Cin;
+  const int lrow = t >> 2, lchk = (t & 3) * 8;  // this thread stages 16-byte chunk lchk of rows lrow + 64 i
+  uint32_t offA[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    int p = m0 + lrow + 64 * i;
+    p = p < a.M ? p : a.M - 1;
+    offA[i] = padded_pixel_off(p, a.S, a.P, a.ld_in, a.rcpS, a.rcpSS, -a.pad, -a.pad) + (uint32_t)(a.coff_in + lchk);
+  }
+  uint32_t offB[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) offB[i] = (uint32_t)((n0 + lrow + 64 * i) * Ktot + lchk);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int cpt = a.Cin / BK;
+  const int nks = a.k * a.k * cpt;
+  u32x4 ra[NS][NA], rb[NS][NB];
+  int lu = 0, lv = 0, lc = 0;
+
+  auto gload = [&](int ks) {
+    const uint32_t soff = (uint32_t)((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) ra[s][i] = *reinterpret_cast<const u32x4*>(a.in + s * a.in_stride + offA[i] + soff);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) rb[s][i] = *reinterpret_cast<const u32x4*>(a.w + s * a.w_stride + offB[i] + ks * BK);
+    }
+    if (++lc == cpt) { lc = 0; if (++lv == a.k) { lv = 0; ++lu; } }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) *reinterpret_cast<u32x4*>(&As[(s * BM + lrow + 64 * i) * LDR + lchk]) = ra[s][i];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) *reinterpret_cast<u32x4*>(&Bs[(s * BN + lrow + 64 * i) * LDR + lchk]) = rb[s][i];
+    }
+  };
+
+  gload(0);
+  lstore();
+  __syncthreads();
+  const int arow = wm * WTM + li, brow = wn * WTN + li;
+  for (int ks = 0; ks < nks; ++ks) {
+    if (ks + 1 < nks) gload(ks + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8 fa[NS][TM], fb[NS][TN];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+          fa[s][mi] = *reinterpret_cast<const bf16x8*>(&As[(s * BM + arow + mi * 32) * LDR + kk * 16 + h * 8]);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+          fb[s][ni] = *reinterpret_cast<const bf16x8*>(&Bs[(s * BN + brow + ni * 32) * LDR + kk * 16 + h * 8]);
+      }
+      // partial products a_i * b_j, i + j < NS, smallest terms first
+#pragma unroll
+      for (int d = NS - 1; d >= 0; --d)
+#pragma unroll
+        for (int i = 0; i <= d; ++i)
+#pragma unroll
+          for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][mi], fb[d - i][ni], acc[mi][ni], 0, 0, 0);
+    }
+    __syncthreads();
+    if (ks + 1 < nks) { lstore(); __syncthreads(); }
+  }
+
+  // ---- epilogue (as conv_igemm_kernel): C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  float s1[TN], s2[TN];
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni) { s1[ni] = 0.f; s2[ni] = 0.f; }
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni) {
+    const int col = n0 + wn * WTN + ni * 32 + li;
+    const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < a.M) {
+          float v = acc[mi][ni][r] + bv;
+          float* dst = a.out + (size_t)row * a.ld_out + a.coff_out + col;
+          if (a.accumulate) v += *dst;
+          *dst = v;
+          s1[ni] += v;
+          s2[ni] += v * v;
+        }
+      }
+    }
+  }
+  if (a.stats) {
+    float* red = reinterpret_cast<float*>(lds);   // [WM][BN][2], aliases the (finished) A tile
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      s1[ni] += __shfl_xor(s1[ni], 32);
+      s2[ni] += __shfl_xor(s2[ni], 32);
+      if (h == 0) {
+        const int c = wn * WTN + ni * 32 + li;
+        red[(wm * BN + c) * 2 + 0] = s1[ni];
+        red[(wm * BN + c) * 2 + 1] = s2[ni];
+      }
+    }
+    __syncthreads();
+    if (t < BN) {
+      float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { u1 += red[(w * BN + t) * 2]; u2 += red[(w * BN + t) * 2 + 1]; }
+      float* dst = a.stats + ((size_t)(m0 / BM) * a.Cout + n0 + t) * 2;
+      dst[0] = u1;
+      dst[1] = u2;
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int NS>
+int launch_split(const SplitConvArgs& a, hipStream_t st) {
+  const int mt = (a.M + BM - 1) / BM, nt = a.Cout / BN;
+  DRS_LAUNCH((conv_split_kernel<BM, BN, WM, WN, NS>), dim3(mt * nt), dim3(256), 0, st, a);
+  return DRS_LAUNCH_CHECK();
+}
+
+template <int NS>
+int dispatch_split(const SplitConvArgs& a, hipStream_t st) {
+  if (a.Cout % 128 == 0) return launch_split<128, 128, 2, 2, NS>(a, st);
+  return launch_split<256, 64, 4, 1, NS>(a, st);
+}
+
+// ------------------------------------------------------------------------------------------------ wgrad
+// dW[(tap, c)][o] = sum_p X[p + tap][c] * G[p][o]: the contraction runs over pixels, so both MFMA operands are wanted
+// pixel-major per lane while the planes are stored [pixel][channel].  The LDS images keep the stored orientation
+// (rows = pixels) and the fragments are fetched with ds_read_b64_tr_b16, the gfx950 transposing LDS read: per 16-lane
+// group it reads a 4-row x 16-column block of 16-bit elements (lane 4q+p supplies the address of row q, columns
+// 4p..4p+3) and hands lane i column i of the 4 rows.  Two such reads = the 8 consecutive k (pixels) of one MFMA
+// operand.  Row stride = tile width + 32 elements (64 B), so the 4 rows of a read fall on the four 64-byte quarters
+// of the 256-byte bank row: conflict-free.
+struct SplitWgradArgs {
+  const uint16_t* x; size_t x_stride; int S, Px, ld_x, coff_x;
+  const uint16_t* g; size_t g_stride; int Pg, ld_g, coff_g;
+  int M;
+  int k, rate, pad, Cin, Cout;
+  float* slab;
+  int chunks_per_split;
+  int ntr, nto;
+  float rcpS, rcpSS;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const uint16_t* p0, const uint16_t* p1) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p1));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int TR, int TO, int NS>
+__global__ __launch_bounds__((TR / 64) * (TO / 64) * 64) void wgrad_split_kernel(const SplitWgradArgs a) {
+  constexpr int WR = TR / 64, WC = TO / 64;
+  constexpr int NT = 64 * WR * WC;
+  constexpr int BP = 32;                        // pixels per K-step = two MFMA k-steps
+  constexpr int LDX = TR + 32, LDG = TO + 32;   // LDS row strides (elements)
+  constexpr int XQ = TR / 8, GQ = TO / 8;       // 16-byte chunks per pixel row
+  constexpr int NX = BP * XQ / NT, NG = BP * GQ / NT;
+  constexpr int XPS = NT / XQ, GPS = NT / GQ;
+
+  __shared__ __attribute__((aligned(16))) uint16_t lds[NS * BP * (LDX + LDG)];
+  __shared__ uint32_t tabx[2][BP], tabg[2][BP];
+  uint16_t* Xs = lds;                           // [NS][BP][LDX]
+  uint16_t* Gs = lds + NS * BP * LDX;           // [NS][BP][LDG]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int wr = wave / WC, wc = wave % WC;
+
+  const int ntile = a.ntr * a.nto;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = id / ntile;
+  const int tile = id % ntile;
+  const int R0 = (tile / a.nto) * TR;
+  const int o0 = (tile % a.nto) * TO;
+  const int rows_all = a.k * a.k * a.Cin;
+  const int myR = R0 + (t % XQ) * 8;            // this thread always stages the same 8 rows (tap, c..c+7)
+  const bool row_ok = myR < rows_all;
+  const int tap = (row_ok ? myR : 0) / a.Cin, c0 = (row_ok ? myR : 0) % a.Cin;
+  const int u = tap / a.k, v = tap % a.k;
+  const int Sxp = a.S + 2 * a.Px;
+  const uint32_t xconst = (uint32_t)((u * a.rate * Sxp + v * a.rate) * a.ld_x + a.coff_x + c0);
+  const uint32_t gconst = (uint32_t)(a.coff_g + o0 + (t % GQ) * 8);
+  const int xpix = t / XQ, gpix = t / GQ;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int nchunks_total = (a.M + BP - 1) / BP;
+  const int cbeg = split * a.chunks_per_split;
+  int cend = cbeg + a.chunks_per_split;
+  cend = cend < nchunks_total ? cend : nchunks_total;
+
+  auto fill_tables = [&](int chunk) {
+    if (t < BP && chunk < cend) {
+      const int p = chunk * BP + t;
+      const int pc = p < a.M ? p : a.M - 1;
+      tabx[chunk & 1][t] = padded_pixel_off(pc, a.S, a.Px, a.ld_x, a.rcpS, a.rcpSS, -a.pad, -a.pad);
+      tabg[chunk & 1][t] = padded_pixel_off(pc, a.S, a.Pg, a.ld_g, a.rcpS, a.rcpSS, 0, 0) | (p < a.M ? 0u : 0x80000000u);
+    }
+  };
+
+  u32x4 rx[NS][NX], rg[NS][NG];
+  auto gload = [&](int chunk) {
+    const uint32_t* tx = tabx[chunk & 1];
+    const uint32_t* tg = tabg[chunk & 1];
+    uint32_t ox[NX], og[NG];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) ox[i] = tx[xpix + XPS * i];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) og[i] = tg[gpix + GPS * i];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) rx[s][i] = *reinterpret_cast<const u32x4*>(a.x + s * a.x_stride + ox[i] + xconst);
+#pragma unroll
+      for (int i = 0; i < NG; ++i) rg[s][i] = *reinterpret_cast<const u32x4*>(a.g + s * a.g_stride + (og[i] & 0x7fffffffu) + gconst);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int i = 0; i < NG; ++i)
+        if (og[i] & 0x80000000u) rg[s][i] = u32x4{0u, 0u, 0u, 0u};
+      if (!row_ok) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) rx[s][i] = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) *reinterpret_cast<u32x4*>(&Xs[(s * BP + xpix + XPS * i) * LDX + (t % XQ) * 8]) = rx[s][i];
+#pragma unroll
+      for (int i = 0; i < NG; ++i) *reinterpret_cast<u32x4*>(&Gs[(s * BP + gpix + GPS * i) * LDG + (t % GQ) * 8]) = rg[s][i];
+    }
+  };
+
+  if (cbeg < cend) {
+    fill_tables(cbeg);
+    fill_tables(cbeg + 1);
+    __syncthreads();
+    gload(cbeg);
+    lstore();
+    __syncthreads();
+    // transposing-read lane roles: group = lane>>4 -> channel block (group&1)*16, pixel block (group>>1)*8;
+    // inside the group lane 4q+p addresses pixel row q, columns 4p..4p+3
+    const int l16 = lane & 15;
+    const int trow = h * 8 + (l16 >> 2);
+    const int tcol = ((lane >> 4) & 1) * 16 + (l16 & 3) * 4;
+    const uint16_t* xbase = Xs + trow * LDX + wr * 64 + tcol;
+    const uint16_t* gbase = Gs + trow * LDG + wc * 64 + tcol;
+    for (int ch = cbeg; ch < cend; ++ch) {
+      if (ch + 1 < cend) gload(ch + 1);
+      fill_tables(ch + 2);
+#pragma unroll
+      for (int kk = 0; kk < BP / 16; ++kk) {
+        bf16x8 fa[NS][2], fb[NS][2];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            const uint16_t* p = xbase + (s * BP + kk * 16) * LDX + mi * 32;
+            fa[s][mi] = tr_frag(p, p + 4 * LDX);
+          }
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const uint16_t* p = gbase + (s * BP + kk * 16) * LDG + ni * 32;
+            fb[s][ni] = tr_frag(p, p + 4 * LDG);
+          }
+        }
+#pragma unroll
+        for (int d = NS - 1; d >= 0; --d)
+#pragma unroll
+          for (int i = 0; i <= d; ++i)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][mi], fb[d - i][ni], acc[mi][ni], 0, 0, 0);
+      }
+      __syncthreads();
+      if (ch + 1 < cend) { lstore(); __syncthreads(); }
+    }
+  }
+  const size_t rows_total = (size_t)rows_all;
+  float* dst = a.slab + ((size_t)split * rows_total + R0) * a.Cout + o0;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int col = wc * 64 + ni * 32 + li;
+        if (R0 + row < rows_all) dst[(size_t)row * a.Cout + col] = acc[mi][ni][r];
+      }
+}
+
+// grad[tap][c][o] = sum over splits (fixed order) of slab[split][tap][c (of cin_pad)][o], c < cin_real
+__global__ void wgrad_split_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, int nsplit, int taps,
+                                          int cin_pad, int cin_real, int cout) {
+  const int n = taps * cin_real * cout;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int o = i % cout;
+    const int rc = i / cout;
+    const int c = rc % cin_real, tap = rc / cin_real;
+    const size_t src = ((size_t)tap * cin_pad + c) * cout + o;
+    const size_t stride = (size_t)taps * cin_pad * cout;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slab[k * stride + src];
+    grad[i] = s;
+  }
+}
+
+template <int TR, int TO, int NS>
+int launch_wgrad_split(const SplitWgradArgs& a, int nsplit, hipStream_t st) {
+  DRS_LAUNCH((wgrad_split_kernel<TR, TO, NS>), dim3(nsplit * a.ntr * a.nto), dim3((TR / 64) * (TO / 64) * 64), 0, st, a);
+  return DRS_LAUNCH_CHECK();
+}
+
+int split_wgrad_rows(int rows) {
+  const int n128 = (rows + 127) / 128;
+  return (double)rows / (n128 * 128.0) >= 0.85 ? 128 : 64;
+}
+
+inline int grid_for(size_t n) { return (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096); }
+
+}  // namespace
+
+extern "C" {
+
+int drs_split_conv_mtile(int cout) { return cout % 128 == 0 ? 128 : 256; }
+
+int drs_split_planes(const float* src, size_t n, int nsplit, unsigned short* planes, size_t plane_stride, void* stream) {
+  if (!src || !planes || (n & 7) || (plane_stride & 7) || plane_stride < n || (nsplit != 2 && nsplit != 3)) return DRS_ERR_ARG;
+  if (n == 0) return DRS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (nsplit == 2) DRS_LAUNCH(split_planes_kernel<2>, dim3(grid_for(n / 8)), dim3(256), 0, st, src, planes, n / 8, plane_stride);
+  else DRS_LAUNCH(split_planes_kernel<3>, dim3(grid_for(n / 8)), dim3(256), 0, st, src, planes, n / 8, plane_stride);
+  return DRS_LAUNCH_CHECK();
+}
+
+int drs_filter_split(const float* w, int k, int cin, int cin_pad, int cout, int nsplit, unsigned short* wf,
+                     unsigned short* wd, void* stream) {
+  if (!w || !wf || cin_pad < cin || cin_pad % 32 || cout % 32 || (nsplit != 2 && nsplit != 3)) return DRS_ERR_ARG;
+  if (wd && cin % 32) return DRS_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n = (size_t)k * k * cout * (cin_pad + (wd ? cin : 0));
+  if (nsplit == 2) DRS_LAUNCH(filter_split_kernel<2>, dim3(grid_for(n)), dim3(256), 0, st, w, k * k, cin, cin_pad, cout, wf, wd);
+  else DRS_LAUNCH(filter_split_kernel<3>, dim3(grid_for(n)), dim3(256), 0, st, w, k * k, cin, cin_pad, cout, wf, wd);
+  return DRS_LAUNCH_CHECK();
+}
+
+int drs_conv_forward_split(const unsigned short* in, size_t in_plane_stride, int B, int S, int P, int ld_in, int coff_in,
+                           const unsigned short* w, size_t w_plane_stride, const float* bias, int k, int rate,
+                           int pad_before, int cin, int cout, float* out, int ld_out, int coff_out, int accumulate,
+                           float* stats_partial, int nsplit, void* stream) {
+  if (!in || !w || !out || cin % 32 || cout % 64 || k < 1 || rate < 1 || P < pad_before) return DRS_ERR_ARG;
+  if (P < (k - 1) * rate - pad_before || (ld_in & 7) || (coff_in & 7) || (nsplit != 2 && nsplit != 3)) return DRS_ERR_ARG;
+  const long long M = (long long)B * S * S;
+  if (M <= 0 || M >= (1 << 24)) return DRS_ERR_ARG;
+  SplitConvArgs a;
+  a.in = in; a.in_stride = in_plane_stride; a.S = S; a.P = P; a.ld_in = ld_in; a.coff_in = coff_in; a.M = (int)M;
+  a.w = w; a.w_stride = w_plane_stride; a.bias = bias; a.out = out; a.ld_out = ld_out; a.coff_out = coff_out;
+  a.stats = stats_partial; a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout; a.accumulate = accumulate;
+  a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
+  hipStream_t st = (hipStream_t)stream;
+  return nsplit == 2 ? dispatch_split<2>(a, st) : dispatch_split<3>(a, st);
+}
+
+int drs_conv_wgrad_split_splits(int B, int S, int k, int cin, int cout) {
+  const long long M = (long long)B * S * S;
+  const int tr = split_wgrad_rows(k * k * cin), to = cout % 128 == 0 ? 128 : 64;
+  const int ntile = ((k * k * cin + tr - 1) / tr) * (cout / to);
+  const int nchunks = (int)((M + 31) / 32);
+  int want = 1536 / ntile;
+  int maxs = (nchunks + 31) / 32;
+  if (maxs < 1) maxs = 1;
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  const int cps = (nchunks + want - 1) / want;
+  return (nchunks + cps - 1) / cps;
+}
+
+int drs_conv_wgrad_split(const unsigned short* x, size_t x_plane_stride, int B, int S, int Px, int ld_x, int coff_x,
+                         const unsigned short* g, size_t g_plane_stride, int Pg, int ld_g, int coff_g, int k, int rate,
+                         int pad_before, int cin, int cin_real, int cout, float* slab, float* grad, int nsplit_terms,
+                         void* stream) {
+  if (!x || !g || !slab || !grad || cin % 32 || cout % 64 || cin_real > cin) return DRS_ERR_ARG;
+  if ((ld_x & 7) || (coff_x & 7) || (ld_g & 7) || (coff_g & 7) || (nsplit_terms != 2 && nsplit_terms != 3)) return DRS_ERR_ARG;
+  const long long M = (long long)B * S * S;
+  if (M <= 0 || M >= (1 << 24)) return DRS_ERR_ARG;
+  SplitWgradArgs a;
+  a.x = x; a.x_stride = x_plane_stride; a.S = S; a.Px = Px; a.ld_x = ld_x; a.coff_x = coff_x;
+  a.g = g; a.g_stride = g_plane_stride; a.Pg = Pg; a.ld_g = ld_g; a.coff_g = coff_g; a.M = (int)M;
+  a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout; a.slab = slab;
+  const int tr = split_wgrad_rows(k * k * cin), to = cout % 128 == 0 ? 128 : 64;
+  a.ntr = (k * k * cin + tr - 1) / tr; a.nto = cout / to;
+  const int nsplit = drs_conv_wgrad_split_splits(B, S, k, cin, cout);
+  const int nchunks = (int)((M + 31) / 32);
+  a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
+  a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (nsplit_terms == 2) {
+    if (tr == 128 && to == 128) rc = launch_wgrad_split<128, 128, 2>(a, nsplit, st);
+    else if (tr == 128) rc = launch_wgrad_split<128, 64, 2>(a, nsplit, st);
+    else if (to == 128) rc = launch_wgrad_split<64, 128, 2>(a, nsplit, st);
+    else rc = launch_wgrad_split<64, 64, 2>(a, nsplit, st);
+  } else {
+    if (tr == 128 && to == 128) rc = launch_wgrad_split<128, 128, 3>(a, nsplit, st);
+    else if (tr == 128) rc = launch_wgrad_split<128, 64, 3>(a, nsplit, st);
+    else if (to == 128) rc = launch_wgrad_split<64, 128, 3>(a, nsplit, st);
+    else rc = launch_wgrad_split<64, 64, 3>(a, nsplit, st);
+  }
+  if (rc) return rc;
+  const int n = k * k * cin_real * cout;
+  DRS_LAUNCH(wgrad_split_reduce_kernel, dim3((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), dim3(256), 0, st, slab, grad,
+             nsplit, k * k, cin, cin_real, cout);
+  return DRS_LAUNCH_CHECK();
+}
+
+}  // extern "C"

@@ -1,0 +1,158 @@
+"""-m gpu: the split-bf16 arithmetic of the convolution (csrc/conv_split.hip: fp32 operands as 2 or 3 bf16 terms,
+3 or 6 partial products on the bf16 MFMA pipe, fp32 accumulation) against the fp64 CPU oracle on the same seeded
+inputs, through the C ABI.  Tolerances, relative to the tensor's max magnitude: 3 terms ("bf16x6") 1e-5, the bound
+the exact-fp32 kernels are held to in test_gpu_ops.py, for both term counts (BASELINE north_star: logits
+within 1e-3 relative end to end)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tf_ops as T
+from oracle import nets as onets
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, dev, padded, rel_err, stream   # noqa: E402
+
+TOL = {2: 1e-5, 3: 1e-5}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from drs_amd import _lib
+    assert torch.cuda.is_available()
+    _lib.load()
+    return _lib
+
+
+def split_host(x, ns):
+    """numpy restatement of the term split: term s = bf16_rne(x - earlier terms); returns float32 terms."""
+    r = x.astype(np.float32).copy()
+    out = []
+    for _ in range(ns):
+        t = torch.from_numpy(r).to(torch.bfloat16).to(torch.float32).numpy()
+        out.append(t)
+        r = r - t
+    return out
+
+
+def planes(lib, t, ns):
+    n = t.numel()
+    assert n % 8 == 0
+    p = torch.zeros(ns * n, dtype=torch.int16, device=DEV)
+    lib.call("drs_split_planes", t.data_ptr(), n, ns, p.data_ptr(), n, stream())
+    return p, n
+
+
+@pytest.mark.parametrize("ns", [2, 3])
+def test_split_planes_terms(lib, ns):
+    rng = np.random.default_rng(ns)
+    x = (rng.normal(size=4096) * np.exp(rng.normal(size=4096) * 4)).astype(np.float32)
+    x[:8] = [0.0, -0.0, 1.0, -1.0, 1e-30, 3.0e38, 1.0 + 2.0 ** -9, 2.0 ** -126]
+    p, n = planes(lib, dev(x), ns)
+    torch.cuda.synchronize()
+    got = p.view(torch.bfloat16).to(torch.float32).cpu().numpy().reshape(ns, n)
+    want = split_host(x, ns)
+    for s in range(ns):
+        assert np.array_equal(got[s], want[s]), s
+    resid = np.abs(x.astype(np.float64) - got.astype(np.float64).sum(axis=0))
+    bound = np.abs(x.astype(np.float64)) * 2.0 ** (-8 * ns - 1) + 1e-40
+    assert np.all(resid <= bound)
+
+
+# (k, rate, cin, cout, B, S): every (k, rate) of the BASELINE nets, both tile shapes, ragged wgrad row tiles
+CASES = [
+    (5, 1, 32, 64, 3, 9), (5, 2, 64, 64, 2, 12), (4, 3, 64, 128, 2, 11), (4, 4, 128, 128, 2, 10),
+    (3, 5, 128, 192, 2, 13), (3, 6, 192, 192, 1, 15), (3, 7, 192, 256, 1, 16), (3, 8, 256, 256, 2, 17),
+    (4, 2, 64, 128, 2, 8), (3, 4, 128, 256, 1, 9), (3, 6, 320, 128, 1, 14), (4, 4, 128, 64, 1, 12), (3, 5, 32, 64, 1, 25),
+]
+
+
+@pytest.mark.parametrize("ns", [2, 3])
+@pytest.mark.parametrize("k,rate,cin,cout,B,S", CASES)
+def test_conv_split_forward_dgrad_wgrad(lib, k, rate, cin, cout, B, S, ns):
+    rng = np.random.default_rng(k * 1000 + rate * 100 + cin + cout + S)
+    x = rng.normal(size=(B, S, S, cin)).astype(np.float32)
+    w = (rng.normal(size=(k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    bias = rng.normal(size=(cout,)).astype(np.float32)
+    g = rng.normal(size=(B, S, S, cout)).astype(np.float32)
+    pb, pa = onets.same_pad(k, rate)
+    P = max(pb, pa) + 1
+    M = B * S * S
+    tol = TOL[ns]
+    xd = padded(x, P, ld=cin + 32, coff=32, fill=7.0)
+    xp, nx = planes(lib, xd, ns)
+    wd, bd = dev(w), dev(bias)
+    nw = k * k * cin * cout
+    wf = torch.zeros(ns * nw, dtype=torch.int16, device=DEV)
+    wg = torch.zeros(ns * nw, dtype=torch.int16, device=DEV)
+    lib.call("drs_filter_split", wd.data_ptr(), k, cin, cin, cout, ns, wf.data_ptr(), wg.data_ptr(), stream())
+    out = torch.full((M, cout + 32), -3.0, dtype=torch.float32, device=DEV)
+    mt = lib.query("drs_split_conv_mtile", cout)
+    rows = (M + mt - 1) // mt
+    stats = torch.zeros(rows * cout * 2, dtype=torch.float32, device=DEV)
+    lib.call("drs_conv_forward_split", xp.data_ptr(), nx, B, S, P, cin + 32, 32, wf.data_ptr(), nw, bd.data_ptr(), k, rate, pb,
+             cin, cout, out.data_ptr(), cout + 32, 32, 0, stats.data_ptr(), ns, stream())
+    torch.cuda.synchronize()
+    x64, w64 = x.astype(np.float64), w.astype(np.float64)
+    ref = T.conv2d_same(x64, w64, rate) + bias.astype(np.float64)
+    got = out.cpu().numpy()
+    e_fwd = rel_err(got[:, 32:].reshape(B, S, S, cout), ref)
+    assert e_fwd < tol
+    assert np.all(got[:, :32] == -3.0)
+    st = stats.cpu().numpy().reshape(rows, cout, 2).astype(np.float64).sum(axis=0)
+    r2 = ref.reshape(-1, cout)
+    assert np.abs(st[:, 0] - r2.sum(axis=0)).max() < tol * np.abs(r2).sum(axis=0).max()
+    assert rel_err(st[:, 1], (r2 ** 2).sum(axis=0)) < tol
+    lib.call("drs_conv_forward_split", xp.data_ptr(), nx, B, S, P, cin + 32, 32, wf.data_ptr(), nw, None, k, rate, pb,
+             cin, cout, out.data_ptr(), cout + 32, 32, 1, None, ns, stream())
+    torch.cuda.synchronize()
+    ref2 = ref + T.conv2d_same(x64, w64, rate)
+    assert rel_err(out.cpu().numpy()[:, 32:].reshape(B, S, S, cout), ref2) < tol
+
+    gx_ref, gw_ref = T.conv2d_same_bwd(x64, w64, rate, g.astype(np.float64))
+    gd = padded(g, P, ld=cout, coff=0)
+    gp, ng = planes(lib, gd, ns)
+    gx = torch.zeros(M * cin, dtype=torch.float32, device=DEV)
+    if cin % 64 == 0:       # the input-gradient GEMM has N = cin; narrower layers stay on the exact-fp32 kernel
+        lib.call("drs_conv_forward_split", gp.data_ptr(), ng, B, S, P, cout, 0, wg.data_ptr(), nw, None, k, rate, pa, cout, cin,
+                 gx.data_ptr(), cin, 0, 0, None, ns, stream())
+    nsplit = lib.query("drs_conv_wgrad_split_splits", B, S, k, cin, cout)
+    slab = torch.zeros(nsplit * nw, dtype=torch.float32, device=DEV)
+    gw = torch.zeros(nw, dtype=torch.float32, device=DEV)
+    lib.call("drs_conv_wgrad_split", xp.data_ptr(), nx, B, S, P, cin + 32, 32, gp.data_ptr(), ng, P, cout, 0, k, rate, pb, cin,
+             cin, cout, slab.data_ptr(), gw.data_ptr(), ns, stream())
+    torch.cuda.synchronize()
+    e_dg = rel_err(gx.cpu().numpy().reshape(B, S, S, cin), gx_ref) if cin % 64 == 0 else 0.0
+    e_wg = rel_err(gw.cpu().numpy().reshape(k, k, cin, cout), gw_ref)
+    print("k%d r%d %3d->%3d terms %d: fwd %.2e dgrad %.2e wgrad %.2e" % (k, rate, cin, cout, ns, e_fwd, e_dg, e_wg))
+    assert e_dg < tol
+    assert e_wg < tol
+
+
+@pytest.mark.parametrize("ns", [2, 3])
+def test_conv1_band_padding_split(lib, ns):
+    """3..5 image bands ride the 32-channel K-step: the padded filter columns are zero, wgrad drops them again."""
+    rng = np.random.default_rng(5)
+    B, S, C, cout, k = 2, 11, 5, 64, 5
+    x = rng.normal(size=(B, S, S, C)).astype(np.float32)
+    w = rng.normal(size=(k, k, C, cout)).astype(np.float32) * 0.1
+    g = rng.normal(size=(B, S, S, cout)).astype(np.float32)
+    xp, nx = planes(lib, padded(x, 2, ld=32, coff=0), ns)
+    nwp = k * k * 32 * cout
+    wf = torch.zeros(ns * nwp, dtype=torch.int16, device=DEV)
+    lib.call("drs_filter_split", dev(w).data_ptr(), k, C, 32, cout, ns, wf.data_ptr(), None, stream())
+    out = torch.zeros(B * S * S * cout, dtype=torch.float32, device=DEV)
+    lib.call("drs_conv_forward_split", xp.data_ptr(), nx, B, S, 2, 32, 0, wf.data_ptr(), nwp, None, k, 1, 2, 32, cout,
+             out.data_ptr(), cout, 0, 0, None, ns, stream())
+    gp, ng = planes(lib, padded(g, 2), ns)
+    nsplit = lib.query("drs_conv_wgrad_split_splits", B, S, k, 32, cout)
+    slab = torch.zeros(nsplit * nwp, dtype=torch.float32, device=DEV)
+    gw = torch.zeros(k * k * C * cout, dtype=torch.float32, device=DEV)
+    lib.call("drs_conv_wgrad_split", xp.data_ptr(), nx, B, S, 2, 32, 0, gp.data_ptr(), ng, 2, cout, 0, k, 1, 2, 32, C, cout,
+             slab.data_ptr(), gw.data_ptr(), ns, stream())
+    torch.cuda.synchronize()
+    ref = T.conv2d_same(x.astype(np.float64), w.astype(np.float64), 1)
+    _, gw_ref = T.conv2d_same_bwd(x.astype(np.float64), w.astype(np.float64), 1, g.astype(np.float64))
+    assert rel_err(out.cpu().numpy().reshape(B, S, S, cout), ref) < TOL[ns]
+    assert rel_err(gw.cpu().numpy().reshape(k, k, C, cout), gw_ref) < TOL[ns]

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Per-layer accuracy and timing of the split-bf16 conv kernels against the exact-fp32 MFMA kernels
+(development aid; Dilated8Pooling shapes, HIP events, median of interleaved repetitions)."""
+import os
+import sys
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from drs_amd import _lib  # noqa: E402
+from drs_amd.nets import Plan  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def timeit(fn, reps=7):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts))
+
+
+def main(B=128, S=64, net="dilated_grsl_rate8", layers=None):
+    _lib.load()
+    plan = Plan(net, 5, 6)
+    st = torch.cuda.current_stream(DEV).cuda_stream
+    M = B * S * S
+    tot = {}
+    for i, L in enumerate(plan.layers):
+        if layers and str(i + 1) not in layers.split(","):
+            continue
+        P = L.halo
+        n = B * (S + 2 * P) ** 2 * L.cin_k
+        x = torch.randn(n, device=DEV)
+        w = torch.randn(L.k * L.k * L.cin_k * L.cout, device=DEV) * 0.05
+        bias = torch.zeros(L.cout, device=DEV)
+        z = torch.zeros(M * L.cout, device=DEV)
+        fl = 2.0 * M * L.k * L.k * L.cin_k * L.cout
+        row = "%-6s k%d r%d %3d->%3d " % (L.name, L.k, L.rate, L.cin_k, L.cout)
+        ms = timeit(lambda: _lib.call("drs_conv_forward", x.data_ptr(), B, S, P, L.cin_k, 0, w.data_ptr(), bias.data_ptr(), L.k, L.rate,
+                                      L.pad_b, L.cin_k, L.cout, z.data_ptr(), L.cout, 0, 0, None, st))
+        row += " f32 %6.3f ms %6.1f TF |" % (ms, fl / ms / 1e9)
+        tot["f32"] = tot.get("f32", 0) + ms
+        zref = z.clone()
+        # fp64 reference on a sample of output rows would need the oracle; compare against the exact-fp32 kernel instead
+        for ns in (2, 3):
+            xp = torch.zeros(ns * n, dtype=torch.int16, device=DEV)
+            wf = torch.zeros(ns * w.numel(), dtype=torch.int16, device=DEV)
+            ms_s = timeit(lambda: _lib.call("drs_split_planes", x.data_ptr(), n, ns, xp.data_ptr(), n, st))
+            _lib.call("drs_filter_split", w.data_ptr(), L.k, L.cin_k, L.cin_k, L.cout, ns, wf.data_ptr(), None, st)
+            z2 = torch.zeros(M * L.cout, device=DEV)
+            ms = timeit(lambda: _lib.call("drs_conv_forward_split", xp.data_ptr(), n, B, S, P, L.cin_k, 0, wf.data_ptr(), w.numel(),
+                                          bias.data_ptr(), L.k, L.rate, L.pad_b, L.cin_k, L.cout, z2.data_ptr(), L.cout, 0, 0, None, ns, st))
+            err = float((z2 - zref).abs().max() / zref.abs().max())
+            row += " x%d %6.3f ms %6.1f TF (split %5.3f ms) err %.1e |" % (3 if ns == 2 else 6, ms, fl / ms / 1e9, ms_s, err)
+            tot["x%d" % ns] = tot.get("x%d" % ns, 0) + ms
+            tot["split%d" % ns] = tot.get("split%d" % ns, 0) + ms_s
+        print(row, flush=True)
+    print("total ms:", {k: round(v, 2) for k, v in tot.items()})
+
+
+if __name__ == "__main__":
+    kw = dict(a.split("=") for a in sys.argv[1:])
+    main(int(kw.get("B", 128)), int(kw.get("S", 64)), kw.get("net", "dilated_grsl_rate8"), kw.get("layers"))
