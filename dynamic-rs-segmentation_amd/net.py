@@ -21,6 +21,9 @@ import torch
 from . import _lib
 from .nets import Plan
 
+# arithmetic of the convolution kernels: exact fp32 MFMA (default), or fp32 operands carried as 2 / 3 bf16 terms with
+# 3 / 6 partial products on the bf16 MFMA pipe (csrc/conv_split.hip); value = number of terms
+ARITH_TERMS = {"f32": 0, "bf16x3": 2, "bf16x6": 3}
 BN_DECAY = 0.999        # tf.contrib.layers.batch_norm default (isprs:658)
 MOMENTUM = 0.9          # isprs:1687
 LR_DECAY_STEPS = 50000  # isprs:1686
@@ -70,8 +73,11 @@ class NoComm(object):
 
 class DilatedNet(object):
     def __init__(self, net_type, channels, num_classes, weight_decay, b_max, s_max, device="cuda:0", seed=42,
-                 comm=None, bessel_moving_var=True, lr_decay_factor=0.5):
+                 comm=None, bessel_moving_var=True, lr_decay_factor=0.5, arith="f32"):
         _lib.load()                       # fail loudly here if the HIP library is absent
+        if arith not in ARITH_TERMS:
+            raise ValueError("arith must be one of %s" % sorted(ARITH_TERMS))
+        self.arith, self.ns = arith, ARITH_TERMS[arith]
         self.plan = Plan(net_type, channels, num_classes)
         self.wd = float(weight_decay)
         self.b_max, self.s_max = int(b_max), int(s_max)
@@ -201,6 +207,20 @@ class DilatedNet(object):
         self.gz = torch.zeros(B * (S + 2 * hmax) ** 2 * cmax, **f32)
         slab = max(_lib.query("drs_conv_wgrad_splits", B, S, L.k, L.cin_k, L.cout) * L.k * L.k * L.cin_k * L.cout
                    for L in p.layers)
+        if self.ns:
+            # split-bf16 arithmetic: bf16 term planes of every conv input slab and of the haloed output gradient, and the
+            # filters in the K-contiguous split form (forward and input-gradient orientation)
+            i16 = dict(dtype=torch.int16, device=self.dev)
+            ns = self.ns
+            srcs = {L.src for i, L in enumerate(p.layers) if self._split_fwd(i)}
+            self.aplanes = {n: torch.zeros(ns * self.abuf[n].numel(), **i16) for n in srcs}
+            self.gzplanes = torch.zeros(ns * self.gz.numel(), **i16)
+            self.wf_planes = [torch.zeros(ns * L.k * L.k * L.cin_k * L.cout, **i16) if self._split_fwd(i) else None
+                       for i, L in enumerate(p.layers)]
+            self.wd_planes = [torch.zeros(ns * L.k * L.k * L.cin * L.cout, **i16) if self._split_dgrad(i) else None
+                       for i, L in enumerate(p.layers)]
+            slab = max([slab] + [_lib.query("drs_conv_wgrad_split_splits", B, S, L.k, L.cin_k, L.cout) * L.k * L.k * L.cin_k * L.cout
+                                 for i, L in enumerate(p.layers) if self._split_fwd(i)])
         self.slab = torch.zeros(slab, **f32)
         self.w0pad = torch.zeros(L0.k * L0.k * L0.cin_k * L0.cout, **f32)
         self.wt = [None] + [torch.zeros(L.k * L.k * L.cin * L.cout, **f32) for L in p.layers[1:]]
@@ -224,6 +244,24 @@ class DilatedNet(object):
                 if isinstance(t, torch.Tensor):
                     tot += t.numel() * t.element_size()
         return tot
+
+    # ------------------------------------------------------------------ split-bf16 arithmetic
+    def _split_fwd(self, i):
+        """conv block i runs its forward and filter-gradient passes on the split-bf16 kernels (tile shapes need Cout % 64)."""
+        return self.ns > 0 and self.plan.layers[i].cout % 64 == 0
+
+    def _split_dgrad(self, i):
+        """... and its input-gradient pass (a GEMM with N = Cin)."""
+        L = self.plan.layers[i]
+        return self._split_fwd(i) and L.src != "x0" and L.cin % 64 == 0
+
+    def _split_slab(self, name, B, S):
+        """bf16 term planes of the current contents of activation slab `name`."""
+        C, P = self.plan.buffers[name]
+        n = B * (S + 2 * P) ** 2 * C
+        t = self.abuf[name]
+        self._k("split", n * (4.0 + 2.0 * self.ns), "drs_split_planes", _ptr(t), n, self.ns, _ptr(self.aplanes[name]), t.numel(),
+                self._stream())
 
     # ------------------------------------------------------------------ views
     def _is_max(self, i):
@@ -280,11 +318,16 @@ class DilatedNet(object):
         return pack_feed(self, batch_x, batch_y, crop_size, mask, acc_mask)
 
     # ------------------------------------------------------------------ forward
-    def _prepare_weights(self, st):
+    def _prepare_weights(self, st, training):
         p = self.plan
         L0 = p.layers[0]
         off, _ = p.offsets[L0.name + "/weights"]
         _lib.call("drs_filter_pad_cin", self.params[off:].data_ptr(), _ptr(self.w0pad), L0.k, L0.cin, L0.cin_k, L0.cout, st)
+        for i, L in enumerate(p.layers):
+            if self._split_fwd(i):
+                off, _ = p.offsets[L.name + "/weights"]
+                _lib.call("drs_filter_split", self.params[off:].data_ptr(), L.k, L.cin, L.cin_k, L.cout, self.ns, _ptr(self.wf_planes[i]),
+                          _ptr(self.wd_planes[i]) if training else None, st)
 
     def _weight_ptr(self, i):
         if i == 0:
@@ -303,13 +346,19 @@ class DilatedNet(object):
     def _forward_layers(self, B, S, training, count):
         p, st = self.plan, self._stream()
         M = B * S * S
-        self._prepare_weights(st)
+        self._prepare_weights(st, training)
         for i, L in enumerate(p.layers):
             xin, Pin, ldin, cin_off = self._in_view(i)
             stats = self.partial if training else None
-            self._k("conv_fwd", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_forward", _ptr(xin), B, S, Pin, ldin, cin_off,
-                    self._weight_ptr(i), self._bias_ptr(L.name),
-                    L.k, L.rate, L.pad_b, L.cin_k, L.cout, _ptr(self.z[i]), L.cout, 0, 0, _ptr(stats), st)
+            if self._split_fwd(i):
+                self._split_slab(L.src, B, S)
+                self._k("conv_fwd", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_forward_split", _ptr(self.aplanes[L.src]),
+                        xin.numel(), B, S, Pin, ldin, cin_off, _ptr(self.wf_planes[i]), L.k * L.k * L.cin_k * L.cout, self._bias_ptr(L.name),
+                        L.k, L.rate, L.pad_b, L.cin_k, L.cout, _ptr(self.z[i]), L.cout, 0, 0, _ptr(stats), self.ns, st)
+            else:
+                self._k("conv_fwd", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_forward", _ptr(xin), B, S, Pin, ldin, cin_off,
+                        self._weight_ptr(i), self._bias_ptr(L.name),
+                        L.k, L.rate, L.pad_b, L.cin_k, L.cout, _ptr(self.z[i]), L.cout, 0, 0, _ptr(stats), st)
             bo = p.bn_offsets[L.name]
             mm, mv = self.bn[bo:bo + L.cout], self.bn[bo + L.cout:bo + 2 * L.cout]
             if training:
@@ -380,6 +429,8 @@ class DilatedNet(object):
         nL = len(p.layers)
         for i in range(1, nL):
             L = p.layers[i]
+            if self._split_dgrad(i):
+                continue            # the split path's input-gradient filter was written by drs_filter_split
             off, _ = p.offsets[L.name + "/weights"]
             _lib.call("drs_filter_flip_transpose", self.params[off:].data_ptr(), _ptr(self.wt[i]), L.k, L.cin, L.cout, st)
         # classifier + loss + gradient wrt the features
@@ -439,18 +490,31 @@ class DilatedNet(object):
                 self.debug["gz%d" % i] = self.gz[:B * (S + 2 * L.halo) ** 2 * L.cout].clone()
             xin, Pin, ldin, cin_off = self._in_view(i)
             goff, _ = p.offsets[L.name + "/weights"]
-            self._k("conv_wgrad", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_wgrad", _ptr(xin), B, S, Pin, ldin, cin_off,
-                    _ptr(self.gz), L.halo, L.cout, 0, L.k, L.rate, L.pad_b, L.cin_k, L.cin, L.cout, _ptr(self.slab),
-                    self.grads[goff:].data_ptr(), st)
+            if self._split_fwd(i):
+                ngz = B * (S + 2 * L.halo) ** 2 * L.cout
+                self._k("split", ngz * (4.0 + 2.0 * self.ns), "drs_split_planes", _ptr(self.gz), ngz, self.ns, _ptr(self.gzplanes),
+                        self.gz.numel(), st)
+                self._k("conv_wgrad", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_wgrad_split", _ptr(self.aplanes[L.src]),
+                        xin.numel(), B, S, Pin, ldin, cin_off, _ptr(self.gzplanes), self.gz.numel(), L.halo, L.cout, 0, L.k, L.rate,
+                        L.pad_b, L.cin_k, L.cin, L.cout, _ptr(self.slab), self.grads[goff:].data_ptr(), self.ns, st)
+            else:
+                self._k("conv_wgrad", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_wgrad", _ptr(xin), B, S, Pin, ldin, cin_off,
+                        _ptr(self.gz), L.halo, L.cout, 0, L.k, L.rate, L.pad_b, L.cin_k, L.cin, L.cout, _ptr(self.slab),
+                        self.grads[goff:].data_ptr(), st)
             if self.comm.world > 1 and i > 0 and (nL - i) % 2 == 0:                   # every second layer: one bucket
                 pending.append(self.comm.all_reduce_sum_async(self.grads[goff:bucket_hi]))
                 bucket_hi = goff
             if L.src != "x0":
                 acc = 1 if L.src in written else 0
                 written.add(L.src)
-                self._k("conv_dgrad", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_forward", _ptr(self.gz), B, S, L.halo, L.cout,
-                        0, _ptr(self.wt[i]), None, L.k, L.rate, L.pad_a, L.cout, L.cin, _ptr(self.gbuf[L.src]), p.buffers[L.src][0], 0,
-                        acc, None, st)
+                if self._split_dgrad(i):
+                    self._k("conv_dgrad", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_forward_split", _ptr(self.gzplanes),
+                            self.gz.numel(), B, S, L.halo, L.cout, 0, _ptr(self.wd_planes[i]), L.k * L.k * L.cin * L.cout, None, L.k, L.rate,
+                            L.pad_a, L.cout, L.cin, _ptr(self.gbuf[L.src]), p.buffers[L.src][0], 0, acc, None, self.ns, st)
+                else:
+                    self._k("conv_dgrad", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_forward", _ptr(self.gz), B, S, L.halo, L.cout,
+                            0, _ptr(self.wt[i]), None, L.k, L.rate, L.pad_a, L.cout, L.cin, _ptr(self.gbuf[L.src]), p.buffers[L.src][0], 0,
+                            acc, None, st)
         if self.comm.world > 1:
             pending.append(self.comm.all_reduce_sum_async(self.grads[0:bucket_hi]))      # the remaining (earliest) layers
             pending.append(self.comm.all_reduce_sum_async(self.grads[woff:]))            # classifier, SE layers and every bias (small)

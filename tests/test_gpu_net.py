@@ -23,7 +23,7 @@ CASES = [("dilated_icpr_original", 3, 6, 2, 25), ("dilated_grsl", 5, 6, 3, 19), 
          ("dilated_icpr_old", 3, 7, 2, 18), ("dilated_grsl_old", 3, 7, 1, 16)]
 
 
-def _mk(net, ch, K, B, S, seed):
+def _mk(net, ch, K, B, S, seed, arith="f32"):
     from drs_amd.net import DilatedNet
     rng = np.random.default_rng(seed)
     o = T.OracleNet(net, ch, K, dtype=np.float64, seed=seed)
@@ -33,7 +33,7 @@ def _mk(net, ch, K, B, S, seed):
             o.p[n] = (rng.normal(size=o.p[n].shape) * 0.1).astype(np.float32).astype(np.float64)
         if n.endswith("moving_variance"):
             o.p[n] = rng.uniform(0.5, 1.5, size=o.p[n].shape).astype(np.float32).astype(np.float64)
-    d = DilatedNet(net, ch, K, weight_decay=0.005, b_max=B, s_max=S, device=DEV)
+    d = DilatedNet(net, ch, K, weight_decay=0.005, b_max=B, s_max=S, device=DEV, arith=arith)
     for n in d.variable_names():
         d.set_variable(n, o.p[n])
     x = rng.normal(size=(B, S, S, ch)).astype(np.float32)
@@ -65,7 +65,18 @@ def _argmax_agrees(pred, logits64):
 
 @pytest.mark.parametrize("net,ch,K,B,S", CASES)
 def test_eval_and_train_parity(net, ch, K, B, S):
-    o, d, x, y = _mk(net, ch, K, B, S, 11)
+    _check_eval_and_train(net, ch, K, B, S, "f32")
+
+
+# the split-bf16 arithmetic of the convolutions (csrc/conv_split.hip) is held to the same bars as the exact-fp32 path
+@pytest.mark.parametrize("arith", ["bf16x3", "bf16x6"])
+@pytest.mark.parametrize("net,ch,K,B,S", CASES[:5] + [("dilated_icpr_rate6_squeeze", 3, 6, 2, 15), ("dilated_icpr_rate6_SE", 5, 2, 1, 21)])
+def test_eval_and_train_parity_split_arithmetic(net, ch, K, B, S, arith):
+    _check_eval_and_train(net, ch, K, B, S, arith)
+
+
+def _check_eval_and_train(net, ch, K, B, S, arith):
+    o, d, x, y = _mk(net, ch, K, B, S, 11, arith)
     d.feed(x.reshape(B, -1), y.reshape(B, -1), S)
     pred, logits = d.forward(B, S)
     ref = o.forward(x.astype(np.float64), False)
@@ -104,9 +115,10 @@ def test_eval_and_train_parity(net, ch, K, B, S):
     np.testing.assert_array_equal(out["conf"].cpu().numpy(), cm)
 
 
-def test_training_trajectory_matches_oracle():
+@pytest.mark.parametrize("arith", ["f32", "bf16x3", "bf16x6"])
+def test_training_trajectory_matches_oracle(arith):
     net, ch, K, B, S = "dilated8_grsl", 5, 6, 2, 17
-    o, d, _, _ = _mk(net, ch, K, B, S, 3)
+    o, d, _, _ = _mk(net, ch, K, B, S, 3, arith)
     rng = np.random.default_rng(9)
     for step in range(4):
         x = rng.normal(size=(B, S, S, ch)).astype(np.float32)
@@ -139,9 +151,10 @@ def test_masked_loss_contest_form():
         assert rel_err(d.get_gradient(name) + 0.005 * d.get_variable(name), g_ref[name]) < 1e-4, name
 
 
-def test_step_is_bitwise_reproducible():
+@pytest.mark.parametrize("arith", ["f32", "bf16x3"])
+def test_step_is_bitwise_reproducible(arith):
     net, ch, K, B, S = "dilated_grsl", 5, 6, 2, 23
-    _, d, x, y = _mk(net, ch, K, B, S, 5)
+    _, d, x, y = _mk(net, ch, K, B, S, 5, arith)
     outs = []
     for rep in range(2):
         d.feed(x.reshape(B, -1), y.reshape(B, -1), S)
