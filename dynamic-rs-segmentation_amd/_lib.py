@@ -18,19 +18,21 @@ SIGNATURES = {
     "drs_filter_flip_transpose": (_i, [_p, _p, _i, _i, _i, _p]),
     "drs_filter_pad_cin": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "drs_split_conv_mtile": (_i, [_i]),
-    "drs_split_planes": (_i, [_p, _sz, _i, _p, _sz, _p]),
+    "drs_split_terms": (_i, [_p, _sz, _i, _p, _p]),
     "drs_filter_split": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p]),
-    "drs_conv_forward_split": (_i, [_p, _sz, _i, _i, _i, _i, _i, _p, _sz, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _i, _p]),
+    "drs_conv_forward_split": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _i, _p]),
     "drs_conv_wgrad_split_splits": (_i, [_i, _i, _i, _i, _i]),
-    "drs_conv_wgrad_split": (_i, [_p, _sz, _i, _i, _i, _i, _i, _p, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p]),
+    "drs_conv_wgrad_split": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p]),
     "drs_colsum_scratch_doubles": (_i, [_i]),
     "drs_stats_reduce": (_i, [_p, _i, _i, _p, _p, _p]),
     "drs_bn_finish": (_i, [_p, _d, _i, _p, _p, _p, _d, _i, _p]),
     "drs_bn_eval_coeffs": (_i, [_p, _p, _i, _p, _p]),
     "drs_bn_act_pool_forward": (_i, [_p, _i, _i, _i, _p, _f, _i, _p, _i, _i, _i, _p, _p]),
+    "drs_bn_act_pool_forward_terms": (_i, [_p, _i, _i, _i, _p, _f, _i, _p, _i, _i, _i, _p, _p, _i, _p]),
     "drs_bn_backward_rows": (_i, [_i, _i, _i, _i]),
     "drs_bn_backward_reduce": (_i, [_p, _i, _i, _p, _p, _i, _i, _i, _p, _f, _i, _p, _p, _p]),
     "drs_bn_backward_apply": (_i, [_p, _p, _i, _i, _i, _p, _p, _d, _p, _i, _i, _i, _p]),
+    "drs_bn_backward_apply_terms": (_i, [_p, _p, _i, _i, _i, _p, _p, _d, _p, _i, _i, _i, _p, _i, _p]),
     "drs_avg_pool_forward": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _p]),
     "drs_avg_pool_backward": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "drs_se_forward": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),

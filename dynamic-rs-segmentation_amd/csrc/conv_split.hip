@@ -10,10 +10,13 @@
 // Each bf16 x bf16 product is exact in fp32, so with NS = 3 the only roundings left are those of the fp32
 // accumulation, as in the exact-fp32 kernel.  The fp32 path (conv_mfma.hip) stays the default arithmetic.
 //
-// Layouts: activation planes use the element indexing of the fp32 slab they were split from (padded NHWC view
-// (S, P, ld, coff)), 2 bytes per element, `plane_stride` elements between planes.  Filters are split into the
-// K-contiguous form the MFMA B operand wants: forward [NS][Cout][k*k*Cin], input gradient [NS][Cin][k*k*Cout] (taps
-// reversed), so both operands of the implicit GEMM are rows of 16-byte K-chunks.
+// Layouts: the terms of a slab are interleaved at 32-channel granularity: fp32 element e (the padded NHWC indexing of
+// the slab the terms were split from: view (S, P, ld, coff), ld and coff multiples of 32) has its term s at
+// (e & ~31) * NS + 32 * s + (e & 31).  The NS 64-byte pieces one K-step needs of a pixel are then one contiguous
+// 64*NS-byte run = whole 128-byte cache lines, instead of NS half-used lines in NS separate planes.  Filters are split
+// into the K-contiguous form the MFMA B operand wants, interleaved the same way: forward [Cout][k*k*Cin/32][NS][32],
+// input gradient [Cin][k*k*Cout/32][NS][32] (taps reversed), so both operands of the implicit GEMM are rows of 16-byte
+// K-chunks.
 #include "drs_common.hpp"
 
 namespace {
@@ -39,9 +42,9 @@ __device__ __forceinline__ void split_terms(float x, uint32_t (&t)[NS]) {
 }
 
 // ------------------------------------------------------------------------------------------------ splitting
-// planes[s][i] = term s of src[i], i < n (n a multiple of 8; slabs are)
+// term s of src[e] -> dst[(e & ~31) * NS + 32 s + (e & 31)], e < n (n a multiple of 32; slabs are)
 template <int NS>
-__global__ void split_planes_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n8, size_t plane_stride) {
+__global__ void split_planes_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n8) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
     const f32x4 a = reinterpret_cast<const f32x4*>(src)[2 * i];
     const f32x4 b = reinterpret_cast<const f32x4*>(src)[2 * i + 1];
@@ -53,13 +56,14 @@ __global__ void split_planes_kernel(const float* __restrict__ src, uint16_t* __r
       u32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = t[2 * e][s] | (t[2 * e + 1][s] << 16);
-      *reinterpret_cast<u32x4*>(dst + s * plane_stride + 8 * i) = o;
+      *reinterpret_cast<u32x4*>(dst + ((i >> 2) * NS + s) * 32 + (i & 3) * 8) = o;
     }
   }
 }
 
-// forward filter planes:  wf[s][o][tap*cin_pad + c] = term s of (c < cin ? w[tap][c][o] : 0)
-// gradient filter planes: wd[s][c][(taps-1-tap)*cout + o] = term s of w[tap][c][o]        (c < cin)
+// forward filter:  row o, K index kf = tap*cin_pad + c          holds (c < cin ? w[tap][c][o] : 0)
+// gradient filter: row c, K index kd = (taps-1-tap)*cout + o    holds w[tap][c][o]        (c < cin)
+// term s of K index kk of a row of length Ktot sits at row*Ktot*NS + (kk & ~31)*NS + 32 s + (kk & 31)
 template <int NS>
 __global__ void filter_split_kernel(const float* __restrict__ w, int taps, int cin, int cin_pad, int cout,
                                     uint16_t* __restrict__ wf, uint16_t* __restrict__ wd) {
@@ -68,27 +72,24 @@ __global__ void filter_split_kernel(const float* __restrict__ w, int taps, int c
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nf + nd; i += gridDim.x * blockDim.x) {
     float v;
     uint16_t* dst;
-    size_t stride;
     if (i < nf) {
       const int c = i % cin_pad;
       const int rest = i / cin_pad;
       const int tap = rest % taps, o = rest / taps;
       v = c < cin ? w[((size_t)tap * cin + c) * cout + o] : 0.f;
-      dst = wf + i;
-      stride = (size_t)nf;
+      dst = wf + (size_t)(i & ~31) * NS + (i & 31);
     } else {
       const int j = i - nf;
       const int o = j % cout;
       const int rest = j / cout;
       const int tapr = rest % taps, c = rest / taps;
       v = w[((size_t)(taps - 1 - tapr) * cin + c) * cout + o];
-      dst = wd + j;
-      stride = (size_t)nd;
+      dst = wd + (size_t)(j & ~31) * NS + (j & 31);
     }
     uint32_t t[NS];
     split_terms<NS>(v, t);
 #pragma unroll
-    for (int s = 0; s < NS; ++s) dst[s * stride] = (uint16_t)t[s];
+    for (int s = 0; s < NS; ++s) dst[32 * s] = (uint16_t)t[s];
   }
 }
 
@@ -97,9 +98,9 @@ constexpr int BK = 32;          // channels per K-step (one filter tap x 32 chan
 constexpr int LDR = BK + 8;     // LDS row stride in bf16 elements: 80 B -> 16 consecutive rows hit 16 distinct 16-B slots
 
 struct SplitConvArgs {
-  const uint16_t* in; size_t in_stride; int S, P, ld_in, coff_in;
+  const uint16_t* in; int S, P, ld_in, coff_in;
   int M;
-  const uint16_t* w; size_t w_stride;   // [NS][Cout][k*k*Cin]
+  const uint16_t* w;                    // [Cout][k*k*Cin/32][NS][32]
   const float* bias;
   float* out; int ld_out, coff_out;
   float* stats;
@@ -138,11 +139,11 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const SplitConvArgs a) 
   for (int i = 0; i < NA; ++i) {
     int p = m0 + lrow + 64 * i;
     p = p < a.M ? p : a.M - 1;
-    offA[i] = padded_pixel_off(p, a.S, a.P, a.ld_in, a.rcpS, a.rcpSS, -a.pad, -a.pad) + (uint32_t)(a.coff_in + lchk);
+    offA[i] = NS * (padded_pixel_off(p, a.S, a.P, a.ld_in, a.rcpS, a.rcpSS, -a.pad, -a.pad) + (uint32_t)a.coff_in) + (uint32_t)lchk;
   }
   uint32_t offB[NB];
 #pragma unroll
-  for (int i = 0; i < NB; ++i) offB[i] = (uint32_t)((n0 + lrow + 64 * i) * Ktot + lchk);
+  for (int i = 0; i < NB; ++i) offB[i] = (uint32_t)(NS * (n0 + lrow + 64 * i) * Ktot + lchk);
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -158,13 +159,13 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const SplitConvArgs a) 
   int lu = 0, lv = 0, lc = 0;
 
   auto gload = [&](int ks) {
-    const uint32_t soff = (uint32_t)((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK);
+    const uint32_t soff = (uint32_t)(NS * ((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK));
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
 #pragma unroll
-      for (int i = 0; i < NA; ++i) ra[s][i] = *reinterpret_cast<const u32x4*>(a.in + s * a.in_stride + offA[i] + soff);
+      for (int i = 0; i < NA; ++i) ra[s][i] = *reinterpret_cast<const u32x4*>(a.in + offA[i] + soff + 32 * s);
 #pragma unroll
-      for (int i = 0; i < NB; ++i) rb[s][i] = *reinterpret_cast<const u32x4*>(a.w + s * a.w_stride + offB[i] + ks * BK);
+      for (int i = 0; i < NB; ++i) rb[s][i] = *reinterpret_cast<const u32x4*>(a.w + offB[i] + NS * ks * BK + 32 * s);
     }
     if (++lc == cpt) { lc = 0; if (++lv == a.k) { lv = 0; ++lu; } }
   };
@@ -259,10 +260,175 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const SplitConvArgs a) 
   }
 }
 
+// ---- the same GEMM with the tiles brought in by LDS-DMA (global_load_lds_dwordx4) into a double-buffered LDS image:
+// no staging registers, no ds_write pass, one barrier per K-step, the load of K-step ks+1 in flight during the MFMAs of
+// ks.  An LDS-DMA wave-instruction writes 64 lanes x 16 B to consecutive LDS bytes, so an image row is the bare 64 B of
+// one pixel's 32 channels (16 rows per instruction) and the bank spread comes from a swizzle instead of padding: the
+// 16-byte chunk c of row r sits in slot c ^ ((r >> 2) & 3); the DMA realises it by fetching, for LDS slot s, source
+// chunk s ^ ((r >> 2) & 3), and the fragment reads apply the same XOR.  16 consecutive rows at one k-chunk then cover
+// the 16 slots of the 256-byte bank row once.
+template <int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(256) void conv_split_dma_kernel(const SplitConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass has no LDS-DMA builtin; it only needs the launch stub
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int IA = BM / 64, IB = BN / 64;            // DMA instructions per wave per plane (16 rows each)
+  constexpr int ROWB = BK * 2;                         // bytes per image row (64)
+  constexpr int PLANE_A = BM * ROWB, PLANE_B = BN * ROWB;
+  constexpr int STAGE = NS * (PLANE_A + PLANE_B);
+
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int ntn = a.Cout / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / ntn) * BM;
+  const int n0 = (tile % ntn) * BN;
+
+  const int Sp = a.S + 2 * a.P;
+  const int Ktot = a.k * a.k * a.Cin;
+  // DMA lane roles: instruction j of a plane covers image rows 16 j .. 16 j + 15; lane l fills row 16 j + (l >> 2), slot l & 3
+  const int drow = lane >> 2;
+  const int dchk = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;           // source chunk (elements) for this lane's slot
+  uint32_t offA[IA], offB[IB];
+#pragma unroll
+  for (int i = 0; i < IA; ++i) {
+    int p = m0 + 16 * (wave + 4 * i) + drow;
+    p = p < a.M ? p : a.M - 1;
+    offA[i] = NS * (padded_pixel_off(p, a.S, a.P, a.ld_in, a.rcpS, a.rcpSS, -a.pad, -a.pad) + (uint32_t)a.coff_in) + (uint32_t)dchk;
+  }
+#pragma unroll
+  for (int i = 0; i < IB; ++i) offB[i] = (uint32_t)(NS * (n0 + 16 * (wave + 4 * i) + drow) * Ktot + dchk);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int cpt = a.Cin / BK;
+  const int nks = a.k * a.k * cpt;
+  int lu = 0, lv = 0, lc = 0;
+
+  auto issue = [&](int ks, int stage) {
+    const uint32_t soff = (uint32_t)(NS * ((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK));
+    unsigned char* sb = lds + stage * STAGE;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int i = 0; i < IA; ++i)
+        __builtin_amdgcn_global_load_lds(a.in + offA[i] + soff + 32 * s,
+                                         (__attribute__((address_space(3))) void*)(sb + s * PLANE_A + (wave + 4 * i) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < IB; ++i)
+        __builtin_amdgcn_global_load_lds(a.w + offB[i] + NS * ks * BK + 32 * s,
+                                         (__attribute__((address_space(3))) void*)(sb + NS * PLANE_A + s * PLANE_B + (wave + 4 * i) * 1024), 16, 0, 0);
+    }
+    if (++lc == cpt) { lc = 0; if (++lv == a.k) { lv = 0; ++lu; } }
+  };
+
+  // fragment read offsets (bytes inside a plane): row * 64 + (chunk ^ ((row >> 2) & 3)) * 16, chunk = 2 kk + h
+  const int sw = (li >> 2) & 3;
+  uint32_t ra[2], rb[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    ra[kk] = (uint32_t)((wm * WTM + li) * ROWB + (((2 * kk + h) ^ sw) * 16));
+    rb[kk] = (uint32_t)((wn * WTN + li) * ROWB + (((2 * kk + h) ^ sw) * 16));
+  }
+
+  issue(0, 0);
+  __syncthreads();
+  for (int ks = 0; ks < nks; ++ks) {
+    if (ks + 1 < nks) issue(ks + 1, (ks + 1) & 1);
+    const unsigned char* sa = lds + (ks & 1) * STAGE;
+    const unsigned char* sbb = sa + NS * PLANE_A;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      bf16x8 fa[NS][TM], fb[NS][TN];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+          fa[s][mi] = *reinterpret_cast<const bf16x8*>(sa + s * PLANE_A + mi * 32 * ROWB + ra[kk]);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+          fb[s][ni] = *reinterpret_cast<const bf16x8*>(sbb + s * PLANE_B + ni * 32 * ROWB + rb[kk]);
+      }
+#pragma unroll
+      for (int d = NS - 1; d >= 0; --d)
+#pragma unroll
+        for (int i = 0; i <= d; ++i)
+#pragma unroll
+          for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][mi], fb[d - i][ni], acc[mi][ni], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  float s1[TN], s2[TN];
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni) { s1[ni] = 0.f; s2[ni] = 0.f; }
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni) {
+    const int col = n0 + wn * WTN + ni * 32 + li;
+    const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < a.M) {
+          float v = acc[mi][ni][r] + bv;
+          float* dst = a.out + (size_t)row * a.ld_out + a.coff_out + col;
+          if (a.accumulate) v += *dst;
+          *dst = v;
+          s1[ni] += v;
+          s2[ni] += v * v;
+        }
+      }
+    }
+  }
+  if (a.stats) {
+    float* red = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      s1[ni] += __shfl_xor(s1[ni], 32);
+      s2[ni] += __shfl_xor(s2[ni], 32);
+      if (h == 0) {
+        const int c = wn * WTN + ni * 32 + li;
+        red[(wm * BN + c) * 2 + 0] = s1[ni];
+        red[(wm * BN + c) * 2 + 1] = s2[ni];
+      }
+    }
+    __syncthreads();
+    if (t < BN) {
+      float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { u1 += red[(w * BN + t) * 2]; u2 += red[(w * BN + t) * 2 + 1]; }
+      float* dst = a.stats + ((size_t)(m0 / BM) * a.Cout + n0 + t) * 2;
+      dst[0] = u1;
+      dst[1] = u2;
+    }
+  }
+#endif
+}
+
+int g_variant = 1;      // 0: register-staged tiles, 1: LDS-DMA double-buffered tiles (development switch, see drs_debug_variant)
+
 template <int BM, int BN, int WM, int WN, int NS>
 int launch_split(const SplitConvArgs& a, hipStream_t st) {
   const int mt = (a.M + BM - 1) / BM, nt = a.Cout / BN;
-  DRS_LAUNCH((conv_split_kernel<BM, BN, WM, WN, NS>), dim3(mt * nt), dim3(256), 0, st, a);
+  if (g_variant == 0) DRS_LAUNCH((conv_split_kernel<BM, BN, WM, WN, NS>), dim3(mt * nt), dim3(256), 0, st, a);
+  else DRS_LAUNCH((conv_split_dma_kernel<BM, BN, WM, WN, NS>), dim3(mt * nt), dim3(256), 0, st, a);
   return DRS_LAUNCH_CHECK();
 }
 
@@ -281,8 +447,8 @@ int dispatch_split(const SplitConvArgs& a, hipStream_t st) {
 // operand.  Row stride = tile width + 32 elements (64 B), so the 4 rows of a read fall on the four 64-byte quarters
 // of the 256-byte bank row: conflict-free.
 struct SplitWgradArgs {
-  const uint16_t* x; size_t x_stride; int S, Px, ld_x, coff_x;
-  const uint16_t* g; size_t g_stride; int Pg, ld_g, coff_g;
+  const uint16_t* x; int S, Px, ld_x, coff_x;
+  const uint16_t* g; int Pg, ld_g, coff_g;
   int M;
   int k, rate, pad, Cin, Cout;
   float* slab;
@@ -333,8 +499,10 @@ __global__ __launch_bounds__((TR / 64) * (TO / 64) * 64) void wgrad_split_kernel
   const int tap = (row_ok ? myR : 0) / a.Cin, c0 = (row_ok ? myR : 0) % a.Cin;
   const int u = tap / a.k, v = tap % a.k;
   const int Sxp = a.S + 2 * a.Px;
-  const uint32_t xconst = (uint32_t)((u * a.rate * Sxp + v * a.rate) * a.ld_x + a.coff_x + c0);
-  const uint32_t gconst = (uint32_t)(a.coff_g + o0 + (t % GQ) * 8);
+  // interleaved-term addressing: NS * (32-aligned fp32 element index) + 32 * term + (index & 31)
+  const uint32_t xconst = (uint32_t)(NS * ((u * a.rate * Sxp + v * a.rate) * a.ld_x + a.coff_x + (c0 & ~31)) + (c0 & 31));
+  const int og0 = o0 + (t % GQ) * 8;
+  const uint32_t gconst = (uint32_t)(NS * (a.coff_g + (og0 & ~31)) + (og0 & 31));
   const int xpix = t / XQ, gpix = t / GQ;
 
   f32x16 acc[2][2];
@@ -371,9 +539,9 @@ __global__ __launch_bounds__((TR / 64) * (TO / 64) * 64) void wgrad_split_kernel
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) rx[s][i] = *reinterpret_cast<const u32x4*>(a.x + s * a.x_stride + ox[i] + xconst);
+      for (int i = 0; i < NX; ++i) rx[s][i] = *reinterpret_cast<const u32x4*>(a.x + NS * ox[i] + xconst + 32 * s);
 #pragma unroll
-      for (int i = 0; i < NG; ++i) rg[s][i] = *reinterpret_cast<const u32x4*>(a.g + s * a.g_stride + (og[i] & 0x7fffffffu) + gconst);
+      for (int i = 0; i < NG; ++i) rg[s][i] = *reinterpret_cast<const u32x4*>(a.g + NS * (og[i] & 0x7fffffffu) + gconst + 32 * s);
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -490,14 +658,17 @@ inline int grid_for(size_t n) { return (int)((n + 255) / 256 < 4096 ? (n + 255) 
 
 extern "C" {
 
+/* development switch between kernel variants (not part of the documented ABI) */
+int drs_debug_variant(int v) { const int old = g_variant; if (v >= 0) g_variant = v; return old; }
+
 int drs_split_conv_mtile(int cout) { return cout % 128 == 0 ? 128 : 256; }
 
-int drs_split_planes(const float* src, size_t n, int nsplit, unsigned short* planes, size_t plane_stride, void* stream) {
-  if (!src || !planes || (n & 7) || (plane_stride & 7) || plane_stride < n || (nsplit != 2 && nsplit != 3)) return DRS_ERR_ARG;
+int drs_split_terms(const float* src, size_t n, int nterms, unsigned short* terms, void* stream) {
+  if (!src || !terms || (n & 31) || (nterms != 2 && nterms != 3)) return DRS_ERR_ARG;
   if (n == 0) return DRS_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (nsplit == 2) DRS_LAUNCH(split_planes_kernel<2>, dim3(grid_for(n / 8)), dim3(256), 0, st, src, planes, n / 8, plane_stride);
-  else DRS_LAUNCH(split_planes_kernel<3>, dim3(grid_for(n / 8)), dim3(256), 0, st, src, planes, n / 8, plane_stride);
+  if (nterms == 2) DRS_LAUNCH(split_planes_kernel<2>, dim3(grid_for(n / 8)), dim3(256), 0, st, src, terms, n / 8);
+  else DRS_LAUNCH(split_planes_kernel<3>, dim3(grid_for(n / 8)), dim3(256), 0, st, src, terms, n / 8);
   return DRS_LAUNCH_CHECK();
 }
 
@@ -512,17 +683,16 @@ int drs_filter_split(const float* w, int k, int cin, int cin_pad, int cout, int 
   return DRS_LAUNCH_CHECK();
 }
 
-int drs_conv_forward_split(const unsigned short* in, size_t in_plane_stride, int B, int S, int P, int ld_in, int coff_in,
-                           const unsigned short* w, size_t w_plane_stride, const float* bias, int k, int rate,
-                           int pad_before, int cin, int cout, float* out, int ld_out, int coff_out, int accumulate,
-                           float* stats_partial, int nsplit, void* stream) {
+int drs_conv_forward_split(const unsigned short* in, int B, int S, int P, int ld_in, int coff_in, const unsigned short* w,
+                           const float* bias, int k, int rate, int pad_before, int cin, int cout, float* out, int ld_out,
+                           int coff_out, int accumulate, float* stats_partial, int nsplit, void* stream) {
   if (!in || !w || !out || cin % 32 || cout % 64 || k < 1 || rate < 1 || P < pad_before) return DRS_ERR_ARG;
-  if (P < (k - 1) * rate - pad_before || (ld_in & 7) || (coff_in & 7) || (nsplit != 2 && nsplit != 3)) return DRS_ERR_ARG;
+  if (P < (k - 1) * rate - pad_before || (ld_in & 31) || (coff_in & 31) || (nsplit != 2 && nsplit != 3)) return DRS_ERR_ARG;
   const long long M = (long long)B * S * S;
   if (M <= 0 || M >= (1 << 24)) return DRS_ERR_ARG;
   SplitConvArgs a;
-  a.in = in; a.in_stride = in_plane_stride; a.S = S; a.P = P; a.ld_in = ld_in; a.coff_in = coff_in; a.M = (int)M;
-  a.w = w; a.w_stride = w_plane_stride; a.bias = bias; a.out = out; a.ld_out = ld_out; a.coff_out = coff_out;
+  a.in = in; a.S = S; a.P = P; a.ld_in = ld_in; a.coff_in = coff_in; a.M = (int)M;
+  a.w = w; a.bias = bias; a.out = out; a.ld_out = ld_out; a.coff_out = coff_out;
   a.stats = stats_partial; a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout; a.accumulate = accumulate;
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
   hipStream_t st = (hipStream_t)stream;
@@ -543,17 +713,16 @@ int drs_conv_wgrad_split_splits(int B, int S, int k, int cin, int cout) {
   return (nchunks + cps - 1) / cps;
 }
 
-int drs_conv_wgrad_split(const unsigned short* x, size_t x_plane_stride, int B, int S, int Px, int ld_x, int coff_x,
-                         const unsigned short* g, size_t g_plane_stride, int Pg, int ld_g, int coff_g, int k, int rate,
-                         int pad_before, int cin, int cin_real, int cout, float* slab, float* grad, int nsplit_terms,
-                         void* stream) {
+int drs_conv_wgrad_split(const unsigned short* x, int B, int S, int Px, int ld_x, int coff_x, const unsigned short* g,
+                         int Pg, int ld_g, int coff_g, int k, int rate, int pad_before, int cin, int cin_real, int cout,
+                         float* slab, float* grad, int nsplit_terms, void* stream) {
   if (!x || !g || !slab || !grad || cin % 32 || cout % 64 || cin_real > cin) return DRS_ERR_ARG;
-  if ((ld_x & 7) || (coff_x & 7) || (ld_g & 7) || (coff_g & 7) || (nsplit_terms != 2 && nsplit_terms != 3)) return DRS_ERR_ARG;
+  if ((ld_x & 31) || (coff_x & 31) || (ld_g & 31) || (coff_g & 31) || (nsplit_terms != 2 && nsplit_terms != 3)) return DRS_ERR_ARG;
   const long long M = (long long)B * S * S;
   if (M <= 0 || M >= (1 << 24)) return DRS_ERR_ARG;
   SplitWgradArgs a;
-  a.x = x; a.x_stride = x_plane_stride; a.S = S; a.Px = Px; a.ld_x = ld_x; a.coff_x = coff_x;
-  a.g = g; a.g_stride = g_plane_stride; a.Pg = Pg; a.ld_g = ld_g; a.coff_g = coff_g; a.M = (int)M;
+  a.x = x; a.S = S; a.Px = Px; a.ld_x = ld_x; a.coff_x = coff_x;
+  a.g = g; a.Pg = Pg; a.ld_g = ld_g; a.coff_g = coff_g; a.M = (int)M;
   a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout; a.slab = slab;
   const int tr = split_wgrad_rows(k * k * cin), to = cout % 128 == 0 ? 128 : 64;
   a.ntr = (k * k * cin + tr - 1) / tr; a.nto = cout / to;

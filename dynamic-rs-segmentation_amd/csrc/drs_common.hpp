@@ -14,12 +14,33 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // A view of a spatially padded NHWC activation slab [B][S+2P][S+2P][ld]; the slice starts at channel `coff`.
 // `base` addresses the padded element (b=0, y=-P, x=-P, ch=0).
 struct ActView {
-  float* base;
+  float* base;     // may be null when only the bf16 terms are wanted
   int S;     // patch side (interior)
   int P;     // halo width (zeros)
   int ld;    // floats per pixel
   int coff;  // first channel of the slice
+  uint16_t* terms; // or null: the split-bf16 image of the same slab (conv_split.hip), written alongside
+  int nt;          // terms per element (2 or 3)
 };
+
+// 4 consecutive channels (element offset e, a multiple of 4, in the slab's fp32 indexing) -> the fp32 slab and/or its
+// bf16 term image: term s of element e lives at (e & ~31) * nt + 32 s + (e & 31); term s = rne_bf16(x - earlier terms).
+__device__ __forceinline__ void view_store4(const ActView& v, size_t e, f32x4 x) {
+  if (v.base) *reinterpret_cast<f32x4*>(v.base + e) = x;
+  if (v.terms) {
+    uint16_t* t = v.terms + (e & ~(size_t)31) * v.nt + (e & 31);
+    f32x4 r = x;
+    for (int s = 0; s < v.nt; ++s) {
+      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+      bf16x4_t h;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) h[j] = (__bf16)r[j];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] -= (float)h[j];
+      *reinterpret_cast<bf16x4_t*>(t + 32 * s) = h;
+    }
+  }
+}
 
 // q = n / d, r = n % d for 0 <= n < 2^24 (exact in f32), d >= 1; rcp = 1.0f/d.
 __device__ __forceinline__ void divmod24(int n, int d, float rcp, int& q, int& r) {

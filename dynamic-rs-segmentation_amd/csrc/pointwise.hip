@@ -92,10 +92,10 @@ __global__ void bn_act_pool_fwd_kernel(const float* __restrict__ z, int B, int S
   if (e >= Sp * CQ) return;
   const int xx = e / CQ, cq = e - xx * CQ;
   const int b = blockIdx.y / Sp, yy = blockIdx.y - b * Sp;
-  float* dst = out.base + ((size_t)(b * Sp + yy) * Sp + xx) * out.ld + out.coff + cq * 4;
+  const size_t dst = ((size_t)(b * Sp + yy) * Sp + xx) * out.ld + out.coff + cq * 4;
   const int y = yy - out.P, x = xx - out.P;
   if (y < 0 || y >= S || x < 0 || x >= S) {
-    *reinterpret_cast<f32x4*>(dst) = f32x4{0.f, 0.f, 0.f, 0.f};
+    view_store4(out, dst, f32x4{0.f, 0.f, 0.f, 0.f});
     return;
   }
   const f32x4 mr0 = *reinterpret_cast<const f32x4*>(mean_rstd + cq * 8);        // (m0, r0, m1, r1)
@@ -128,7 +128,7 @@ __global__ void bn_act_pool_fwd_kernel(const float* __restrict__ z, int B, int S
       }
     }
   }
-  *reinterpret_cast<f32x4*>(dst) = best;
+  view_store4(out, dst, best);
   if (POOL && idx) {
     const unsigned packed = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
     *reinterpret_cast<unsigned*>(idx + pix * C + cq * 4) = packed;
@@ -235,7 +235,7 @@ __global__ void zero_halo_kernel(ActView out, int B, int C) {
   const int b = blockIdx.y / Sp, yy = blockIdx.y - b * Sp;
   const int y = yy - out.P, x = xx - out.P;
   if (y >= 0 && y < out.S && x >= 0 && x < out.S) return;
-  *reinterpret_cast<f32x4*>(out.base + ((size_t)(b * Sp + yy) * Sp + xx) * out.ld + out.coff + cq * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+  view_store4(out, ((size_t)(b * Sp + yy) * Sp + xx) * out.ld + out.coff + cq * 4, f32x4{0.f, 0.f, 0.f, 0.f});
 }
 
 __global__ void bn_act_pool_fwd_slide_kernel(const float* __restrict__ z, int B, int S, int C, const float* __restrict__ mean_rstd,
@@ -286,7 +286,7 @@ __global__ void bn_act_pool_fwd_slide_kernel(const float* __restrict__ z, int B,
       if (m1[j] > best[j]) { best[j] = m1[j]; code[j] = 3u + c1[j]; }
       if (m2[j] > best[j]) { best[j] = m2[j]; code[j] = 6u + c2[j]; }
     }
-    *reinterpret_cast<f32x4*>(out.base + ((size_t)(b * Sp + y + out.P) * Sp + x + out.P) * out.ld + out.coff + cq * 4) = best;
+    view_store4(out, ((size_t)(b * Sp + y + out.P) * Sp + x + out.P) * out.ld + out.coff + cq * 4, best);
     if (idx) {
       const size_t pix = ((size_t)b * S + y) * S + x;
       *reinterpret_cast<unsigned*>(idx + pix * C + cq * 4) = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
@@ -545,10 +545,10 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ gxh, const float* 
   if (e >= Sp * CQ) return;
   const int xx = e / CQ, cq = e - xx * CQ;
   const int b = blockIdx.y / Sp, yy = blockIdx.y - b * Sp;
-  float* dst = out.base + ((size_t)(b * Sp + yy) * Sp + xx) * out.ld + out.coff + cq * 4;
+  const size_t dst = ((size_t)(b * Sp + yy) * Sp + xx) * out.ld + out.coff + cq * 4;
   const int y = yy - out.P, x = xx - out.P;
   if (y < 0 || y >= S || x < 0 || x >= S) {
-    *reinterpret_cast<f32x4*>(dst) = f32x4{0.f, 0.f, 0.f, 0.f};
+    view_store4(out, dst, f32x4{0.f, 0.f, 0.f, 0.f});
     return;
   }
   const size_t pix = ((size_t)b * S + y) * S + x;
@@ -563,7 +563,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ gxh, const float* 
     const float xh = (zv[j] - mu) * rs;
     o[j] = rs * (gv[j] - m1 - xh * m2);
   }
-  *reinterpret_cast<f32x4*>(dst) = o;
+  view_store4(out, dst, o);
 }
 
 // ------------------------------------------------------------------------------------------------ classifier + loss
@@ -763,7 +763,7 @@ __global__ void confusion_kernel(const unsigned char* __restrict__ labels, const
 }
 
 inline ActView mkview(float* base, int S, int P, int ld, int coff) {
-  ActView v; v.base = base; v.S = S; v.P = P; v.ld = ld; v.coff = coff; return v;
+  ActView v; v.base = base; v.S = S; v.P = P; v.ld = ld; v.coff = coff; v.terms = nullptr; v.nt = 0; return v;
 }
 
 }  // namespace
@@ -795,14 +795,17 @@ int drs_bn_eval_coeffs(const float* moving_mean, const float* moving_var, int C,
   return DRS_LAUNCH_CHECK();
 }
 
-int drs_bn_act_pool_forward(const float* z, int B, int S, int C, const float* mean_rstd, float alpha, int pool,
-                            float* out, int P_out, int ld_out, int coff_out, unsigned char* argmax, void* stream) {
-  if (!z || !mean_rstd || !out || C % 4) return DRS_ERR_ARG;
+static int bn_act_pool_forward_impl(const float* z, int B, int S, int C, const float* mean_rstd, float alpha, int pool,
+                                    float* out, int P_out, int ld_out, int coff_out, unsigned char* argmax,
+                                    unsigned short* terms, int nterms, void* stream) {
+  if (!z || !mean_rstd || (!out && !terms) || C % 4) return DRS_ERR_ARG;
+  if (terms && ((nterms != 2 && nterms != 3) || (ld_out & 31) || (coff_out & 31))) return DRS_ERR_ARG;
   const int Sp = S + 2 * P_out;
   if ((long long)B * Sp > 65535) return DRS_ERR_ARG;
   const int per_row = Sp * (C / 4);
   dim3 grid((per_row + 255) / 256, B * Sp);
   ActView v = mkview(out, S, P_out, ld_out, coff_out);
+  v.terms = terms; v.nt = terms ? nterms : 0;
   if (pool && C / 4 <= 256) {
     const SlideCfg c = slide_cfg(B, S, C);
     if (P_out > 0) DRS_LAUNCH(zero_halo_kernel, grid, dim3(256), 0, (hipStream_t)stream, v, B, C);
@@ -813,6 +816,19 @@ int drs_bn_act_pool_forward(const float* z, int B, int S, int C, const float* me
   else
     DRS_LAUNCH(bn_act_pool_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, z, B, S, C, mean_rstd, alpha, v, argmax);
   return DRS_LAUNCH_CHECK();
+}
+
+int drs_bn_act_pool_forward(const float* z, int B, int S, int C, const float* mean_rstd, float alpha, int pool,
+                            float* out, int P_out, int ld_out, int coff_out, unsigned char* argmax, void* stream) {
+  if (!out) return DRS_ERR_ARG;
+  return bn_act_pool_forward_impl(z, B, S, C, mean_rstd, alpha, pool, out, P_out, ld_out, coff_out, argmax, nullptr, 0, stream);
+}
+
+int drs_bn_act_pool_forward_terms(const float* z, int B, int S, int C, const float* mean_rstd, float alpha, int pool,
+                                  float* out, int P_out, int ld_out, int coff_out, unsigned char* argmax,
+                                  unsigned short* terms, int nterms, void* stream) {
+  if (!terms) return DRS_ERR_ARG;
+  return bn_act_pool_forward_impl(z, B, S, C, mean_rstd, alpha, pool, out, P_out, ld_out, coff_out, argmax, terms, nterms, stream);
 }
 
 // rows of the slab drs_bn_backward_reduce writes (partial must hold rows * C * 2 floats)
@@ -854,16 +870,32 @@ int drs_bn_backward_reduce(const float* ga, int ld_ga, int coff_ga, const float*
   return DRS_LAUNCH_CHECK();
 }
 
-int drs_bn_backward_apply(const float* gxhat, const float* z, int B, int S, int C, const float* mean_rstd, const double* sums,
-                          double count, float* gz, int P_out, int ld_out, int coff_out, void* stream) {
-  if (!gxhat || !z || !mean_rstd || !sums || !gz || C % 4) return DRS_ERR_ARG;
+static int bn_backward_apply_impl(const float* gxhat, const float* z, int B, int S, int C, const float* mean_rstd,
+                                  const double* sums, double count, float* gz, int P_out, int ld_out, int coff_out,
+                                  unsigned short* terms, int nterms, void* stream) {
+  if (!gxhat || !z || !mean_rstd || !sums || (!gz && !terms) || C % 4) return DRS_ERR_ARG;
+  if (terms && ((nterms != 2 && nterms != 3) || (ld_out & 31) || (coff_out & 31))) return DRS_ERR_ARG;
   const int Sp = S + 2 * P_out;
   if ((long long)B * Sp > 65535) return DRS_ERR_ARG;
   const int per_row = Sp * (C / 4);
   dim3 grid((per_row + 255) / 256, B * Sp);
-  DRS_LAUNCH(bn_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, gxhat, z, B, S, C, mean_rstd, sums, count,
-                     mkview(gz, S, P_out, ld_out, coff_out));
+  ActView v = mkview(gz, S, P_out, ld_out, coff_out);
+  v.terms = terms; v.nt = terms ? nterms : 0;
+  DRS_LAUNCH(bn_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, gxhat, z, B, S, C, mean_rstd, sums, count, v);
   return DRS_LAUNCH_CHECK();
+}
+
+int drs_bn_backward_apply(const float* gxhat, const float* z, int B, int S, int C, const float* mean_rstd, const double* sums,
+                          double count, float* gz, int P_out, int ld_out, int coff_out, void* stream) {
+  if (!gz) return DRS_ERR_ARG;
+  return bn_backward_apply_impl(gxhat, z, B, S, C, mean_rstd, sums, count, gz, P_out, ld_out, coff_out, nullptr, 0, stream);
+}
+
+int drs_bn_backward_apply_terms(const float* gxhat, const float* z, int B, int S, int C, const float* mean_rstd,
+                                const double* sums, double count, float* gz, int P_out, int ld_out, int coff_out,
+                                unsigned short* terms, int nterms, void* stream) {
+  if (!terms) return DRS_ERR_ARG;
+  return bn_backward_apply_impl(gxhat, z, B, S, C, mean_rstd, sums, count, gz, P_out, ld_out, coff_out, terms, nterms, stream);
 }
 
 int drs_classifier_rows(int B, int S) { return (B * S * S + 255) / 256; }

@@ -214,6 +214,10 @@ class DilatedNet(object):
             ns = self.ns
             srcs = {L.src for i, L in enumerate(p.layers) if self._split_fwd(i)}
             self.aplanes = {n: torch.zeros(ns * self.abuf[n].numel(), **i16) for n in srcs}
+            # slabs somebody still reads as fp32 (the classifier, convolutions that stay on the fp32 kernels); the other
+            # slabs exist as bf16 terms only, written by the producing kernel itself
+            self.f32_slabs = {p.feat} | {L.src for i, L in enumerate(p.layers) if not self._split_fwd(i)} | (set(p.buffers) - srcs)
+            self.terms_stale = set(self.aplanes)
             self.gzplanes = torch.zeros(ns * self.gz.numel(), **i16)
             self.wf_planes = [torch.zeros(ns * L.k * L.k * L.cin_k * L.cout, **i16) if self._split_fwd(i) else None
                        for i, L in enumerate(p.layers)]
@@ -256,12 +260,19 @@ class DilatedNet(object):
         return self._split_fwd(i) and L.src != "x0" and L.cin % 64 == 0
 
     def _split_slab(self, name, B, S):
-        """bf16 term planes of the current contents of activation slab `name`."""
+        """bf16 terms of activation slab `name` from its fp32 image, unless every write of this pass already came with terms."""
+        if name not in self.terms_stale:
+            return
         C, P = self.plan.buffers[name]
         n = B * (S + 2 * P) ** 2 * C
         t = self.abuf[name]
-        self._k("split", n * (4.0 + 2.0 * self.ns), "drs_split_planes", _ptr(t), n, self.ns, _ptr(self.aplanes[name]), t.numel(),
-                self._stream())
+        self._k("split", n * (4.0 + 2.0 * self.ns), "drs_split_terms", _ptr(t), n, self.ns, _ptr(self.aplanes[name]), self._stream())
+        self.terms_stale.discard(name)
+
+    def _touch_f32(self, name):
+        """slab `name` was just written as fp32 only (crop / feed, SE and average-pool producers)."""
+        if self.ns and name in self.aplanes:
+            self.terms_stale.add(name)
 
     # ------------------------------------------------------------------ views
     def _is_max(self, i):
@@ -347,13 +358,14 @@ class DilatedNet(object):
         p, st = self.plan, self._stream()
         M = B * S * S
         self._prepare_weights(st, training)
+        self._touch_f32("x0")
         for i, L in enumerate(p.layers):
             xin, Pin, ldin, cin_off = self._in_view(i)
             stats = self.partial if training else None
             if self._split_fwd(i):
                 self._split_slab(L.src, B, S)
                 self._k("conv_fwd", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_forward_split", _ptr(self.aplanes[L.src]),
-                        xin.numel(), B, S, Pin, ldin, cin_off, _ptr(self.wf_planes[i]), L.k * L.k * L.cin_k * L.cout, self._bias_ptr(L.name),
+                        B, S, Pin, ldin, cin_off, _ptr(self.wf_planes[i]), self._bias_ptr(L.name),
                         L.k, L.rate, L.pad_b, L.cin_k, L.cout, _ptr(self.z[i]), L.cout, 0, 0, _ptr(stats), self.ns, st)
             else:
                 self._k("conv_fwd", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_forward", _ptr(xin), B, S, Pin, ldin, cin_off,
@@ -378,15 +390,27 @@ class DilatedNet(object):
                 self._k("se_fwd", M * L.cout * 12.0, "drs_se_forward", _ptr(stt["act"]), B, S, L.cout, L.cout // 4,
                         self._pptr(sc + "_fc1/weights"), self._pptr(sc + "_fc1/biases"), self._pptr(sc + "_fc2/weights"),
                         self._pptr(sc + "_fc2/biases"), _ptr(stt["s"]), _ptr(stt["e1"]), _ptr(stt["e2"]), _ptr(out), Pout, ldout, coff, st)
+                self._touch_f32(L.dst)
             elif ak:    # activation into a plain [M][C] buffer, then the k x k average into the next layer's slab
                 self._k("bn_act_pool_fwd", M * L.cout * 8.0, "drs_bn_act_pool_forward", _ptr(self.z[i]), B, S, L.cout,
                         _ptr(self.mean_rstd[i]), p.alpha, 0, _ptr(self.act), 0, L.cout, 0, None, st)
                 self._k("avg_pool_fwd", M * L.cout * 8.0, "drs_avg_pool_forward", _ptr(self.act), B, S, L.cout, ak, _ptr(out), Pout,
                         ldout, coff, st)
+                self._touch_f32(L.dst)
+            elif self.ns and L.dst in self.aplanes and ldout == L.cout and coff == 0:
+                # the producer of a whole slab writes the bf16 terms the next convolution reads itself (and the fp32 image only
+                # if someone needs it); channel slices of a shared slab (dense / squeeze nets) go through drs_split_terms
+                keep = L.dst in self.f32_slabs
+                self.terms_stale.discard(L.dst)
+                self._k("bn_act_pool_fwd", M * L.cout * ((5.0 if (training and mx) else 4.0) + 2.0 * self.ns + (4.0 if keep else 0.0)),
+                        "drs_bn_act_pool_forward_terms", _ptr(self.z[i]), B, S, L.cout, _ptr(self.mean_rstd[i]), p.alpha,
+                        1 if mx else 0, _ptr(out) if keep else None, Pout, ldout, coff,
+                        _ptr(self.idx[i]) if (training and mx) else None, _ptr(self.aplanes[L.dst]), self.ns, st)
             else:
                 self._k("bn_act_pool_fwd", M * L.cout * (9.0 if (training and mx) else 8.0), "drs_bn_act_pool_forward",
                         _ptr(self.z[i]), B, S, L.cout, _ptr(self.mean_rstd[i]), p.alpha, 1 if mx else 0, _ptr(out), Pout, ldout,
                         coff, _ptr(self.idx[i]) if (training and mx) else None, st)
+                self._touch_f32(L.dst)
 
     def forward(self, B, S, want_logits=True, labels=False, acc_mask=False, ignore_label=-1):
         """is_training=False pass over the slab filled by crop/feed: returns (pred uint8 [B,S,S] device,
@@ -483,19 +507,22 @@ class DilatedNet(object):
             _lib.call("drs_stats_reduce", _ptr(self.partial), _lib.query("drs_bn_backward_rows", B, S, L.cout, 1 if mx else 0), L.cout,
                       _ptr(self.sums), _ptr(self.colsum_scratch), st)
             self.comm.all_reduce_sum(self.sums[:2 * L.cout])
-            self._k("bn_bwd_apply", M * L.cout * 12.0, "drs_bn_backward_apply", _ptr(self.gxh), _ptr(self.z[i]), B, S, L.cout,
-                    _ptr(self.mean_rstd[i]), _ptr(self.sums), n_bn, _ptr(self.gz), L.halo, L.cout, 0, st)
+            if self._split_fwd(i):
+                keep = self.debug is not None or (L.src != "x0" and not self._split_dgrad(i))     # an fp32 kernel still reads gz
+                self._k("bn_bwd_apply", M * L.cout * (8.0 + 2.0 * self.ns + (4.0 if keep else 0.0)), "drs_bn_backward_apply_terms",
+                        _ptr(self.gxh), _ptr(self.z[i]), B, S, L.cout, _ptr(self.mean_rstd[i]), _ptr(self.sums), n_bn,
+                        _ptr(self.gz) if keep else None, L.halo, L.cout, 0, _ptr(self.gzplanes), self.ns, st)
+            else:
+                self._k("bn_bwd_apply", M * L.cout * 12.0, "drs_bn_backward_apply", _ptr(self.gxh), _ptr(self.z[i]), B, S, L.cout,
+                        _ptr(self.mean_rstd[i]), _ptr(self.sums), n_bn, _ptr(self.gz), L.halo, L.cout, 0, st)
             if self.debug is not None:      # diagnostics only: per-layer snapshots for tests/diag_net.py
                 self.debug["gxh%d" % i] = self.gxh[:M * L.cout].clone()
                 self.debug["gz%d" % i] = self.gz[:B * (S + 2 * L.halo) ** 2 * L.cout].clone()
             xin, Pin, ldin, cin_off = self._in_view(i)
             goff, _ = p.offsets[L.name + "/weights"]
             if self._split_fwd(i):
-                ngz = B * (S + 2 * L.halo) ** 2 * L.cout
-                self._k("split", ngz * (4.0 + 2.0 * self.ns), "drs_split_planes", _ptr(self.gz), ngz, self.ns, _ptr(self.gzplanes),
-                        self.gz.numel(), st)
                 self._k("conv_wgrad", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_wgrad_split", _ptr(self.aplanes[L.src]),
-                        xin.numel(), B, S, Pin, ldin, cin_off, _ptr(self.gzplanes), self.gz.numel(), L.halo, L.cout, 0, L.k, L.rate,
+                        B, S, Pin, ldin, cin_off, _ptr(self.gzplanes), L.halo, L.cout, 0, L.k, L.rate,
                         L.pad_b, L.cin_k, L.cin, L.cout, _ptr(self.slab), self.grads[goff:].data_ptr(), self.ns, st)
             else:
                 self._k("conv_wgrad", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_wgrad", _ptr(xin), B, S, Pin, ldin, cin_off,
@@ -509,7 +536,7 @@ class DilatedNet(object):
                 written.add(L.src)
                 if self._split_dgrad(i):
                     self._k("conv_dgrad", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_forward_split", _ptr(self.gzplanes),
-                            self.gz.numel(), B, S, L.halo, L.cout, 0, _ptr(self.wd_planes[i]), L.k * L.k * L.cin * L.cout, None, L.k, L.rate,
+                            B, S, L.halo, L.cout, 0, _ptr(self.wd_planes[i]), None, L.k, L.rate,
                             L.pad_a, L.cout, L.cin, _ptr(self.gbuf[L.src]), p.buffers[L.src][0], 0, acc, None, self.ns, st)
                 else:
                     self._k("conv_dgrad", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_forward", _ptr(self.gz), B, S, L.halo, L.cout,

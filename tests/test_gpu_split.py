@@ -37,10 +37,11 @@ def split_host(x, ns):
 
 
 def planes(lib, t, ns):
+    """device terms of a float32 tensor in the kernels' layout: term s of element e at (e & ~31)*ns + 32*s + (e & 31)"""
     n = t.numel()
-    assert n % 8 == 0
+    assert n % 32 == 0
     p = torch.zeros(ns * n, dtype=torch.int16, device=DEV)
-    lib.call("drs_split_planes", t.data_ptr(), n, ns, p.data_ptr(), n, stream())
+    lib.call("drs_split_terms", t.data_ptr(), n, ns, p.data_ptr(), stream())
     return p, n
 
 
@@ -51,7 +52,7 @@ def test_split_planes_terms(lib, ns):
     x[:8] = [0.0, -0.0, 1.0, -1.0, 1e-30, 3.0e38, 1.0 + 2.0 ** -9, 2.0 ** -126]
     p, n = planes(lib, dev(x), ns)
     torch.cuda.synchronize()
-    got = p.view(torch.bfloat16).to(torch.float32).cpu().numpy().reshape(ns, n)
+    got = p.view(torch.bfloat16).to(torch.float32).cpu().numpy().reshape(n // 32, ns, 32).transpose(1, 0, 2).reshape(ns, n)
     want = split_host(x, ns)
     for s in range(ns):
         assert np.array_equal(got[s], want[s]), s
@@ -91,7 +92,7 @@ def test_conv_split_forward_dgrad_wgrad(lib, k, rate, cin, cout, B, S, ns):
     mt = lib.query("drs_split_conv_mtile", cout)
     rows = (M + mt - 1) // mt
     stats = torch.zeros(rows * cout * 2, dtype=torch.float32, device=DEV)
-    lib.call("drs_conv_forward_split", xp.data_ptr(), nx, B, S, P, cin + 32, 32, wf.data_ptr(), nw, bd.data_ptr(), k, rate, pb,
+    lib.call("drs_conv_forward_split", xp.data_ptr(), B, S, P, cin + 32, 32, wf.data_ptr(), bd.data_ptr(), k, rate, pb,
              cin, cout, out.data_ptr(), cout + 32, 32, 0, stats.data_ptr(), ns, stream())
     torch.cuda.synchronize()
     x64, w64 = x.astype(np.float64), w.astype(np.float64)
@@ -104,7 +105,7 @@ def test_conv_split_forward_dgrad_wgrad(lib, k, rate, cin, cout, B, S, ns):
     r2 = ref.reshape(-1, cout)
     assert np.abs(st[:, 0] - r2.sum(axis=0)).max() < tol * np.abs(r2).sum(axis=0).max()
     assert rel_err(st[:, 1], (r2 ** 2).sum(axis=0)) < tol
-    lib.call("drs_conv_forward_split", xp.data_ptr(), nx, B, S, P, cin + 32, 32, wf.data_ptr(), nw, None, k, rate, pb,
+    lib.call("drs_conv_forward_split", xp.data_ptr(), B, S, P, cin + 32, 32, wf.data_ptr(), None, k, rate, pb,
              cin, cout, out.data_ptr(), cout + 32, 32, 1, None, ns, stream())
     torch.cuda.synchronize()
     ref2 = ref + T.conv2d_same(x64, w64, rate)
@@ -115,12 +116,12 @@ def test_conv_split_forward_dgrad_wgrad(lib, k, rate, cin, cout, B, S, ns):
     gp, ng = planes(lib, gd, ns)
     gx = torch.zeros(M * cin, dtype=torch.float32, device=DEV)
     if cin % 64 == 0:       # the input-gradient GEMM has N = cin; narrower layers stay on the exact-fp32 kernel
-        lib.call("drs_conv_forward_split", gp.data_ptr(), ng, B, S, P, cout, 0, wg.data_ptr(), nw, None, k, rate, pa, cout, cin,
+        lib.call("drs_conv_forward_split", gp.data_ptr(), B, S, P, cout, 0, wg.data_ptr(), None, k, rate, pa, cout, cin,
                  gx.data_ptr(), cin, 0, 0, None, ns, stream())
     nsplit = lib.query("drs_conv_wgrad_split_splits", B, S, k, cin, cout)
     slab = torch.zeros(nsplit * nw, dtype=torch.float32, device=DEV)
     gw = torch.zeros(nw, dtype=torch.float32, device=DEV)
-    lib.call("drs_conv_wgrad_split", xp.data_ptr(), nx, B, S, P, cin + 32, 32, gp.data_ptr(), ng, P, cout, 0, k, rate, pb, cin,
+    lib.call("drs_conv_wgrad_split", xp.data_ptr(), B, S, P, cin + 32, 32, gp.data_ptr(), P, cout, 0, k, rate, pb, cin,
              cin, cout, slab.data_ptr(), gw.data_ptr(), ns, stream())
     torch.cuda.synchronize()
     e_dg = rel_err(gx.cpu().numpy().reshape(B, S, S, cin), gx_ref) if cin % 64 == 0 else 0.0
@@ -143,13 +144,13 @@ def test_conv1_band_padding_split(lib, ns):
     wf = torch.zeros(ns * nwp, dtype=torch.int16, device=DEV)
     lib.call("drs_filter_split", dev(w).data_ptr(), k, C, 32, cout, ns, wf.data_ptr(), None, stream())
     out = torch.zeros(B * S * S * cout, dtype=torch.float32, device=DEV)
-    lib.call("drs_conv_forward_split", xp.data_ptr(), nx, B, S, 2, 32, 0, wf.data_ptr(), nwp, None, k, 1, 2, 32, cout,
+    lib.call("drs_conv_forward_split", xp.data_ptr(), B, S, 2, 32, 0, wf.data_ptr(), None, k, 1, 2, 32, cout,
              out.data_ptr(), cout, 0, 0, None, ns, stream())
     gp, ng = planes(lib, padded(g, 2), ns)
     nsplit = lib.query("drs_conv_wgrad_split_splits", B, S, k, 32, cout)
     slab = torch.zeros(nsplit * nwp, dtype=torch.float32, device=DEV)
     gw = torch.zeros(k * k * C * cout, dtype=torch.float32, device=DEV)
-    lib.call("drs_conv_wgrad_split", xp.data_ptr(), nx, B, S, 2, 32, 0, gp.data_ptr(), ng, 2, cout, 0, k, 1, 2, 32, C, cout,
+    lib.call("drs_conv_wgrad_split", xp.data_ptr(), B, S, 2, 32, 0, gp.data_ptr(), 2, cout, 0, k, 1, 2, 32, C, cout,
              slab.data_ptr(), gw.data_ptr(), ns, stream())
     torch.cuda.synchronize()
     ref = T.conv2d_same(x.astype(np.float64), w.astype(np.float64), 1)

@@ -50,18 +50,18 @@ def main(B=128, S=64, net="dilated_grsl_rate8", layers=None):
         tot["f32"] = tot.get("f32", 0) + ms
         zref = z.clone()
         # fp64 reference on a sample of output rows would need the oracle; compare against the exact-fp32 kernel instead
-        for ns in (2, 3):
+        for ns, variant in [(2, 0), (2, 1), (3, 0), (3, 1)]:
+            _lib.load().drs_debug_variant(variant)
             xp = torch.zeros(ns * n, dtype=torch.int16, device=DEV)
             wf = torch.zeros(ns * w.numel(), dtype=torch.int16, device=DEV)
-            ms_s = timeit(lambda: _lib.call("drs_split_planes", x.data_ptr(), n, ns, xp.data_ptr(), n, st))
+            ms_s = timeit(lambda: _lib.call("drs_split_terms", x.data_ptr(), n, ns, xp.data_ptr(), st))
             _lib.call("drs_filter_split", w.data_ptr(), L.k, L.cin_k, L.cin_k, L.cout, ns, wf.data_ptr(), None, st)
             z2 = torch.zeros(M * L.cout, device=DEV)
-            ms = timeit(lambda: _lib.call("drs_conv_forward_split", xp.data_ptr(), n, B, S, P, L.cin_k, 0, wf.data_ptr(), w.numel(),
+            ms = timeit(lambda: _lib.call("drs_conv_forward_split", xp.data_ptr(), B, S, P, L.cin_k, 0, wf.data_ptr(),
                                           bias.data_ptr(), L.k, L.rate, L.pad_b, L.cin_k, L.cout, z2.data_ptr(), L.cout, 0, 0, None, ns, st))
             err = float((z2 - zref).abs().max() / zref.abs().max())
-            row += " x%d %6.3f ms %6.1f TF (split %5.3f ms) err %.1e |" % (3 if ns == 2 else 6, ms, fl / ms / 1e9, ms_s, err)
-            tot["x%d" % ns] = tot.get("x%d" % ns, 0) + ms
-            tot["split%d" % ns] = tot.get("split%d" % ns, 0) + ms_s
+            row += " x%d v%d %6.3f ms %6.1f TF err %.1e |" % (3 if ns == 2 else 6, variant, ms, fl / ms / 1e9, err)
+            tot["x%d v%d" % (ns, variant)] = tot.get("x%d v%d" % (ns, variant), 0) + ms
         print(row, flush=True)
     print("total ms:", {k: round(v, 2) for k, v in tot.items()})
 
