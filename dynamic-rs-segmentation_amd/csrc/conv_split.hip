@@ -435,6 +435,7 @@ int launch_split(const SplitConvArgs& a, hipStream_t st) {
 template <int NS>
 int dispatch_split(const SplitConvArgs& a, hipStream_t st) {
   if (a.Cout % 128 == 0) return launch_split<128, 128, 2, 2, NS>(a, st);
+  if (a.Cout % 192 == 0 && g_variant != 0) return launch_split<128, 192, 2, 2, NS>(a, st);
   return launch_split<256, 64, 4, 1, NS>(a, st);
 }
 
@@ -454,6 +455,7 @@ struct SplitWgradArgs {
   float* slab;
   int chunks_per_split;
   int ntr, nto;
+  int o_base;                // first output column of this launch (Cout = 192 runs as a 128-wide and a 64-wide launch)
   float rcpS, rcpSS;
 };
 
@@ -492,7 +494,7 @@ __global__ __launch_bounds__((TR / 64) * (TO / 64) * 64) void wgrad_split_kernel
   const int split = id / ntile;
   const int tile = id % ntile;
   const int R0 = (tile / a.nto) * TR;
-  const int o0 = (tile % a.nto) * TO;
+  const int o0 = a.o_base + (tile % a.nto) * TO;
   const int rows_all = a.k * a.k * a.Cin;
   const int myR = R0 + (t % XQ) * 8;            // this thread always stages the same 8 rows (tap, c..c+7)
   const bool row_ok = myR < rows_all;
@@ -625,6 +627,185 @@ __global__ __launch_bounds__((TR / 64) * (TO / 64) * 64) void wgrad_split_kernel
       }
 }
 
+// ---- the same filter-gradient GEMM with LDS-DMA tiles (double-buffered, one barrier per 32-pixel chunk).  The DMA
+// writes lane-linear LDS, so the images are unpadded and swizzled instead: X rows are 256 B (128 rows of the
+// [k*k*Cin] dimension), 16-byte chunk c of pixel row r at slot c ^ (((r & 3) << 2) | ((r >> 2) & 3)); G rows are 256 B
+// (TO = 128, same rule) or 128 B (TO = 64, slot c ^ (((r >> 1) & 1) << 2)).  With these the four pixel rows of every
+// transposing read fall on the four 64-byte quarters of the bank row.  Pixels past the end read G from the slab's first
+// halo pixel (zeros; needs Pg > 0), so no select is needed; X rows past k*k*Cin read a valid address and only feed
+// accumulator rows that are never stored.
+template <int TO, int NS>
+__global__ __launch_bounds__((TO / 64) * 128) void wgrad_split_dma_kernel(const SplitWgradArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass has no LDS-DMA builtin; it only needs the launch stub
+  constexpr int TR = 128;
+  constexpr int WC = TO / 64;
+  constexpr int NW = 2 * WC;                    // waves
+  constexpr int BP = 32;
+  constexpr int XROW = TR * 2, GROW = TO * 2;   // bytes per image row
+  constexpr int XT = BP * XROW, GT = BP * GROW; // bytes per term tile
+  constexpr int STAGE = NS * (XT + GT);
+  constexpr int IX = 8 / NW;                    // X DMA instructions per wave per term (4 pixel rows each)
+  constexpr int IG = (GT / 1024) / NW;          // G DMA instructions per wave per term (4 or 8 pixel rows each)
+  constexpr int GRPI = 1024 / GROW;             // pixel rows per G instruction
+
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+  __shared__ uint32_t tabx[2][BP], tabg[2][BP];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 31, h = lane >> 5;
+  const int wr = wave / WC, wc = wave % WC;
+
+  const int ntile = a.ntr * a.nto;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = id / ntile;
+  const int tile = id % ntile;
+  const int R0 = (tile / a.nto) * TR;
+  const int o0 = a.o_base + (tile % a.nto) * TO;
+  const int rows_all = a.k * a.k * a.Cin;
+  const int Sxp = a.S + 2 * a.Px;
+
+  // DMA lane roles.  X instruction j: pixel row 4 j + (lane >> 4), slot lane & 15 <- source chunk slot ^ fX(row)
+  uint32_t xconst[IX];
+  int xrow[IX];
+#pragma unroll
+  for (int i = 0; i < IX; ++i) {
+    const int j = wave + NW * i;
+    xrow[i] = 4 * j + (lane >> 4);
+    const int chunk = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (j & 3));
+    int R = R0 + chunk * 8;
+    R = R < rows_all ? R : 0;
+    const int tap = R / a.Cin, c0 = R % a.Cin;
+    const int u = tap / a.k, v = tap % a.k;
+    xconst[i] = (uint32_t)(NS * ((u * a.rate * Sxp + v * a.rate) * a.ld_x + a.coff_x + (c0 & ~31)) + (c0 & 31));
+  }
+  uint32_t gconst;
+  int grow[IG];
+  {
+    const int slot = TO == 128 ? (lane & 15) : (lane & 7);
+    const int chunk = TO == 128 ? (slot ^ ((((lane >> 4) & 3) << 2) | (wave & 3))) : (slot ^ (((lane >> 4) & 1) << 2));
+    const int og0 = o0 + chunk * 8;
+    gconst = (uint32_t)(NS * (a.coff_g + (og0 & ~31)) + (og0 & 31));
+#pragma unroll
+    for (int i = 0; i < IG; ++i) grow[i] = GRPI * (wave + NW * i) + (TO == 128 ? (lane >> 4) : (lane >> 3));
+  }
+  static_assert(TO == 64 || NW == 4, "the TO = 128 G swizzle uses j & 3 == wave");
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int nchunks_total = (a.M + BP - 1) / BP;
+  const int cbeg = split * a.chunks_per_split;
+  int cend = cbeg + a.chunks_per_split;
+  cend = cend < nchunks_total ? cend : nchunks_total;
+
+  auto fill_tables = [&](int chunk) {
+    if (t < BP && chunk < cend) {
+      const int p = chunk * BP + t;
+      const int pc = p < a.M ? p : a.M - 1;
+      tabx[chunk & 1][t] = padded_pixel_off(pc, a.S, a.Px, a.ld_x, a.rcpS, a.rcpSS, -a.pad, -a.pad);
+      tabg[chunk & 1][t] = p < a.M ? padded_pixel_off(pc, a.S, a.Pg, a.ld_g, a.rcpS, a.rcpSS, 0, 0) : 0u;   // 0 = a halo pixel: zeros
+    }
+  };
+  auto issue = [&](int chunk, int stage) {
+    const uint32_t* tx = tabx[chunk & 1];
+    const uint32_t* tg = tabg[chunk & 1];
+    unsigned char* sb = lds + stage * STAGE;
+    uint32_t ox[IX], og[IG];
+#pragma unroll
+    for (int i = 0; i < IX; ++i) ox[i] = NS * tx[xrow[i]] + xconst[i];
+#pragma unroll
+    for (int i = 0; i < IG; ++i) og[i] = NS * tg[grow[i]] + gconst;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int i = 0; i < IX; ++i)
+        __builtin_amdgcn_global_load_lds(a.x + ox[i] + 32 * s,
+                                         (__attribute__((address_space(3))) void*)(sb + s * XT + (wave + NW * i) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < IG; ++i)
+        __builtin_amdgcn_global_load_lds(a.g + og[i] + 32 * s,
+                                         (__attribute__((address_space(3))) void*)(sb + NS * XT + s * GT + (wave + NW * i) * 1024), 16, 0, 0);
+    }
+  };
+
+  if (cbeg < cend) {
+    // transposing-read offsets (bytes inside a term tile, kk = 0): lane 4q+p of a 16-lane group addresses pixel row
+    // r0 + q, 16-byte chunk c0 + (p >> 1), half p & 1, with r0 = 16 kk + 8 h + 4 j2 and c0 = the group's 16 columns
+    const int l16 = lane & 15, q = l16 >> 2, pp = l16 & 3, g1 = (lane >> 4) & 1;
+    uint32_t xo[2][2], go[2][2];      // [mi | ni][j2]
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int j2 = 0; j2 < 2; ++j2) {
+        const int row = 8 * h + 4 * j2 + q;
+        const int fx = (q << 2) | ((2 * h + j2) & 3);
+        const int chx = (wr * 8 + m * 4 + g1 * 2 + (pp >> 1)) ^ fx;
+        xo[m][j2] = (uint32_t)(XROW * row + 16 * chx + 8 * (pp & 1));
+        if (TO == 128) {
+          const int chg = (wc * 8 + m * 4 + g1 * 2 + (pp >> 1)) ^ fx;
+          go[m][j2] = (uint32_t)(GROW * row + 16 * chg + 8 * (pp & 1));
+        } else {
+          const int chg = (m * 4 + g1 * 2 + (pp >> 1)) ^ (((q >> 1) & 1) << 2);
+          go[m][j2] = (uint32_t)(GROW * row + 16 * chg + 8 * (pp & 1));
+        }
+      }
+    fill_tables(cbeg);
+    fill_tables(cbeg + 1);
+    __syncthreads();
+    issue(cbeg, 0);
+    __syncthreads();
+    for (int ch = cbeg; ch < cend; ++ch) {
+      const int stage = (ch - cbeg) & 1;
+      if (ch + 1 < cend) issue(ch + 1, stage ^ 1);
+      fill_tables(ch + 2);
+      const uint16_t* sx = reinterpret_cast<const uint16_t*>(lds + stage * STAGE);
+      const uint16_t* sg = reinterpret_cast<const uint16_t*>(lds + stage * STAGE + NS * XT);
+#pragma unroll
+      for (int kk = 0; kk < BP / 16; ++kk) {
+        bf16x8 fa[NS][2], fb[NS][2];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+            fa[s][mi] = tr_frag(sx + (s * XT + kk * 16 * XROW + xo[mi][0]) / 2, sx + (s * XT + kk * 16 * XROW + xo[mi][1]) / 2);
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            fb[s][ni] = tr_frag(sg + (s * GT + kk * 16 * GROW + go[ni][0]) / 2, sg + (s * GT + kk * 16 * GROW + go[ni][1]) / 2);
+        }
+#pragma unroll
+        for (int d = NS - 1; d >= 0; --d)
+#pragma unroll
+          for (int i = 0; i <= d; ++i)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][mi], fb[d - i][ni], acc[mi][ni], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+  const size_t rows_total = (size_t)rows_all;
+  float* dst = a.slab + ((size_t)split * rows_total + R0) * a.Cout + o0;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int col = wc * 64 + ni * 32 + li;
+        if (R0 + row < rows_all) dst[(size_t)row * a.Cout + col] = acc[mi][ni][r];
+      }
+#endif
+}
+
 // grad[tap][c][o] = sum over splits (fixed order) of slab[split][tap][c (of cin_pad)][o], c < cin_real
 __global__ void wgrad_split_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, int nsplit, int taps,
                                           int cin_pad, int cin_real, int cout) {
@@ -647,7 +828,8 @@ int launch_wgrad_split(const SplitWgradArgs& a, int nsplit, hipStream_t st) {
   return DRS_LAUNCH_CHECK();
 }
 
-int split_wgrad_rows(int rows) {
+int split_wgrad_rows(int rows, int Pg) {
+  if (g_variant != 0 && Pg > 0) return 128;       // the LDS-DMA kernel: 128-row tiles only, zeros fetched from the halo
   const int n128 = (rows + 127) / 128;
   return (double)rows / (n128 * 128.0) >= 0.85 ? 128 : 64;
 }
@@ -661,7 +843,7 @@ extern "C" {
 /* development switch between kernel variants (not part of the documented ABI) */
 int drs_debug_variant(int v) { const int old = g_variant; if (v >= 0) g_variant = v; return old; }
 
-int drs_split_conv_mtile(int cout) { return cout % 128 == 0 ? 128 : 256; }
+int drs_split_conv_mtile(int cout) { return (cout % 128 == 0 || (cout % 192 == 0 && g_variant != 0)) ? 128 : 256; }
 
 int drs_split_terms(const float* src, size_t n, int nterms, unsigned short* terms, void* stream) {
   if (!src || !terms || (n & 31) || (nterms != 2 && nterms != 3)) return DRS_ERR_ARG;
@@ -699,10 +881,11 @@ int drs_conv_forward_split(const unsigned short* in, int B, int S, int P, int ld
   return nsplit == 2 ? dispatch_split<2>(a, st) : dispatch_split<3>(a, st);
 }
 
-int drs_conv_wgrad_split_splits(int B, int S, int k, int cin, int cout) {
+int drs_conv_wgrad_split_splits(int B, int S, int k, int cin, int cout, int Pg) {
   const long long M = (long long)B * S * S;
-  const int tr = split_wgrad_rows(k * k * cin), to = cout % 128 == 0 ? 128 : 64;
-  const int ntile = ((k * k * cin + tr - 1) / tr) * (cout / to);
+  const int tr = split_wgrad_rows(k * k * cin, Pg), to = cout % 128 == 0 ? 128 : 64;
+  int ntile = ((k * k * cin + tr - 1) / tr) * (cout / to);
+  if (g_variant != 0 && Pg > 0 && to == 64 && cout > 64) ntile = ((k * k * cin + tr - 1) / tr) * ((cout / 128) + 1);   // 128-wide tiles + one 64-wide
   const int nchunks = (int)((M + 31) / 32);
   int want = 1536 / ntile;
   int maxs = (nchunks + 31) / 32;
@@ -724,15 +907,33 @@ int drs_conv_wgrad_split(const unsigned short* x, int B, int S, int Px, int ld_x
   a.x = x; a.S = S; a.Px = Px; a.ld_x = ld_x; a.coff_x = coff_x;
   a.g = g; a.Pg = Pg; a.ld_g = ld_g; a.coff_g = coff_g; a.M = (int)M;
   a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout; a.slab = slab;
-  const int tr = split_wgrad_rows(k * k * cin), to = cout % 128 == 0 ? 128 : 64;
+  const int tr = split_wgrad_rows(k * k * cin, Pg), to = cout % 128 == 0 ? 128 : 64;
   a.ntr = (k * k * cin + tr - 1) / tr; a.nto = cout / to;
-  const int nsplit = drs_conv_wgrad_split_splits(B, S, k, cin, cout);
+  const int nsplit = drs_conv_wgrad_split_splits(B, S, k, cin, cout, Pg);
   const int nchunks = (int)((M + 31) / 32);
   a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
+  a.o_base = 0;
   hipStream_t st = (hipStream_t)stream;
-  int rc;
-  if (nsplit_terms == 2) {
+  int rc = DRS_OK;
+  if (g_variant != 0 && Pg > 0) {
+    // 128-wide column tiles wherever they fit, one 64-wide tile for what is left (Cout = 64, 192)
+    const int n128 = cout / 128, rest = cout % 128;
+    if (n128) {
+      a.nto = n128; a.o_base = 0;
+      const dim3 grid(nsplit * a.ntr * a.nto);
+      if (nsplit_terms == 2) DRS_LAUNCH((wgrad_split_dma_kernel<128, 2>), grid, dim3(256), 0, st, a);
+      else DRS_LAUNCH((wgrad_split_dma_kernel<128, 3>), grid, dim3(256), 0, st, a);
+      rc = DRS_LAUNCH_CHECK();
+    }
+    if (rest && rc == DRS_OK) {
+      a.nto = 1; a.o_base = n128 * 128;
+      const dim3 grid(nsplit * a.ntr);
+      if (nsplit_terms == 2) DRS_LAUNCH((wgrad_split_dma_kernel<64, 2>), grid, dim3(128), 0, st, a);
+      else DRS_LAUNCH((wgrad_split_dma_kernel<64, 3>), grid, dim3(128), 0, st, a);
+      rc = DRS_LAUNCH_CHECK();
+    }
+  } else if (nsplit_terms == 2) {
     if (tr == 128 && to == 128) rc = launch_wgrad_split<128, 128, 2>(a, nsplit, st);
     else if (tr == 128) rc = launch_wgrad_split<128, 64, 2>(a, nsplit, st);
     else if (to == 128) rc = launch_wgrad_split<64, 128, 2>(a, nsplit, st);

@@ -187,8 +187,7 @@ class DilatedNet(object):
         hmax = max(L.halo for L in p.layers)
         self.sums = torch.zeros(cmax * 2, **f64)
         self.colsum_scratch = torch.zeros(_lib.query("drs_colsum_scratch_doubles", max(2 * cmax, p.c_last * p.K)), **f64)
-        rows_fwd = max((M + _lib.query("drs_conv_mtile", L.cout) - 1) // _lib.query("drs_conv_mtile", L.cout)
-                       for L in p.layers)
+        rows_fwd = max((M + self._mtile(i) - 1) // self._mtile(i) for i in range(len(p.layers)))
         # the slab's row count depends on the patch size through the kernel's tiling: size it for every S up to s_max
         part = max(max(_lib.query("drs_bn_backward_rows", B, s, L.cout, 1 if self._is_max(i) else 0) * L.cout * 2
                        for i, L in enumerate(p.layers)) for s in range(1, S + 1))
@@ -223,7 +222,7 @@ class DilatedNet(object):
                        for i, L in enumerate(p.layers)]
             self.wd_planes = [torch.zeros(ns * L.k * L.k * L.cin * L.cout, **i16) if self._split_dgrad(i) else None
                        for i, L in enumerate(p.layers)]
-            slab = max([slab] + [_lib.query("drs_conv_wgrad_split_splits", B, S, L.k, L.cin_k, L.cout) * L.k * L.k * L.cin_k * L.cout
+            slab = max([slab] + [_lib.query("drs_conv_wgrad_split_splits", B, S, L.k, L.cin_k, L.cout, L.halo) * L.k * L.k * L.cin_k * L.cout
                                  for i, L in enumerate(p.layers) if self._split_fwd(i)])
         self.slab = torch.zeros(slab, **f32)
         self.w0pad = torch.zeros(L0.k * L0.k * L0.cin_k * L0.cout, **f32)
@@ -253,6 +252,10 @@ class DilatedNet(object):
     def _split_fwd(self, i):
         """conv block i runs its forward and filter-gradient passes on the split-bf16 kernels (tile shapes need Cout % 64)."""
         return self.ns > 0 and self.plan.layers[i].cout % 64 == 0
+
+    def _mtile(self, i):
+        """pixels per row of the batch-norm statistics slab the forward convolution of block i writes"""
+        return _lib.query("drs_split_conv_mtile" if self._split_fwd(i) else "drs_conv_mtile", self.plan.layers[i].cout)
 
     def _split_dgrad(self, i):
         """... and its input-gradient pass (a GEMM with N = Cin)."""
@@ -374,7 +377,7 @@ class DilatedNet(object):
             bo = p.bn_offsets[L.name]
             mm, mv = self.bn[bo:bo + L.cout], self.bn[bo + L.cout:bo + 2 * L.cout]
             if training:
-                mt = _lib.query("drs_conv_mtile", L.cout)
+                mt = self._mtile(i)
                 _lib.call("drs_stats_reduce", _ptr(self.partial), (M + mt - 1) // mt, L.cout, _ptr(self.sums), _ptr(self.colsum_scratch), st)
                 self.comm.all_reduce_sum(self.sums[:2 * L.cout])           # sync batch norm over the global batch
                 _lib.call("drs_bn_finish", _ptr(self.sums), float(count), L.cout, _ptr(self.mean_rstd[i]), _ptr(mm), _ptr(mv),
