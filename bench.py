@@ -30,18 +30,32 @@ GLOBAL_BATCH, PATCH = 128, 64
 TILE = 2048
 LR, WD = 0.01, 0.005
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
+# arithmetic of the convolution kernels (net.ARITH_TERMS): MFMA peak it is priced against, MFMA products issued per
+# algorithmic multiply, the dtype string of the JSON line and the dominant kernel's name
+ARITH = {
+    "f32": dict(peak=PEAK_FP32_MFMA_TFLOPS, products=1, dtype="f32", kernel="conv_igemm_kernel (fwd + dgrad launches)",
+                pmc_key="conv_igemm_kernel (all)"),
+    "bf16x3": dict(peak=PEAK_BF16_MFMA_TFLOPS, products=3, kernel="conv_split_dma_kernel (fwd + dgrad launches)",
+                   dtype="bf16x3 (fp32 operands as 2 bf16 terms, 3 bf16 MFMA products per multiply, fp32 accumulate)",
+                   pmc_key="conv_split_dma_kernel (all)"),
+    "bf16x6": dict(peak=PEAK_BF16_MFMA_TFLOPS, products=6, kernel="conv_split_dma_kernel (fwd + dgrad launches)",
+                   dtype="bf16x6 (fp32 operands as 3 bf16 terms, 6 bf16 MFMA products per multiply, fp32 accumulate)",
+                   pmc_key="conv_split_dma_kernel (all)"),
+}
 
 
-def pmc_traffic():
-    """HBM-side bytes per conv_igemm_kernel launch from the committed rocprofv3 --pmc passes of this same command
-    (profiles/rNN/pmc_traffic.json, written by tools/pmc_summary.py); None when no profile is committed."""
+def pmc_traffic(arith):
+    """HBM-side bytes per launch of the dominant conv kernel from the committed rocprofv3 --pmc passes of this same command
+    (profiles/rNN/pmc_traffic[_<arith>].json, written by tools/pmc_summary.py); None when no profile is committed."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
+    name = "pmc_traffic.json" if arith == "f32" else "pmc_traffic_%s.json" % arith
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)))
     if not files:
         return None
     try:
-        return json.load(open(files[-1]))["conv_igemm_kernel (all)"]["traffic_bytes_per_launch"]
+        return json.load(open(files[-1]))[ARITH[arith]["pmc_key"]]["traffic_bytes_per_launch"]
     except (KeyError, ValueError):
         return None
 
@@ -96,7 +110,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--arith", choices=sorted(ARITH), default="f32",
+                    help="arithmetic of the convolution kernels: exact fp32 MFMA (default) or split-bf16 (conv_split.hip)")
     args = ap.parse_args()
+    ar = ARITH[args.arith]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -129,7 +146,7 @@ def main():
     inst = grid_instances(TILE, TILE, PATCH, 25, GLOBAL_BATCH * 100, seed=0)      # the super-batch (isprs:1630-1632)
     mean = tile[:, :, :3].mean(axis=(0, 1)).tolist()
     std = tile[:, :, :3].std(axis=(0, 1)).tolist()
-    net = DilatedNet(NET, CHANNELS, CLASSES, WD, b_max=B_local, s_max=PATCH, device=dev, seed=42, comm=comm)
+    net = DilatedNet(NET, CHANNELS, CLASSES, WD, b_max=B_local, s_max=PATCH, device=dev, seed=42, comm=comm, arith=args.arith)
     sl = shard_slice(GLOBAL_BATCH, rank, world)
 
     import random
@@ -184,7 +201,7 @@ def main():
             if kind.startswith("conv_"):
                 ach = d["work"] / (d["ms"] * 1e-3) / 1e12
                 kernels[kind] = dict(bound="mfma", launches_per_step=d["launches"] // 3, avg_ms=round(avg_ms, 4),
-                                     achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4))
+                                     achieved=round(ach, 2), peak=ar["peak"], unit="TFLOP/s", frac=round(ach / ar["peak"], 4))
             else:
                 ach = d["work"] / (d["ms"] * 1e-3) / 1e9
                 kernels[kind] = dict(bound="hbm", launches_per_step=d["launches"] // 3, avg_ms=round(avg_ms, 4),
@@ -194,9 +211,13 @@ def main():
         ms = sum(summ[k]["ms"] for k in ("conv_fwd", "conv_dgrad") if k in summ)
         nl = sum(summ[k]["launches"] for k in ("conv_fwd", "conv_dgrad") if k in summ)
         ach = w / (ms * 1e-3) / 1e12
-        roofline = dict(kernel="conv_igemm_kernel (fwd + dgrad launches)", bound="mfma", achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS,
-                        unit="TFLOP/s", frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=pmc_traffic(),
+        roofline = dict(kernel=ar["kernel"], bound="mfma", achieved=round(ach, 2), peak=ar["peak"],
+                        unit="TFLOP/s", frac=round(ach / ar["peak"], 4), traffic=pmc_traffic(args.arith),
                         launches=nl, avg_launch_ms=round(ms / nl, 4), algorithmic_gflop_per_launch=round(w / nl / 1e9, 2))
+        if ar["products"] > 1:      # the MFMA pipe executes `products` partial products per algorithmic multiply
+            roofline["mfma_products_per_multiply"] = ar["products"]
+            roofline["mfma_issued_tflops"] = round(ach * ar["products"], 1)
+            roofline["mfma_issued_frac"] = round(ach * ar["products"] / ar["peak"], 4)
 
     # ---- validation half of the metric: forward-only pixels/sec (eval-mode BN, arg-max, confusion), isprs:1569-1618
     vb = 4
@@ -227,7 +248,7 @@ def main():
         line = {
             "metric": "training patches/sec dilated_grsl_rate8 64x64x5", "value": round(value, 2), "unit": "patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": ar["dtype"], "data": "synthetic",
             "config": {"workload": "dilated_grsl_rate8 (Dilated8Pooling) training step, single_fixed 64x64, 5-band synthetic "
                                    "2048x2048 tile, global batch 128 (crop+augment+normalise, fwd, loss, bwd, momentum, confusion)",
                        "global_batch": GLOBAL_BATCH, "patch": PATCH, "bands": CHANNELS, "classes": CLASSES,

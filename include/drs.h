@@ -60,6 +60,34 @@ int drs_filter_flip_transpose(const float* w, float* wt, int k, int cin, int cou
 /* wp[u][v][c < cin_pad][o] = c < cin ? w[u][v][c][o] : 0 */
 int drs_filter_pad_cin(const float* w, float* wp, int k, int cin, int cin_pad, int cout, void* stream);
 
+/* ---- the same convolution in split-bf16 arithmetic (csrc/conv_split.hip) ---------------------------------------
+ * An opt-in second arithmetic for isprs:710-713 and its gradients; the exact-fp32 entry points above stay the default.
+ * Every fp32 operand x is carried as `nterms` bf16 terms, term s = round-to-nearest-even bf16 of what the earlier terms
+ * left (x = t0 + t1 (+ t2) up to 2^-17 |x| / 2^-25 |x|), and a product is evaluated on the bf16 MFMA pipe as the
+ * partial products t_i * u_j with i + j < nterms (3 products for 2 terms, 6 for 3), accumulated in fp32.
+ * Term layout: interleaved at 32-channel granularity over the fp32 indexing e of the slab the terms mirror:
+ * term s of element e sits at (e & ~31) * nterms + 32 * s + (e & 31), 2 bytes each, so views need ld and coff
+ * multiples of 32.  Filter terms are K-contiguous rows interleaved the same way (see drs_filter_split).
+ *   drs_split_terms    : n fp32 (n % 32 == 0) -> their terms (a whole slab, halo included).
+ *   drs_filter_split   : HWIO filter -> wf = forward operand [cout][k*k*cin_pad] and, if wd != NULL, wd = input-gradient
+ *                        operand [cin][k*k*cout] (taps reversed: what drs_filter_flip_transpose is to the fp32 path).
+ *   drs_conv_forward_split : drs_conv_forward on terms (`in`, `w`); cout % 64 == 0.  The input-gradient pass is the same
+ *                        call on the terms of the haloed output gradient with wd and pad_before := pad_after.
+ *                        stats_partial rows hold drs_split_conv_mtile(cout) pixels.
+ *   drs_conv_wgrad_split : drs_conv_wgrad on terms; slab = drs_conv_wgrad_split_splits(..., Pg) * k*k*cin*cout floats.
+ *                        With Pg > 0 pixels past the end read the gradient slab's first halo pixel (zeros). */
+int drs_split_conv_mtile(int cout);
+int drs_split_terms(const float* src, size_t n, int nterms, unsigned short* terms, void* stream);
+int drs_filter_split(const float* w, int k, int cin, int cin_pad, int cout, int nterms, unsigned short* wf,
+                     unsigned short* wd, void* stream);
+int drs_conv_forward_split(const unsigned short* in, int B, int S, int P, int ld_in, int coff_in, const unsigned short* w,
+                           const float* bias, int k, int rate, int pad_before, int cin, int cout, float* out, int ld_out,
+                           int coff_out, int accumulate, float* stats_partial, int nterms, void* stream);
+int drs_conv_wgrad_split_splits(int B, int S, int k, int cin, int cout, int Pg);
+int drs_conv_wgrad_split(const unsigned short* x, int B, int S, int Px, int ld_x, int coff_x, const unsigned short* g,
+                         int Pg, int ld_g, int coff_g, int k, int rate, int pad_before, int cin, int cin_real, int cout,
+                         float* slab, float* grad, int nterms, void* stream);
+
 /* ---- tf.contrib.layers.batch_norm(center=False, scale=False, eps=1e-3, decay=0.999)  (isprs:655-663) -----
  * drs_stats_reduce : partial[nrows][C][2] (fp32) -> sums[C][2] (fp64), fixed order; scratch holds
  *                    drs_colsum_scratch_doubles(2*C) doubles.  Under data parallelism the caller all-reduces
@@ -79,6 +107,10 @@ int drs_bn_eval_coeffs(const float* moving_mean, const float* moving_var, int C,
  * position 0..8 of the first maximum, which the backward pass routes gradients to (TF MaxPoolGrad). */
 int drs_bn_act_pool_forward(const float* z, int B, int S, int C, const float* mean_rstd, float alpha, int pool,
                             float* out, int P_out, int ld_out, int coff_out, unsigned char* argmax, void* stream);
+/* the same, also (out != NULL) or only (out == NULL) writing the split-bf16 terms of the output slab (layout above) */
+int drs_bn_act_pool_forward_terms(const float* z, int B, int S, int C, const float* mean_rstd, float alpha, int pool,
+                                  float* out, int P_out, int ld_out, int coff_out, unsigned char* argmax,
+                                  unsigned short* terms, int nterms, void* stream);
 
 /* ---- backward of the block above ----------------------------------------------------------------------
  * reduce: ga [B*S*S][ld_ga]+coff_ga = gradient wrt the block output -> gxhat [B*S*S][C] (gradient wrt the
@@ -91,6 +123,10 @@ int drs_bn_backward_reduce(const float* ga, int ld_ga, int coff_ga, const float*
 int drs_bn_backward_apply(const float* gxhat, const float* z, int B, int S, int C, const float* mean_rstd,
                           const double* sums, double count, float* gz, int P_out, int ld_out, int coff_out,
                           void* stream);
+/* the same, also (gz != NULL) or only (gz == NULL) writing the split-bf16 terms of the haloed gradient */
+int drs_bn_backward_apply_terms(const float* gxhat, const float* z, int B, int S, int C, const float* mean_rstd,
+                                const double* sums, double count, float* gz, int P_out, int ld_out, int coff_out,
+                                unsigned short* terms, int nterms, void* stream);
 
 /* ---- tf.nn.avg_pool(k x k, stride 1, SAME) of the `_avgpool` variant (isprs:753-758, 818-854) ------------------
  * forward: in [B*S*S][C] -> interior of a haloed view (halo zeroed), divisor = pixels of the window inside the image;

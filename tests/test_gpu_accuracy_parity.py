@@ -25,17 +25,24 @@ def test_heldout_pixel_accuracy_matches_cpu_oracle():
     held, held_lab = make_tile(96, 96, ch, K, seed=4, n_seeds=12, class_signal=0.35)
     mean, std = tile[:, :, :3].mean(axis=(0, 1)), tile[:, :, :3].std(axis=(0, 1))
     inst = grid_instances(160, 160, S, 8, B * steps, seed=1)
-    d = DilatedNet(net_type, ch, K, wd, b_max=B, s_max=S, device=DEV, seed=21)
+    # the exact-fp32 arithmetic and the two split-bf16 arithmetics of the convolutions, all from the same initial weights
+    ariths = ["f32", "bf16x3", "bf16x6"]
+    nets = [DilatedNet(net_type, ch, K, wd, b_max=B, s_max=S, device=DEV, seed=21, arith=a) for a in ariths]
+    d = nets[0]
     o = T.OracleNet(net_type, ch, K, dtype=np.float32, seed=0)
     o.p = {n: d.get_variable(n) for n in d.variable_names()}
     t = TorchNet(net_type, ch, K, params=o.p, dtype=torch.float32)
     pool = P.TilePool([tile], [lab], DEV)
     loss_d, loss_t = [], []
+    loss_x = {a: [] for a in ariths[1:]}
     for i in range(steps):
         rows = inst[i * B:(i + 1) * B]
         P.crop_to_net(d, pool, rows, S, mean, std)
         out = d.train_step(B, S, lr)
         loss_d.append(d.loss_value(out["loss_parts"]))
+        for a, dn in zip(ariths[1:], nets[1:]):
+            P.crop_to_net(dn, pool, rows, S, mean, std)
+            loss_x[a].append(dn.loss_value(dn.train_step(B, S, lr)["loss_parts"]))
         x, y, _ = H.dynamically_create_patches([tile], [lab], rows, S, is_train=False)
         x = x.copy()
         H.normalize_images(x, list(mean) + [0, 0], list(std) + [1, 1])
@@ -43,6 +50,10 @@ def test_heldout_pixel_accuracy_matches_cpu_oracle():
         loss_t.append(lt)
     print("loss HIP  ", np.round(loss_d[::30], 4))
     print("loss torch", np.round(loss_t[::30], 4))
+    for a in loss_x:
+        print("loss %-6s" % a, np.round(loss_x[a][::30], 4))
+        assert abs(loss_x[a][0] - loss_t[0]) < 1e-4 * loss_t[0]
+        assert abs(np.mean(loss_x[a][-5:]) - np.mean(loss_t[-5:])) < 0.05 * np.mean(loss_t[-5:])
     assert np.mean(loss_d[-5:]) < 0.7 * loss_d[0]                          # it learns
     assert abs(loss_d[0] - loss_t[0]) < 1e-4 * loss_t[0]                   # identical start
     assert abs(np.mean(loss_d[-5:]) - np.mean(loss_t[-5:])) < 0.05 * np.mean(loss_t[-5:])
@@ -62,3 +73,8 @@ def test_heldout_pixel_accuracy_matches_cpu_oracle():
     acc_t = float((pred_t == held_lab).mean())
     print("held-out pixel accuracy: HIP %.4f  CPU oracle %.4f  (chance %.3f)" % (acc_d, acc_t, 1.0 / K))
     assert acc_t > 2.0 / K and abs(acc_d - acc_t) < 0.03
+    for a, dn in zip(ariths[1:], nets[1:]):
+        pred_x, _ = loops.predict_tile(dn, hpool, 0, S, B, mean, std)
+        acc_x = float((pred_x.cpu().numpy() == held_lab).mean())
+        print("held-out pixel accuracy: HIP %s %.4f" % (a, acc_x))
+        assert abs(acc_x - acc_t) < 0.03
