@@ -21,7 +21,7 @@ SIGNATURES = {
     "drs_split_terms": (_i, [_p, _sz, _i, _p, _p]),
     "drs_filter_split": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "drs_conv_forward_split": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _i, _p]),
-    "drs_conv_wgrad_split_splits": (_i, [_i, _i, _i, _i, _i, _i]),
+    "drs_conv_wgrad_split_splits": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "drs_conv_wgrad_split": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p]),
     "drs_colsum_scratch_doubles": (_i, [_i]),
     "drs_stats_reduce": (_i, [_p, _i, _i, _p, _p, _p]),

@@ -427,7 +427,8 @@ int g_variant = 1;      // 0: register-staged tiles, 1: LDS-DMA double-buffered 
 template <int BM, int BN, int WM, int WN, int NS>
 int launch_split(const SplitConvArgs& a, hipStream_t st) {
   const int mt = (a.M + BM - 1) / BM, nt = a.Cout / BN;
-  if (g_variant == 0) DRS_LAUNCH((conv_split_kernel<BM, BN, WM, WN, NS>), dim3(mt * nt), dim3(256), 0, st, a);
+  // three terms: the double-buffered LDS-DMA image (96 KiB) leaves one workgroup per CU; the register-staged kernel keeps two
+  if (g_variant == 0 || NS == 3) DRS_LAUNCH((conv_split_kernel<BM, BN, WM, WN, NS>), dim3(mt * nt), dim3(256), 0, st, a);
   else DRS_LAUNCH((conv_split_dma_kernel<BM, BN, WM, WN, NS>), dim3(mt * nt), dim3(256), 0, st, a);
   return DRS_LAUNCH_CHECK();
 }
@@ -435,7 +436,7 @@ int launch_split(const SplitConvArgs& a, hipStream_t st) {
 template <int NS>
 int dispatch_split(const SplitConvArgs& a, hipStream_t st) {
   if (a.Cout % 128 == 0) return launch_split<128, 128, 2, 2, NS>(a, st);
-  if (a.Cout % 192 == 0 && g_variant != 0) return launch_split<128, 192, 2, 2, NS>(a, st);
+  if (a.Cout % 192 == 0) return launch_split<128, 192, 2, 2, NS>(a, st);
   return launch_split<256, 64, 4, 1, NS>(a, st);
 }
 
@@ -828,8 +829,9 @@ int launch_wgrad_split(const SplitWgradArgs& a, int nsplit, hipStream_t st) {
   return DRS_LAUNCH_CHECK();
 }
 
-int split_wgrad_rows(int rows, int Pg) {
-  if (g_variant != 0 && Pg > 0) return 128;       // the LDS-DMA kernel: 128-row tiles only, zeros fetched from the halo
+inline bool wgrad_dma(int nterms, int Pg) { return g_variant != 0 && nterms == 2 && Pg > 0; }
+int split_wgrad_rows(int rows, int Pg, int nterms) {
+  if (wgrad_dma(nterms, Pg)) return 128;       // the LDS-DMA kernel: 128-row tiles only, zeros fetched from the halo
   const int n128 = (rows + 127) / 128;
   return (double)rows / (n128 * 128.0) >= 0.85 ? 128 : 64;
 }
@@ -843,7 +845,7 @@ extern "C" {
 /* development switch between kernel variants (not part of the documented ABI) */
 int drs_debug_variant(int v) { const int old = g_variant; if (v >= 0) g_variant = v; return old; }
 
-int drs_split_conv_mtile(int cout) { return (cout % 128 == 0 || (cout % 192 == 0 && g_variant != 0)) ? 128 : 256; }
+int drs_split_conv_mtile(int cout) { return (cout % 128 == 0 || cout % 192 == 0) ? 128 : 256; }
 
 int drs_split_terms(const float* src, size_t n, int nterms, unsigned short* terms, void* stream) {
   if (!src || !terms || (n & 31) || (nterms != 2 && nterms != 3)) return DRS_ERR_ARG;
@@ -881,11 +883,11 @@ int drs_conv_forward_split(const unsigned short* in, int B, int S, int P, int ld
   return nsplit == 2 ? dispatch_split<2>(a, st) : dispatch_split<3>(a, st);
 }
 
-int drs_conv_wgrad_split_splits(int B, int S, int k, int cin, int cout, int Pg) {
+int drs_conv_wgrad_split_splits(int B, int S, int k, int cin, int cout, int Pg, int nterms) {
   const long long M = (long long)B * S * S;
-  const int tr = split_wgrad_rows(k * k * cin, Pg), to = cout % 128 == 0 ? 128 : 64;
+  const int tr = split_wgrad_rows(k * k * cin, Pg, nterms), to = cout % 128 == 0 ? 128 : 64;
   int ntile = ((k * k * cin + tr - 1) / tr) * (cout / to);
-  if (g_variant != 0 && Pg > 0 && to == 64 && cout > 64) ntile = ((k * k * cin + tr - 1) / tr) * ((cout / 128) + 1);   // 128-wide tiles + one 64-wide
+  if (wgrad_dma(nterms, Pg) && to == 64 && cout > 64) ntile = ((k * k * cin + tr - 1) / tr) * ((cout / 128) + 1);   // 128-wide tiles + one 64-wide
   const int nchunks = (int)((M + 31) / 32);
   int want = 1536 / ntile;
   int maxs = (nchunks + 31) / 32;
@@ -907,30 +909,28 @@ int drs_conv_wgrad_split(const unsigned short* x, int B, int S, int Px, int ld_x
   a.x = x; a.S = S; a.Px = Px; a.ld_x = ld_x; a.coff_x = coff_x;
   a.g = g; a.Pg = Pg; a.ld_g = ld_g; a.coff_g = coff_g; a.M = (int)M;
   a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout; a.slab = slab;
-  const int tr = split_wgrad_rows(k * k * cin, Pg), to = cout % 128 == 0 ? 128 : 64;
+  const int tr = split_wgrad_rows(k * k * cin, Pg, nsplit_terms), to = cout % 128 == 0 ? 128 : 64;
   a.ntr = (k * k * cin + tr - 1) / tr; a.nto = cout / to;
-  const int nsplit = drs_conv_wgrad_split_splits(B, S, k, cin, cout, Pg);
+  const int nsplit = drs_conv_wgrad_split_splits(B, S, k, cin, cout, Pg, nsplit_terms);
   const int nchunks = (int)((M + 31) / 32);
   a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
   a.o_base = 0;
   hipStream_t st = (hipStream_t)stream;
   int rc = DRS_OK;
-  if (g_variant != 0 && Pg > 0) {
+  if (wgrad_dma(nsplit_terms, Pg)) {
     // 128-wide column tiles wherever they fit, one 64-wide tile for what is left (Cout = 64, 192)
     const int n128 = cout / 128, rest = cout % 128;
     if (n128) {
       a.nto = n128; a.o_base = 0;
       const dim3 grid(nsplit * a.ntr * a.nto);
-      if (nsplit_terms == 2) DRS_LAUNCH((wgrad_split_dma_kernel<128, 2>), grid, dim3(256), 0, st, a);
-      else DRS_LAUNCH((wgrad_split_dma_kernel<128, 3>), grid, dim3(256), 0, st, a);
+      DRS_LAUNCH((wgrad_split_dma_kernel<128, 2>), grid, dim3(256), 0, st, a);
       rc = DRS_LAUNCH_CHECK();
     }
     if (rest && rc == DRS_OK) {
       a.nto = 1; a.o_base = n128 * 128;
       const dim3 grid(nsplit * a.ntr);
-      if (nsplit_terms == 2) DRS_LAUNCH((wgrad_split_dma_kernel<64, 2>), grid, dim3(128), 0, st, a);
-      else DRS_LAUNCH((wgrad_split_dma_kernel<64, 3>), grid, dim3(128), 0, st, a);
+      DRS_LAUNCH((wgrad_split_dma_kernel<64, 2>), grid, dim3(128), 0, st, a);
       rc = DRS_LAUNCH_CHECK();
     }
   } else if (nsplit_terms == 2) {

@@ -222,7 +222,7 @@ class DilatedNet(object):
                        for i, L in enumerate(p.layers)]
             self.wd_planes = [torch.zeros(ns * L.k * L.k * L.cin * L.cout, **i16) if self._split_dgrad(i) else None
                        for i, L in enumerate(p.layers)]
-            slab = max([slab] + [_lib.query("drs_conv_wgrad_split_splits", B, S, L.k, L.cin_k, L.cout, L.halo) * L.k * L.k * L.cin_k * L.cout
+            slab = max([slab] + [_lib.query("drs_conv_wgrad_split_splits", B, S, L.k, L.cin_k, L.cout, L.halo, self.ns) * L.k * L.k * L.cin_k * L.cout
                                  for i, L in enumerate(p.layers) if self._split_fwd(i)])
         self.slab = torch.zeros(slab, **f32)
         self.w0pad = torch.zeros(L0.k * L0.k * L0.cin_k * L0.cout, **f32)

@@ -74,7 +74,7 @@ int drs_filter_pad_cin(const float* w, float* wp, int k, int cin, int cin_pad, i
  *   drs_conv_forward_split : drs_conv_forward on terms (`in`, `w`); cout % 64 == 0.  The input-gradient pass is the same
  *                        call on the terms of the haloed output gradient with wd and pad_before := pad_after.
  *                        stats_partial rows hold drs_split_conv_mtile(cout) pixels.
- *   drs_conv_wgrad_split : drs_conv_wgrad on terms; slab = drs_conv_wgrad_split_splits(..., Pg) * k*k*cin*cout floats.
+ *   drs_conv_wgrad_split : drs_conv_wgrad on terms; slab = drs_conv_wgrad_split_splits(..., Pg, nterms) * k*k*cin*cout floats.
  *                        With Pg > 0 pixels past the end read the gradient slab's first halo pixel (zeros). */
 int drs_split_conv_mtile(int cout);
 int drs_split_terms(const float* src, size_t n, int nterms, unsigned short* terms, void* stream);
@@ -83,7 +83,7 @@ int drs_filter_split(const float* w, int k, int cin, int cin_pad, int cout, int 
 int drs_conv_forward_split(const unsigned short* in, int B, int S, int P, int ld_in, int coff_in, const unsigned short* w,
                            const float* bias, int k, int rate, int pad_before, int cin, int cout, float* out, int ld_out,
                            int coff_out, int accumulate, float* stats_partial, int nterms, void* stream);
-int drs_conv_wgrad_split_splits(int B, int S, int k, int cin, int cout, int Pg);
+int drs_conv_wgrad_split_splits(int B, int S, int k, int cin, int cout, int Pg, int nterms);
 int drs_conv_wgrad_split(const unsigned short* x, int B, int S, int Px, int ld_x, int coff_x, const unsigned short* g,
                          int Pg, int ld_g, int coff_g, int k, int rate, int pad_before, int cin, int cin_real, int cout,
                          float* slab, float* grad, int nterms, void* stream);

@@ -118,7 +118,7 @@ def test_conv_split_forward_dgrad_wgrad(lib, k, rate, cin, cout, B, S, ns):
     if cin % 64 == 0:       # the input-gradient GEMM has N = cin; narrower layers stay on the exact-fp32 kernel
         lib.call("drs_conv_forward_split", gp.data_ptr(), B, S, P, cout, 0, wg.data_ptr(), None, k, rate, pa, cout, cin,
                  gx.data_ptr(), cin, 0, 0, None, ns, stream())
-    nsplit = lib.query("drs_conv_wgrad_split_splits", B, S, k, cin, cout, P)
+    nsplit = lib.query("drs_conv_wgrad_split_splits", B, S, k, cin, cout, P, ns)
     slab = torch.zeros(nsplit * nw, dtype=torch.float32, device=DEV)
     gw = torch.zeros(nw, dtype=torch.float32, device=DEV)
     lib.call("drs_conv_wgrad_split", xp.data_ptr(), B, S, P, cin + 32, 32, gp.data_ptr(), P, cout, 0, k, rate, pb, cin,
@@ -147,7 +147,7 @@ def test_conv1_band_padding_split(lib, ns):
     lib.call("drs_conv_forward_split", xp.data_ptr(), B, S, 2, 32, 0, wf.data_ptr(), None, k, 1, 2, 32, cout,
              out.data_ptr(), cout, 0, 0, None, ns, stream())
     gp, ng = planes(lib, padded(g, 2), ns)
-    nsplit = lib.query("drs_conv_wgrad_split_splits", B, S, k, 32, cout, 2)
+    nsplit = lib.query("drs_conv_wgrad_split_splits", B, S, k, 32, cout, 2, ns)
     slab = torch.zeros(nsplit * nwp, dtype=torch.float32, device=DEV)
     gw = torch.zeros(k * k * C * cout, dtype=torch.float32, device=DEV)
     lib.call("drs_conv_wgrad_split", xp.data_ptr(), B, S, 2, 32, 0, gp.data_ptr(), 2, cout, 0, k, 1, 2, 32, C, cout,

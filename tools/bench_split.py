@@ -50,7 +50,7 @@ def main(B=128, S=64, net="dilated_grsl_rate8", layers=None):
         tot["f32"] = tot.get("f32", 0) + ms
         zref = z.clone()
         # fp64 reference on a sample of output rows would need the oracle; compare against the exact-fp32 kernel instead
-        for ns, variant in [(2, 0), (2, 1)]:
+        for ns, variant in [(int(a[0]), int(a[1])) for a in os.environ.get('SPLIT_CASES', '20,21').split(',')]:
             _lib.load().drs_debug_variant(variant)
             xp = torch.zeros(ns * n, dtype=torch.int16, device=DEV)
             wf = torch.zeros(ns * w.numel(), dtype=torch.int16, device=DEV)
@@ -67,7 +67,7 @@ def main(B=128, S=64, net="dilated_grsl_rate8", layers=None):
             g = torch.randn(ng, device=DEV)
             gp = torch.zeros(ns * ng, dtype=torch.int16, device=DEV)
             _lib.call("drs_split_terms", g.data_ptr(), ng, ns, gp.data_ptr(), st)
-            nsp = _lib.query("drs_conv_wgrad_split_splits", B, S, L.k, L.cin_k, L.cout, P)
+            nsp = _lib.query("drs_conv_wgrad_split_splits", B, S, L.k, L.cin_k, L.cout, P, ns)
             slab = torch.zeros(nsp * w.numel(), device=DEV)
             gw = torch.zeros(w.numel(), device=DEV)
             ms = timeit(lambda: _lib.call("drs_conv_wgrad_split", xp.data_ptr(), B, S, P, L.cin_k, 0, gp.data_ptr(), P, L.cout, 0, L.k, L.rate,
