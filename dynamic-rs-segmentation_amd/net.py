@@ -487,6 +487,27 @@ class DilatedNet(object):
         # reverse loop over the conv blocks.  The gradient wrt a slab is first SET (by the classifier, or by the first block
         # that propagates into it) and then ACCUMULATED into by every further reader of that slab (dense / squeeze nets)
         written = {p.feat}
+
+        def filter_gradient(i):
+            """filter gradient of conv block i from its input slab and the gz currently in place; then, under data parallelism,
+            the gradient bucket that this layer completes"""
+            nonlocal bucket_hi
+            L = p.layers[i]
+            xin, Pin, ldin, cin_off = self._in_view(i)
+            goff, _ = p.offsets[L.name + "/weights"]
+            if self._split_fwd(i):
+                self._k("conv_wgrad", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_wgrad_split", _ptr(self.aplanes[L.src]),
+                        B, S, Pin, ldin, cin_off, _ptr(self.gzplanes), L.halo, L.cout, 0, L.k, L.rate,
+                        L.pad_b, L.cin_k, L.cin, L.cout, _ptr(self.slab), self.grads[goff:].data_ptr(), self.ns, st)
+            else:
+                self._k("conv_wgrad", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_wgrad", _ptr(xin), B, S, Pin, ldin, cin_off,
+                        _ptr(self.gz), L.halo, L.cout, 0, L.k, L.rate, L.pad_b, L.cin_k, L.cin, L.cout, _ptr(self.slab),
+                        self.grads[goff:].data_ptr(), st)
+            if self.comm.world > 1 and i > 0 and (nL - i) % 2 == 0:                   # every second layer: one bucket
+                pending.append(self.comm.all_reduce_sum_async(self.grads[goff:bucket_hi]))
+                bucket_hi = goff
+
+        deferred_wgrad = None
         for i in reversed(range(nL)):
             L = p.layers[i]
             gcur, ldc, cc = self.gbuf[L.dst], p.buffers[L.dst][0], L.dst_coff
@@ -509,7 +530,12 @@ class DilatedNet(object):
                     _ptr(self.gxh), _ptr(self.partial), st)
             _lib.call("drs_stats_reduce", _ptr(self.partial), _lib.query("drs_bn_backward_rows", B, S, L.cout, 1 if mx else 0), L.cout,
                       _ptr(self.sums), _ptr(self.colsum_scratch), st)
-            self.comm.all_reduce_sum(self.sums[:2 * L.cout])
+            # sync batch norm: the all-reduce of (sum g, sum g*xhat) runs on the collective's stream while this stream computes the
+            # filter gradient of the block above (deferred to here: it only needs that block's gz, which is still in place)
+            h_bn = self.comm.all_reduce_sum_async(self.sums[:2 * L.cout])
+            if deferred_wgrad is not None:
+                deferred_wgrad()
+            self.comm.wait([h_bn])
             if self._split_fwd(i):
                 keep = self.debug is not None or (L.src != "x0" and not self._split_dgrad(i))     # an fp32 kernel still reads gz
                 self._k("bn_bwd_apply", M * L.cout * (8.0 + 2.0 * self.ns + (4.0 if keep else 0.0)), "drs_bn_backward_apply_terms",
@@ -521,19 +547,6 @@ class DilatedNet(object):
             if self.debug is not None:      # diagnostics only: per-layer snapshots for tests/diag_net.py
                 self.debug["gxh%d" % i] = self.gxh[:M * L.cout].clone()
                 self.debug["gz%d" % i] = self.gz[:B * (S + 2 * L.halo) ** 2 * L.cout].clone()
-            xin, Pin, ldin, cin_off = self._in_view(i)
-            goff, _ = p.offsets[L.name + "/weights"]
-            if self._split_fwd(i):
-                self._k("conv_wgrad", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_wgrad_split", _ptr(self.aplanes[L.src]),
-                        B, S, Pin, ldin, cin_off, _ptr(self.gzplanes), L.halo, L.cout, 0, L.k, L.rate,
-                        L.pad_b, L.cin_k, L.cin, L.cout, _ptr(self.slab), self.grads[goff:].data_ptr(), self.ns, st)
-            else:
-                self._k("conv_wgrad", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_wgrad", _ptr(xin), B, S, Pin, ldin, cin_off,
-                        _ptr(self.gz), L.halo, L.cout, 0, L.k, L.rate, L.pad_b, L.cin_k, L.cin, L.cout, _ptr(self.slab),
-                        self.grads[goff:].data_ptr(), st)
-            if self.comm.world > 1 and i > 0 and (nL - i) % 2 == 0:                   # every second layer: one bucket
-                pending.append(self.comm.all_reduce_sum_async(self.grads[goff:bucket_hi]))
-                bucket_hi = goff
             if L.src != "x0":
                 acc = 1 if L.src in written else 0
                 written.add(L.src)
@@ -545,6 +558,8 @@ class DilatedNet(object):
                     self._k("conv_dgrad", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_forward", _ptr(self.gz), B, S, L.halo, L.cout,
                             0, _ptr(self.wt[i]), None, L.k, L.rate, L.pad_a, L.cout, L.cin, _ptr(self.gbuf[L.src]), p.buffers[L.src][0], 0,
                             acc, None, st)
+            deferred_wgrad = (lambda i=i: filter_gradient(i))
+        deferred_wgrad()
         if self.comm.world > 1:
             pending.append(self.comm.all_reduce_sum_async(self.grads[0:bucket_hi]))      # the remaining (earliest) layers
             pending.append(self.comm.all_reduce_sum_async(self.grads[woff:]))            # classifier, SE layers and every bias (small)
