@@ -33,11 +33,13 @@ def main(fetch_csv, write_csv, out):
         wb = (w[k][1] / w[k][0] * 1024) if k in w else 0.0
         res[k] = dict(launches=f[k][0], fetch_bytes_per_launch=round(fb), write_bytes_per_launch=round(wb),
                       traffic_bytes_per_launch=round(fb + wb))
-    # the dominant kernel of bench.py's roofline: all conv_igemm_kernel launches together
-    conv = [k for k in res if k.startswith("conv_igemm_kernel")]
-    n = sum(res[k]["launches"] for k in conv)
-    res["conv_igemm_kernel (all)"] = dict(launches=n, traffic_bytes_per_launch=round(
-        sum(res[k]["traffic_bytes_per_launch"] * res[k]["launches"] for k in conv) / n))
+    # the dominant kernel of bench.py's roofline: all launches of the forward / input-gradient conv kernel together
+    for fam in ("conv_igemm_kernel", "conv_split_dma"):
+        conv = [k for k in res if k.startswith(fam)]
+        n = sum(res[k]["launches"] for k in conv)
+        if n:
+            res[("conv_split_dma_kernel" if fam == "conv_split_dma" else fam) + " (all)"] = dict(launches=n, traffic_bytes_per_launch=round(
+                sum(res[k]["traffic_bytes_per_launch"] * res[k]["launches"] for k in conv) / n))
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     for k in sorted(res, key=lambda k: -res[k]["traffic_bytes_per_launch"]):
         print("%-48s %4d launches  %8.1f MB/launch" % (k, res[k]["launches"], res[k]["traffic_bytes_per_launch"] / 1e6))
