@@ -4,7 +4,7 @@
 // /root/reference/isprs_dilated_random.py:710-713); what differs is the arithmetic.  Every fp32 operand x is stored
 // as NS bf16 planes x = x_0 + x_1 (+ x_2) (+ residual), each plane the round-to-nearest bf16 of what the previous
 // ones left, and a product a*b is evaluated on the bf16 MFMA pipe (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA
-// rate) as the partial products a_i*b_j with i + j < NS, accumulated in fp32:
+// rate; this file uses the 16x16x32 form in the LDS-DMA kernel) as the partial products a_i*b_j with i + j < NS, accumulated in fp32:
 //   NS = 2 ("bf16x3"):  a0 b0 + a0 b1 + a1 b0                         relative error of a product <= ~2^-16
 //   NS = 3 ("bf16x6"):  a0 b0 + a0 b1 + a1 b0 + a0 b2 + a2 b0 + a1 b1  relative error <= ~2^-25 (below one fp32 ulp)
 // Each bf16 x bf16 product is exact in fp32, so with NS = 3 the only roundings left are those of the fp32
@@ -266,164 +266,10 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const SplitConvArgs a) 
 // one pixel's 32 channels (16 rows per instruction) and the bank spread comes from a swizzle instead of padding: the
 // 16-byte chunk c of row r sits in slot c ^ ((r >> 2) & 3); the DMA realises it by fetching, for LDS slot s, source
 // chunk s ^ ((r >> 2) & 3), and the fragment reads apply the same XOR.  16 consecutive rows at one k-chunk then cover
-// the 16 slots of the 256-byte bank row once.
+// the 16 slots of the 256-byte bank row once.  MFMA shape: v_mfma_f32_16x16x32_bf16 (one 32-deep k-step per K-step; the
+// 32x32x16 form of this kernel costs the same cycles per flop but the chip holds a lower clock on it: -4 % measured).
 template <int BM, int BN, int WM, int WN, int NS>
 __global__ __launch_bounds__(256) void conv_split_dma_kernel(const SplitConvArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)   // the host pass has no LDS-DMA builtin; it only needs the launch stub
-  static_assert(WM * WN == 4, "4 waves");
-  constexpr int WTM = BM / WM, WTN = BN / WN;
-  constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int IA = BM / 64, IB = BN / 64;            // DMA instructions per wave per plane (16 rows each)
-  constexpr int ROWB = BK * 2;                         // bytes per image row (64)
-  constexpr int PLANE_A = BM * ROWB, PLANE_B = BN * ROWB;
-  constexpr int STAGE = NS * (PLANE_A + PLANE_B);
-
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
-
-  const int t = threadIdx.x;
-  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int li = lane & 31, h = lane >> 5;
-  const int wm = wave / WN, wn = wave % WN;
-
-  const int ntn = a.Cout / BN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (tile / ntn) * BM;
-  const int n0 = (tile % ntn) * BN;
-
-  const int Sp = a.S + 2 * a.P;
-  const int Ktot = a.k * a.k * a.Cin;
-  // DMA lane roles: instruction j of a plane covers image rows 16 j .. 16 j + 15; lane l fills row 16 j + (l >> 2), slot l & 3
-  const int drow = lane >> 2;
-  const int dchk = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;           // source chunk (elements) for this lane's slot
-  uint32_t offA[IA], offB[IB];
-#pragma unroll
-  for (int i = 0; i < IA; ++i) {
-    int p = m0 + 16 * (wave + 4 * i) + drow;
-    p = p < a.M ? p : a.M - 1;
-    offA[i] = NS * (padded_pixel_off(p, a.S, a.P, a.ld_in, a.rcpS, a.rcpSS, -a.pad, -a.pad) + (uint32_t)a.coff_in) + (uint32_t)dchk;
-  }
-#pragma unroll
-  for (int i = 0; i < IB; ++i) offB[i] = (uint32_t)(NS * (n0 + 16 * (wave + 4 * i) + drow) * Ktot + dchk);
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-  const int cpt = a.Cin / BK;
-  const int nks = a.k * a.k * cpt;
-  int lu = 0, lv = 0, lc = 0;
-
-  auto issue = [&](int ks, int stage) {
-    const uint32_t soff = (uint32_t)(NS * ((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK));
-    unsigned char* sb = lds + stage * STAGE;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-#pragma unroll
-      for (int i = 0; i < IA; ++i)
-        __builtin_amdgcn_global_load_lds(a.in + offA[i] + soff + 32 * s,
-                                         (__attribute__((address_space(3))) void*)(sb + s * PLANE_A + (wave + 4 * i) * 1024), 16, 0, 0);
-#pragma unroll
-      for (int i = 0; i < IB; ++i)
-        __builtin_amdgcn_global_load_lds(a.w + offB[i] + NS * ks * BK + 32 * s,
-                                         (__attribute__((address_space(3))) void*)(sb + NS * PLANE_A + s * PLANE_B + (wave + 4 * i) * 1024), 16, 0, 0);
-    }
-    if (++lc == cpt) { lc = 0; if (++lv == a.k) { lv = 0; ++lu; } }
-  };
-
-  // fragment read offsets (bytes inside a plane): row * 64 + (chunk ^ ((row >> 2) & 3)) * 16, chunk = 2 kk + h
-  const int sw = (li >> 2) & 3;
-  uint32_t ra[2], rb[2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    ra[kk] = (uint32_t)((wm * WTM + li) * ROWB + (((2 * kk + h) ^ sw) * 16));
-    rb[kk] = (uint32_t)((wn * WTN + li) * ROWB + (((2 * kk + h) ^ sw) * 16));
-  }
-
-  issue(0, 0);
-  __syncthreads();
-  for (int ks = 0; ks < nks; ++ks) {
-    if (ks + 1 < nks) issue(ks + 1, (ks + 1) & 1);
-    const unsigned char* sa = lds + (ks & 1) * STAGE;
-    const unsigned char* sbb = sa + NS * PLANE_A;
-#pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      bf16x8 fa[NS][TM], fb[NS][TN];
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-          fa[s][mi] = *reinterpret_cast<const bf16x8*>(sa + s * PLANE_A + mi * 32 * ROWB + ra[kk]);
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-          fb[s][ni] = *reinterpret_cast<const bf16x8*>(sbb + s * PLANE_B + ni * 32 * ROWB + rb[kk]);
-      }
-#pragma unroll
-      for (int d = NS - 1; d >= 0; --d)
-#pragma unroll
-        for (int i = 0; i <= d; ++i)
-#pragma unroll
-          for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][mi], fb[d - i][ni], acc[mi][ni], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-
-  float s1[TN], s2[TN];
-#pragma unroll
-  for (int ni = 0; ni < TN; ++ni) { s1[ni] = 0.f; s2[ni] = 0.f; }
-#pragma unroll
-  for (int ni = 0; ni < TN; ++ni) {
-    const int col = n0 + wn * WTN + ni * 32 + li;
-    const float bv = a.bias ? a.bias[col] : 0.f;
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < a.M) {
-          float v = acc[mi][ni][r] + bv;
-          float* dst = a.out + (size_t)row * a.ld_out + a.coff_out + col;
-          if (a.accumulate) v += *dst;
-          *dst = v;
-          s1[ni] += v;
-          s2[ni] += v * v;
-        }
-      }
-    }
-  }
-  if (a.stats) {
-    float* red = reinterpret_cast<float*>(lds);
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-      s1[ni] += __shfl_xor(s1[ni], 32);
-      s2[ni] += __shfl_xor(s2[ni], 32);
-      if (h == 0) {
-        const int c = wn * WTN + ni * 32 + li;
-        red[(wm * BN + c) * 2 + 0] = s1[ni];
-        red[(wm * BN + c) * 2 + 1] = s2[ni];
-      }
-    }
-    __syncthreads();
-    if (t < BN) {
-      float u1 = 0.f, u2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) { u1 += red[(w * BN + t) * 2]; u2 += red[(w * BN + t) * 2 + 1]; }
-      float* dst = a.stats + ((size_t)(m0 / BM) * a.Cout + n0 + t) * 2;
-      dst[0] = u1;
-      dst[1] = u2;
-    }
-  }
-#endif
-}
-
-template <int BM, int BN, int WM, int WN, int NS>
-__global__ __launch_bounds__(256) void conv_split_dma16_kernel(const SplitConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass has no LDS-DMA builtin; it only needs the launch stub
   static_assert(WM * WN == 4, "4 waves");
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -574,15 +420,14 @@ __global__ __launch_bounds__(256) void conv_split_dma16_kernel(const SplitConvAr
 #endif
 }
 
-int g_variant = 2;      // 0: register-staged tiles, 1: LDS-DMA double-buffered tiles on 32x32x16 MFMAs, 2: the same on 16x16x32 MFMAs
-                        // (+4 %: the chip holds a higher clock on that shape); development switch, see drs_debug_variant
+int g_variant = 1;      // 0: register-staged tiles everywhere, 1: LDS-DMA double-buffered tiles for the two-term arithmetic
+                        // (development switch, see drs_debug_variant)
 
 template <int BM, int BN, int WM, int WN, int NS>
 int launch_split(const SplitConvArgs& a, hipStream_t st) {
   const int mt = (a.M + BM - 1) / BM, nt = a.Cout / BN;
   // three terms: the double-buffered LDS-DMA image (96 KiB) leaves one workgroup per CU; the register-staged kernel keeps two
   if (g_variant == 0 || NS == 3) DRS_LAUNCH((conv_split_kernel<BM, BN, WM, WN, NS>), dim3(mt * nt), dim3(256), 0, st, a);
-  else if (g_variant == 2) DRS_LAUNCH((conv_split_dma16_kernel<BM, BN, WM, WN, NS>), dim3(mt * nt), dim3(256), 0, st, a);
   else DRS_LAUNCH((conv_split_dma_kernel<BM, BN, WM, WN, NS>), dim3(mt * nt), dim3(256), 0, st, a);
   return DRS_LAUNCH_CHECK();
 }
