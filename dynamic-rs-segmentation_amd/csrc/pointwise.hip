@@ -596,13 +596,18 @@ __global__ __launch_bounds__(256) void classifier_loss_kernel(const ClsArgs a) {
   __shared__ unsigned int confs[KM * KM];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int K = a.K;
+  // a lane owns its CI channels in groups of V consecutive ones, so that a pixel's features move as 16- / 8-byte accesses
+  // (1 KiB / 512 B per wave-instruction instead of 256 B): channel of slot i = (i / V) * 64 V + lane * V + i % V
+  constexpr int V = CI % 4 == 0 ? 4 : (CI % 2 == 0 ? 2 : 1);
+  typedef float fvec __attribute__((ext_vector_type(V)));
+  auto chan = [&](int i) { return (i / V) * 64 * V + lane * V + (i % V); };
   if (threadIdx.x < KM * KM) confs[threadIdx.x] = 0u;
   float wr[CI][KM], dw[CI][KM];
 #pragma unroll
   for (int i = 0; i < CI; ++i)
 #pragma unroll
     for (int k = 0; k < KM; ++k) {
-      wr[i][k] = k < K ? a.w[(size_t)(lane + 64 * i) * K + k] : 0.f;
+      wr[i][k] = k < K ? a.w[(size_t)chan(i) * K + k] : 0.f;
       dw[i][k] = 0.f;
     }
   float bk[KM], db[KM];
@@ -613,21 +618,49 @@ __global__ __launch_bounds__(256) void classifier_loss_kernel(const ClsArgs a) {
   const int p0 = blockIdx.x * a.rows_per_block;
   int pend = p0 + a.rows_per_block;
   pend = pend < a.M ? pend : a.M;
-  for (int p = p0 + wave; p < pend; p += 4) {
-    const uint32_t off = padded_pixel_off(p, a.feat.S, a.feat.P, a.feat.ld, a.rcpS, a.rcpSS, 0, 0) + a.feat.coff;
-    float f[CI];
-#pragma unroll
-    for (int i = 0; i < CI; ++i) f[i] = a.feat.base[off + lane + 64 * i];
-    float lg[KM];
+  // a wave takes PIX consecutive pixels per iteration and issues all their feature loads before the arithmetic of the first:
+  // the kernel is bound by bytes in flight (one pixel = 4 x 256 B per wave), not by its arithmetic
+  constexpr int PIX = 4;
+  auto one_pixel = [&](const int p, const float (&f)[CI]) {
+    // the KM = 8 per-lane partial dot products are summed over the 64 lanes by a halving butterfly: at distance 32 / 16 / 8 a lane
+    // hands its partner the half of its values the partner keeps (4 + 2 + 1 exchanges), then three plain steps finish the one
+    // value left (class 4*b5 + 2*b4 + b3 of the lane id); 10 cross-lane moves per pixel instead of 48, summation order fixed
+    float v8[KM];
 #pragma unroll
     for (int k = 0; k < KM; ++k) {
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < CI; ++i) s += f[i] * wr[i][k];
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-      lg[k] = s + bk[k];
+      v8[k] = s;
     }
+    float v4[4], v2[2], v1;
+    {
+      const bool hi = lane & 32;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float give = hi ? v8[j] : v8[4 + j], keep = hi ? v8[4 + j] : v8[j];
+        v4[j] = keep + __shfl_xor(give, 32);
+      }
+    }
+    {
+      const bool hi = lane & 16;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float give = hi ? v4[j] : v4[2 + j], keep = hi ? v4[2 + j] : v4[j];
+        v2[j] = keep + __shfl_xor(give, 16);
+      }
+    }
+    {
+      const bool hi = lane & 8;
+      const float give = hi ? v2[0] : v2[1], keep = hi ? v2[1] : v2[0];
+      v1 = keep + __shfl_xor(give, 8);
+    }
+    v1 += __shfl_xor(v1, 4);
+    v1 += __shfl_xor(v1, 2);
+    v1 += __shfl_xor(v1, 1);
+    float lg[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) lg[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v1), 8 * k)) + bk[k];     // class k's total lives in lanes 8k .. 8k+7
     // arg-max (first maximum) and softmax over the K live classes; every lane holds the same values
     int am = 0;
     float mx = lg[0];
@@ -639,7 +672,7 @@ __global__ __launch_bounds__(256) void classifier_loss_kernel(const ClsArgs a) {
         for (int k = 0; k < K; ++k) a.logits[(size_t)p * K + k] = lg[k];
       if (a.pred) a.pred[p] = (unsigned char)am;
     }
-    if (!a.labels) continue;
+    if (!a.labels) return;
     const int y = a.labels[p];
     if (lane == 0 && a.conf && (!a.acc_mask || a.acc_mask[p]) && y < K) atomicAdd(&confs[y * KM + am], 1u);
     const bool in_loss = !a.loss_mask || a.loss_mask[p];
@@ -658,24 +691,47 @@ __global__ __launch_bounds__(256) void classifier_loss_kernel(const ClsArgs a) {
     if (in_loss) lsum += (double)(logf(se) + mx - ly);
     if (a.gfeat) {
 #pragma unroll
-      for (int i = 0; i < CI; ++i) {
-        float g = 0.f;
+      for (int gi = 0; gi < CI / V; ++gi) {
+        fvec gv;
 #pragma unroll
-        for (int k = 0; k < KM; ++k) g += dl[k] * wr[i][k];
-        a.gfeat[(size_t)p * a.ld_g + a.coff_g + lane + 64 * i] = g;
+        for (int e = 0; e < V; ++e) {
+          const int i = gi * V + e;
+          float g = 0.f;
 #pragma unroll
-        for (int k = 0; k < KM; ++k) dw[i][k] += f[i] * dl[k];
+          for (int k = 0; k < KM; ++k) g += dl[k] * wr[i][k];
+          gv[e] = g;
+#pragma unroll
+          for (int k = 0; k < KM; ++k) dw[i][k] += f[i] * dl[k];
+        }
+        *reinterpret_cast<fvec*>(a.gfeat + (size_t)p * a.ld_g + a.coff_g + gi * 64 * V + lane * V) = gv;
       }
 #pragma unroll
       for (int k = 0; k < KM; ++k) db[k] += dl[k];
     }
+    };
+  for (int pb = p0 + wave * PIX; pb < pend; pb += 4 * PIX) {
+    float f[PIX][CI];
+#pragma unroll
+    for (int j = 0; j < PIX; ++j) {
+      const int p = pb + j < pend ? pb + j : pend - 1;
+      const uint32_t off = padded_pixel_off(p, a.feat.S, a.feat.P, a.feat.ld, a.rcpS, a.rcpSS, 0, 0) + a.feat.coff;
+#pragma unroll
+      for (int g = 0; g < CI / V; ++g) {
+        const fvec v = *reinterpret_cast<const fvec*>(a.feat.base + off + g * 64 * V + lane * V);
+#pragma unroll
+        for (int e = 0; e < V; ++e) f[j][g * V + e] = v[e];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PIX; ++j)
+      if (pb + j < pend) one_pixel(pb + j, f[j]);
   }
   if (!a.labels) return;
   // workgroup reduction in wave order, then one slab row per workgroup
 #pragma unroll
   for (int i = 0; i < CI; ++i)
 #pragma unroll
-    for (int k = 0; k < KM; ++k) red[wave][(i * 64 + lane) * KM + k] = dw[i][k];
+    for (int k = 0; k < KM; ++k) red[wave][chan(i) * KM + k] = dw[i][k];
   if (lane == 0) {
 #pragma unroll
     for (int k = 0; k < KM; ++k) redb[wave][k] = db[k];
