@@ -446,6 +446,7 @@ int drs_conv_forward(const float* in, int B, int S, int P, int ld_in, int coff_i
   if (P < (k - 1) * rate - pad_before) return DRS_ERR_ARG;          // halo must cover pad_after too
   const long long M = (long long)B * S * S;
   if (M <= 0 || M >= (1 << 24)) return DRS_ERR_ARG;
+  if ((long long)B * (S + 2 * P) * (S + 2 * P) * ld_in >= (1LL << 32)) return DRS_ERR_ARG;      // 32-bit element offsets
   ConvArgs a;
   a.in = in; a.S = S; a.P = P; a.ld_in = ld_in; a.coff_in = coff_in; a.M = (int)M;
   a.w = w; a.bias = bias; a.out = out; a.ld_out = ld_out; a.coff_out = coff_out; a.stats = stats_partial;
@@ -482,6 +483,8 @@ int drs_conv_wgrad(const float* x, int B, int S, int Px, int ld_x, int coff_x, c
   if (!x || !g || !slab || !grad || cin % 32 || cout % 32 || cin_real > cin) return DRS_ERR_ARG;
   const long long M = (long long)B * S * S;
   if (M <= 0 || M >= (1 << 24)) return DRS_ERR_ARG;
+  if ((long long)B * (S + 2 * Px) * (S + 2 * Px) * ld_x >= (1LL << 32)) return DRS_ERR_ARG;     // 32-bit element offsets
+  if ((long long)B * (S + 2 * Pg) * (S + 2 * Pg) * ld_g >= (1LL << 31)) return DRS_ERR_ARG;     // bit 31 flags a row past the end
   WgradArgs a;
   a.x = x; a.S = S; a.Px = Px; a.ld_x = ld_x; a.coff_x = coff_x;
   a.g = g; a.Pg = Pg; a.ld_g = ld_g; a.coff_g = coff_g; a.M = (int)M;

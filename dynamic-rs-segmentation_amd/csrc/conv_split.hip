@@ -873,6 +873,9 @@ int drs_conv_forward_split(const unsigned short* in, int B, int S, int P, int ld
   if (P < (k - 1) * rate - pad_before || (ld_in & 31) || (coff_in & 31) || (nsplit != 2 && nsplit != 3)) return DRS_ERR_ARG;
   const long long M = (long long)B * S * S;
   if (M <= 0 || M >= (1 << 24)) return DRS_ERR_ARG;
+  // the kernels address with 32-bit element offsets: the whole term image of the input slab and the filter must stay below 2^32
+  if ((long long)B * (S + 2 * P) * (S + 2 * P) * ld_in * nsplit >= (1LL << 32)) return DRS_ERR_ARG;
+  if ((long long)k * k * cin * cout * nsplit >= (1LL << 32)) return DRS_ERR_ARG;
   SplitConvArgs a;
   a.in = in; a.S = S; a.P = P; a.ld_in = ld_in; a.coff_in = coff_in; a.M = (int)M;
   a.w = w; a.bias = bias; a.out = out; a.ld_out = ld_out; a.coff_out = coff_out;
@@ -904,6 +907,8 @@ int drs_conv_wgrad_split(const unsigned short* x, int B, int S, int Px, int ld_x
   if ((ld_x & 31) || (coff_x & 31) || (ld_g & 31) || (coff_g & 31) || (nsplit_terms != 2 && nsplit_terms != 3)) return DRS_ERR_ARG;
   const long long M = (long long)B * S * S;
   if (M <= 0 || M >= (1 << 24)) return DRS_ERR_ARG;
+  if ((long long)B * (S + 2 * Px) * (S + 2 * Px) * ld_x * nsplit_terms >= (1LL << 32)) return DRS_ERR_ARG;   // 32-bit element offsets
+  if ((long long)B * (S + 2 * Pg) * (S + 2 * Pg) * ld_g * nsplit_terms >= (1LL << 31)) return DRS_ERR_ARG;   // bit 31 flags a row
   SplitWgradArgs a;
   a.x = x; a.S = S; a.Px = Px; a.ld_x = ld_x; a.coff_x = coff_x;
   a.g = g; a.Pg = Pg; a.ld_g = ld_g; a.coff_g = coff_g; a.M = (int)M;

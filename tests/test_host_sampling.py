@@ -128,3 +128,31 @@ def test_missing_library_fails_loudly(monkeypatch):
         _lib.load()
     with pytest.raises(_lib.DrsError):
         _lib.call("drs_conv_mtile", 64)
+
+
+def test_entry_points_reject_bad_arguments_before_any_launch():
+    """Argument validation is host code: every rejected call returns DRS_ERR_ARG (raised as DrsError) without touching the
+    device, so it can be exercised without a GPU.  Pointers are dummies; a call that passed validation would launch."""
+    import pytest
+    from drs_amd import _lib
+    _lib.load()
+    p = 0x1000
+    bad = [
+        ("drs_conv_forward", (p, 2, 8, 2, 64, 0, p, p, 3, 2, 2, 48, 64, p, 64, 0, 0, None, None)),               # cin % 32
+        ("drs_conv_forward", (p, 2, 8, 1, 64, 0, p, p, 3, 2, 2, 64, 64, p, 64, 0, 0, None, None)),               # halo < pad
+        ("drs_conv_forward", (p, 4096, 4096, 2, 64, 0, p, p, 3, 2, 2, 64, 64, p, 64, 0, 0, None, None)),         # B*S*S >= 2^24
+        ("drs_conv_forward_split", (p, 2, 8, 2, 64, 0, p, p, 3, 2, 2, 64, 96, p, 96, 0, 0, None, 2, None)),     # cout % 64
+        ("drs_conv_forward_split", (p, 2, 8, 2, 64, 0, p, p, 3, 2, 2, 64, 64, p, 64, 0, 0, None, 4, None)),     # nterms
+        ("drs_conv_forward_split", (p, 2, 8, 2, 72, 0, p, p, 3, 2, 2, 64, 64, p, 64, 0, 0, None, 2, None)),     # ld % 32
+        ("drs_conv_wgrad_split", (p, 2, 8, 2, 64, 0, p, 2, 64, 8, 3, 2, 2, 64, 64, 64, p, p, 2, None)),         # coff_g % 32
+        ("drs_split_terms", (p, 100, 2, p, None)),                                                              # n % 32
+        ("drs_filter_split", (p, 3, 5, 24, 64, 2, p, None, None)),                                              # cin_pad % 32
+        ("drs_bn_act_pool_forward_terms", (p, 2, 8, 64, p, 0.1, 1, None, 2, 64, 0, None, None, 2, None)),       # no terms
+        ("drs_bn_backward_apply_terms", (p, p, 2, 8, 64, p, p, 128.0, None, 2, 72, 0, p, 2, None)),             # ld % 32
+    ]
+    for name, args in bad:
+        with pytest.raises(_lib.DrsError):
+            _lib.call(name, *args)
+    assert _lib.query("drs_split_conv_mtile", 256) == 128 and _lib.query("drs_split_conv_mtile", 192) == 128
+    assert _lib.query("drs_split_conv_mtile", 64) == 256
+    assert _lib.query("drs_conv_wgrad_split_splits", 64, 64, 3, 256, 256, 8, 2) >= 1
