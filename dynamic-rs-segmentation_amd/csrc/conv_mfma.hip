@@ -278,9 +278,11 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   };
 
   f32x4 rx[NX], rg[NG];
+  uint32_t gflag[NG];
   // branch-free: every offset in the tables is a valid address (rows past the end are clamped); what must be zero
-  // (G rows of pixels >= M, X rows of a ragged tile) is zeroed by a select after the load.  All table reads are
-  // issued before the first global load.
+  // (G rows of pixels >= M, X rows of a ragged tile) is zeroed by a select when the registers are written to LDS, not
+  // here: a select right behind the loads would put the wait for them in front of the MFMAs of the current chunk, i.e.
+  // in front of what the prefetch is there to overlap.  All table reads are issued before the first global load.
   auto gload = [&](int chunk) {
     const uint32_t* tx = tabx[chunk & 1];
     const uint32_t* tg = tabg[chunk & 1];
@@ -294,18 +296,15 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
 #pragma unroll
     for (int i = 0; i < NG; ++i) rg[i] = *reinterpret_cast<const f32x4*>(a.g + (og[i] & 0x7fffffffu) + gconst);
 #pragma unroll
-    for (int i = 0; i < NG; ++i)
-      if (og[i] & 0x80000000u) rg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!row_ok) {
-#pragma unroll
-      for (int i = 0; i < NX; ++i) rx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int i = 0; i < NG; ++i) gflag[i] = og[i] & 0x80000000u;
   };
   auto lstore = [&]() {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) *reinterpret_cast<f32x4*>(&Xs[(xpix + XPS * i) * LDX + (t % XQ) * 4]) = rx[i];
+    for (int i = 0; i < NX; ++i)
+      *reinterpret_cast<f32x4*>(&Xs[(xpix + XPS * i) * LDX + (t % XQ) * 4]) = row_ok ? rx[i] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < NG; ++i) *reinterpret_cast<f32x4*>(&Gs[(gpix + GPS * i) * LDG + (t % GQ) * 4]) = rg[i];
+    for (int i = 0; i < NG; ++i)
+      *reinterpret_cast<f32x4*>(&Gs[(gpix + GPS * i) * LDG + (t % GQ) * 4]) = gflag[i] ? f32x4{0.f, 0.f, 0.f, 0.f} : rg[i];
   };
 
   if (cbeg < cend) {

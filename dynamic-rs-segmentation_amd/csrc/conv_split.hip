@@ -530,6 +530,7 @@ __global__ __launch_bounds__((TR / 64) * (TO / 64) * 64) void wgrad_split_kernel
   };
 
   u32x4 rx[NS][NX], rg[NS][NG];
+  uint32_t gflag[NG];
   auto gload = [&](int chunk) {
     const uint32_t* tx = tabx[chunk & 1];
     const uint32_t* tg = tabg[chunk & 1];
@@ -546,23 +547,19 @@ __global__ __launch_bounds__((TR / 64) * (TO / 64) * 64) void wgrad_split_kernel
       for (int i = 0; i < NG; ++i) rg[s][i] = *reinterpret_cast<const u32x4*>(a.g + NS * (og[i] & 0x7fffffffu) + gconst + 32 * s);
     }
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-#pragma unroll
-      for (int i = 0; i < NG; ++i)
-        if (og[i] & 0x80000000u) rg[s][i] = u32x4{0u, 0u, 0u, 0u};
-      if (!row_ok) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) rx[s][i] = u32x4{0u, 0u, 0u, 0u};
-      }
-    }
+    for (int i = 0; i < NG; ++i) gflag[i] = og[i] & 0x80000000u;
   };
+  // rows that must read as zero (G rows of pixels >= M, X rows of a ragged tile) are zeroed here, at the LDS write, so that
+  // nothing waits on the loads before the MFMAs of the current chunk
   auto lstore = [&]() {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) *reinterpret_cast<u32x4*>(&Xs[(s * BP + xpix + XPS * i) * LDX + (t % XQ) * 8]) = rx[s][i];
+      for (int i = 0; i < NX; ++i)
+        *reinterpret_cast<u32x4*>(&Xs[(s * BP + xpix + XPS * i) * LDX + (t % XQ) * 8]) = row_ok ? rx[s][i] : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int i = 0; i < NG; ++i) *reinterpret_cast<u32x4*>(&Gs[(s * BP + gpix + GPS * i) * LDG + (t % GQ) * 8]) = rg[s][i];
+      for (int i = 0; i < NG; ++i)
+        *reinterpret_cast<u32x4*>(&Gs[(s * BP + gpix + GPS * i) * LDG + (t % GQ) * 8]) = gflag[i] ? u32x4{0u, 0u, 0u, 0u} : rg[s][i];
     }
   };
 
