@@ -32,11 +32,12 @@ struct ConvArgs {
   float* stats;         // [mtiles][Cout][2] partial (sum, sumsq) of the output rows of each M tile, or null
   int k, rate, pad, Cin, Cout;
   int accumulate;
+  int skip_halo_taps;
   float rcpS, rcpSS;
 };
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, BM == 256 ? 3 : 1) void conv_igemm_kernel(const ConvArgs a) {   // 256-row tiles: hold the allocation to 3 waves per SIMD
   static_assert(WM * WN == 4, "4 waves");
   constexpr int LDB = BN + 4;
   constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
@@ -80,9 +81,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   const int cpt = a.Cin / BK;                 // K-steps per filter tap
-  const int nks = a.k * a.k * cpt;
+  // tap rows that fall entirely into the zero halo for this tile's pixel rows are not multiplied at all (exact zeros)
+  int u_lo, u_hi;
+  live_tap_rows(m0, BM, a.M, a.S, a.k, a.rate, a.pad, a.rcpS, a.rcpSS, u_lo, u_hi);
+  if (!a.skip_halo_taps) { u_lo = 0; u_hi = a.k; }
+  const int nks = (u_hi - u_lo) * a.k * cpt;                           // K-steps of the live tap rows, counted from 0
+  const float* wlive = a.w + (size_t)u_lo * a.k * a.Cin * a.Cout;      // filter rows of the first live tap row
   f32x4 ra[NA], rb[NB];
-  int lu = 0, lv = 0, lc = 0;                 // (tap row, tap col, channel chunk) of the next K-step to fetch
+  int lu = u_lo, lv = 0, lc = 0;              // (tap row, tap col, channel chunk) of the next K-step to fetch
 
   auto gload = [&](int ks) {
     const uint32_t soff = (uint32_t)((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK);
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a.in + offA[i] + soff);
 #pragma unroll
     for (int i = 0; i < NB; ++i)
-      rb[i] = *reinterpret_cast<const f32x4*>(a.w + (size_t)(ks * BK + brow + BROWS * i) * a.Cout + n0 + bcol);
+      rb[i] = *reinterpret_cast<const f32x4*>(wlive + (size_t)(ks * BK + brow + BROWS * i) * a.Cout + n0 + bcol);
     if (++lc == cpt) { lc = 0; if (++lv == a.k) { lv = 0; ++lu; } }
   };
   auto lstore = [&]() {
@@ -420,6 +426,8 @@ int launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t st) {
   return DRS_LAUNCH_CHECK();
 }
 
+int g_skip_halo_taps = 1;    // development switch (drs_debug_skip_taps): 0 multiplies the all-zero tap rows too
+
 int pick_tile(int c) { return c % 128 == 0 ? 128 : (c % 64 == 0 ? 64 : 32); }
 
 // wgrad row tile: rows = k*k*Cin may be cut anywhere (a tile spans taps, the last one may be ragged), so take the
@@ -434,6 +442,9 @@ int pick_wgrad_rows(int rows) {
 }  // namespace
 
 extern "C" {
+
+/* development switch (not part of the documented ABI) */
+int drs_debug_skip_taps(int v) { const int old = g_skip_halo_taps; if (v >= 0) g_skip_halo_taps = v; return old; }
 
 // M-tile height the forward/dgrad kernel uses for this Cout (= rows per BN-statistics slab row)
 int drs_conv_mtile(int cout) { return pick_tile(cout) == 128 ? 128 : 256; }
@@ -451,6 +462,7 @@ int drs_conv_forward(const float* in, int B, int S, int P, int ld_in, int coff_i
   a.w = w; a.bias = bias; a.out = out; a.ld_out = ld_out; a.coff_out = coff_out; a.stats = stats_partial;
   a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout; a.accumulate = accumulate;
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
+  a.skip_halo_taps = g_skip_halo_taps;
   hipStream_t st = (hipStream_t)stream;
   switch (pick_tile(cout)) {
     case 128: return launch_conv<128, 128, 2, 2>(a, st);

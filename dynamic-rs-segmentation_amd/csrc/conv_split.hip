@@ -154,9 +154,12 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const SplitConvArgs a) 
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   const int cpt = a.Cin / BK;
-  const int nks = a.k * a.k * cpt;
+  int u_lo, u_hi;                               // tap rows that are not entirely in the zero halo for this tile (drs_common.hpp)
+  live_tap_rows(m0, BM, a.M, a.S, a.k, a.rate, a.pad, a.rcpS, a.rcpSS, u_lo, u_hi);
+  const int ks0 = u_lo * a.k * cpt;
+  const int nks = u_hi * a.k * cpt;
   u32x4 ra[NS][NA], rb[NS][NB];
-  int lu = 0, lv = 0, lc = 0;
+  int lu = u_lo, lv = 0, lc = 0;
 
   auto gload = [&](int ks) {
     const uint32_t soff = (uint32_t)(NS * ((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK));
@@ -179,11 +182,11 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const SplitConvArgs a) 
     }
   };
 
-  gload(0);
+  gload(ks0);
   lstore();
   __syncthreads();
   const int arow = wm * WTM + li, brow = wn * WTN + li;
-  for (int ks = 0; ks < nks; ++ks) {
+  for (int ks = ks0; ks < nks; ++ks) {
     if (ks + 1 < nks) gload(ks + 1);
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
@@ -315,8 +318,11 @@ __global__ __launch_bounds__(256) void conv_split_dma_kernel(const SplitConvArgs
       for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.f;
 
   const int cpt = a.Cin / BK;
-  const int nks = a.k * a.k * cpt;
-  int lu = 0, lv = 0, lc = 0;
+  int u_lo, u_hi;                               // tap rows that are not entirely in the zero halo for this tile (drs_common.hpp)
+  live_tap_rows(m0, BM, a.M, a.S, a.k, a.rate, a.pad, a.rcpS, a.rcpSS, u_lo, u_hi);
+  const int ks0 = u_lo * a.k * cpt;
+  const int nks = u_hi * a.k * cpt;
+  int lu = u_lo, lv = 0, lc = 0;
 
   auto issue = [&](int ks, int stage) {
     const uint32_t soff = (uint32_t)(NS * ((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK));
@@ -340,9 +346,9 @@ __global__ __launch_bounds__(256) void conv_split_dma_kernel(const SplitConvArgs
   const uint32_t ra = (uint32_t)((wm * WTM + li) * ROWB + ((h ^ sw) * 16));
   const uint32_t rb = (uint32_t)((wn * WTN + li) * ROWB + ((h ^ sw) * 16));
 
-  issue(0, 0);
+  issue(ks0, ks0 & 1);
   __syncthreads();
-  for (int ks = 0; ks < nks; ++ks) {
+  for (int ks = ks0; ks < nks; ++ks) {
     if (ks + 1 < nks) issue(ks + 1, (ks + 1) & 1);
     const unsigned char* sa = lds + (ks & 1) * STAGE;
     const unsigned char* sbb = sa + NS * PLANE_A;

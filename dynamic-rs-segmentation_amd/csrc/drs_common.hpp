@@ -59,6 +59,28 @@ __device__ __forceinline__ uint32_t padded_pixel_off(int p, int S, int P, int ld
   return (uint32_t)(((b * Sp + y + P + dy) * Sp + (x + P + dx))) * (uint32_t)ld;
 }
 
+// Filter-tap rows whose whole input row range lies in the zero halo contribute exact zeros to every pixel of an M tile:
+// for the tile of pixels [m0, m0 + BM) (clipped to M) return the range [lo, hi) of tap rows u, dy = u * rate - pad, for
+// which some pixel row y of the tile has 0 <= y + dy < S.  A tile that crosses an image boundary keeps every tap row.
+// (Rows are skipped, columns are not: a tile spans whole image rows.)  Adding the skipped products would add +-0.
+__device__ __forceinline__ void live_tap_rows(int m0, int BM, int M, int S, int k, int rate, int pad, float rcpS, float rcpSS,
+                                              int& lo, int& hi) {
+  const int p1 = (m0 + BM - 1 < M ? m0 + BM : M) - 1;
+  int b0, r0, b1, r1, y0, y1, x;
+  divmod24(m0, S * S, rcpSS, b0, r0);
+  divmod24(p1, S * S, rcpSS, b1, r1);
+  divmod24(r0, S, rcpS, y0, x);
+  divmod24(r1, S, rcpS, y1, x);
+  if (b0 != b1) { y0 = 0; y1 = S - 1; }
+  // u * rate - pad >= -y1   and   u * rate - pad <= S - 1 - y0
+  const int a = pad - y1;
+  lo = a > 0 ? (a + rate - 1) / rate : 0;
+  const int bnum = S - 1 - y0 + pad;
+  hi = bnum / rate + 1;
+  hi = hi < k ? hi : k;
+  if (lo >= hi) { lo = 0; hi = k; }        // cannot happen for SAME padding (the centre taps always land inside); stay safe
+}
+
 // Bijective XCD-aware remap of a 1-D grid: blocks b and b+8 share an XCD (round-robin dispatch), so give every
 // XCD one contiguous chunk of the logical tile order (neighbouring tiles then share that XCD's 4 MiB L2).
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

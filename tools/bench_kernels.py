@@ -48,6 +48,16 @@ def main(B=128, S=64, net="dilated_grsl_rate8", which="fwd,dgrad,wgrad"):
         gw = torch.zeros(L.k * L.k * L.cin_k * L.cout, device=DEV)
         fl = 2.0 * M * L.k * L.k * L.cin_k * L.cout
         row = "%-6s k%d r%d %3d->%3d " % (L.name, L.k, L.rate, L.cin_k, L.cout)
+        if "ab" in which:       # A/B of the halo-tap skipping inside one process (same device, interleaved)
+            f = lambda: _lib.call("drs_conv_forward", x.data_ptr(), B, S, P, L.cin_k, 0, w.data_ptr(), bias.data_ptr(), L.k, L.rate,
+                                  L.pad_b, L.cin_k, L.cout, z.data_ptr(), L.cout, 0, 0, stats.data_ptr(), st)
+            res = {0: [], 1: []}
+            for rep in range(4):
+                for v in (0, 1):
+                    _lib.load().drs_debug_skip_taps(v)
+                    res[v].append(timeit(f, reps=3))
+            _lib.load().drs_debug_skip_taps(1)
+            row += " fwd all taps %6.3f ms | skipping halo tap rows %6.3f ms (%+.1f %%)" % (min(res[0]), min(res[1]), 100 * (min(res[1]) / min(res[0]) - 1))
         if "fwd" in which:
             ms = timeit(lambda: _lib.call("drs_conv_forward", x.data_ptr(), B, S, P, L.cin_k, 0, w.data_ptr(), bias.data_ptr(), L.k, L.rate,
                                           L.pad_b, L.cin_k, L.cout, z.data_ptr(), L.cout, 0, 0, stats.data_ptr(), st))
