@@ -32,7 +32,6 @@ struct ConvArgs {
   float* stats;         // [mtiles][Cout][2] partial (sum, sumsq) of the output rows of each M tile, or null
   int k, rate, pad, Cin, Cout;
   int accumulate;
-  int skip_halo_taps;
   float rcpS, rcpSS;
 };
 
@@ -84,7 +83,6 @@ __global__ __launch_bounds__(256, BM == 256 ? 3 : 1) void conv_igemm_kernel(cons
   // tap rows that fall entirely into the zero halo for this tile's pixel rows are not multiplied at all (exact zeros)
   int u_lo, u_hi;
   live_tap_rows(m0, BM, a.M, a.S, a.k, a.rate, a.pad, a.rcpS, a.rcpSS, u_lo, u_hi);
-  if (!a.skip_halo_taps) { u_lo = 0; u_hi = a.k; }
   const int nks = (u_hi - u_lo) * a.k * cpt;                           // K-steps of the live tap rows, counted from 0
   const float* wlive = a.w + (size_t)u_lo * a.k * a.Cin * a.Cout;      // filter rows of the first live tap row
   f32x4 ra[NA], rb[NB];
@@ -216,6 +214,7 @@ struct WgradArgs {
   float* slab;               // [nsplit][k*k*Cin][Cout]
   int chunks_per_split;      // 32-pixel chunks per split
   int ntr, nto;
+  int skip_halo;
   float rcpS, rcpSS;
 };
 
@@ -270,16 +269,25 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   const int cbeg = split * a.chunks_per_split;
   int cend = cbeg + a.chunks_per_split;
   cend = cend < nchunks_total ? cend : nchunks_total;
+  // pixel rows that meet only halo zeros for this tile's tap rows are neither fetched nor multiplied: the chunk sequence jumps
+  // over them (drs_common.hpp); chunks are taken in increasing order, so a step's sums are in the same order as without the jump
+  int live_lo, live_hi;
+  {
+    const int rlast = (R0 + TR < rows_all ? R0 + TR : rows_all) - 1;
+    live_pixel_range(R0, rlast, a.Cin, a.k, a.rate, a.pad, a.S, a.skip_halo, live_lo, live_hi);
+  }
+  const int S2 = a.S * a.S;
+  auto next_chunk = [&](int c) { return next_live_chunk(c, S2, a.rcpSS, live_lo, live_hi); };
 
   // the pixel -> padded-offset arithmetic (two divisions per pixel) is done once per chunk by BP threads, not by
-  // every thread for every load: the first BP threads fill the tables for chunk `chunk` into slot `chunk & 1`
-  auto fill_tables = [&](int chunk) {
+  // every thread for every load: the first BP threads fill the tables for chunk `chunk` into slot `slot`
+  auto fill_tables = [&](int chunk, int slot) {
     if (t < BP && chunk < cend) {
       const int p = chunk * BP + t;
       const int pc = p < a.M ? p : a.M - 1;                    // clamped X rows meet a zero G row
-      tabx[chunk & 1][t] = padded_pixel_off(pc, a.S, a.Px, a.ld_x, a.rcpS, a.rcpSS, -a.pad, -a.pad);
+      tabx[slot][t] = padded_pixel_off(pc, a.S, a.Px, a.ld_x, a.rcpS, a.rcpSS, -a.pad, -a.pad);
       // bit 31 flags a pixel past the end (its G row must read as zero); the offset itself stays a valid address
-      tabg[chunk & 1][t] = padded_pixel_off(pc, a.S, a.Pg, a.ld_g, a.rcpS, a.rcpSS, 0, 0) | (p < a.M ? 0u : 0x80000000u);
+      tabg[slot][t] = padded_pixel_off(pc, a.S, a.Pg, a.ld_g, a.rcpS, a.rcpSS, 0, 0) | (p < a.M ? 0u : 0x80000000u);
     }
   };
 
@@ -289,9 +297,9 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   // (G rows of pixels >= M, X rows of a ragged tile) is zeroed by a select when the registers are written to LDS, not
   // here: a select right behind the loads would put the wait for them in front of the MFMAs of the current chunk, i.e.
   // in front of what the prefetch is there to overlap.  All table reads are issued before the first global load.
-  auto gload = [&](int chunk) {
-    const uint32_t* tx = tabx[chunk & 1];
-    const uint32_t* tg = tabg[chunk & 1];
+  auto gload = [&](int slot) {
+    const uint32_t* tx = tabx[slot];
+    const uint32_t* tg = tabg[slot];
     uint32_t ox[NX], og[NG];
 #pragma unroll
     for (int i = 0; i < NX; ++i) ox[i] = tx[xpix + XPS * i];
@@ -313,17 +321,20 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
       *reinterpret_cast<f32x4*>(&Gs[(gpix + GPS * i) * LDG + (t % GQ) * 4]) = gflag[i] ? f32x4{0.f, 0.f, 0.f, 0.f} : rg[i];
   };
 
-  if (cbeg < cend) {
-    fill_tables(cbeg);
-    fill_tables(cbeg + 1);
+  int ck0 = next_chunk(cbeg - 1);
+  if (ck0 < cend) {
+    int ck1 = next_chunk(ck0);
+    fill_tables(ck0, 0);
+    fill_tables(ck1, 1);
     __syncthreads();
-    gload(cbeg);
+    gload(0);
     lstore();
     __syncthreads();
     const int xr = wr * WTR + li, gc = wc * WTO + li;
-    for (int ch = cbeg; ch < cend; ++ch) {
-      if (ch + 1 < cend) gload(ch + 1);          // reads table slot (ch+1)&1, filled one iteration ago
-      fill_tables(ch + 2);                       // overwrites slot ch&1, last read by gload(ch) one iteration ago
+    for (int it = 0; ck0 < cend; ++it) {
+      const int ck2 = next_chunk(ck1);
+      if (ck1 < cend) gload((it + 1) & 1);        // table slot filled one iteration ago
+      fill_tables(ck2, it & 1);                   // overwrites the slot last read (for chunk ck0) one iteration ago
       {
         // fragments of pixel pair s+1 are read before the MFMAs of pair s are issued (see conv_igemm_kernel)
         float acur[TMr], bcur[TNo], anext[TMr], bnext[TNo];
@@ -355,7 +366,9 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
         }
       }
       __syncthreads();
-      if (ch + 1 < cend) { lstore(); __syncthreads(); }
+      if (ck1 < cend) { lstore(); __syncthreads(); }
+      ck0 = ck1;
+      ck1 = ck2;
     }
   }
   const size_t rows_total = (size_t)a.k * a.k * a.Cin;
@@ -426,7 +439,13 @@ int launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t st) {
   return DRS_LAUNCH_CHECK();
 }
 
-int g_skip_halo_taps = 1;    // development switch (drs_debug_skip_taps): 0 multiplies the all-zero tap rows too
+}  // namespace
+
+int drs_g_skip_halo_taps = 1;
+
+namespace {
+
+int g_wgrad_target = 3072;   // workgroups the pixel split of the filter gradient aims at (development switch drs_debug_wgrad_target)
 
 int pick_tile(int c) { return c % 128 == 0 ? 128 : (c % 64 == 0 ? 64 : 32); }
 
@@ -443,8 +462,10 @@ int pick_wgrad_rows(int rows) {
 
 extern "C" {
 
-/* development switch (not part of the documented ABI) */
-int drs_debug_skip_taps(int v) { const int old = g_skip_halo_taps; if (v >= 0) g_skip_halo_taps = v; return old; }
+/* development switch (not part of the documented ABI): 0 = also multiply the filter taps / pixel chunks that meet only halo zeros */
+int drs_debug_skip_taps(int v) { const int old = drs_g_skip_halo_taps; if (v >= 0) drs_g_skip_halo_taps = v; return old; }
+
+int drs_debug_wgrad_target(int v) { const int old = g_wgrad_target; if (v > 0) g_wgrad_target = v; return old; }
 
 // M-tile height the forward/dgrad kernel uses for this Cout (= rows per BN-statistics slab row)
 int drs_conv_mtile(int cout) { return pick_tile(cout) == 128 ? 128 : 256; }
@@ -462,7 +483,6 @@ int drs_conv_forward(const float* in, int B, int S, int P, int ld_in, int coff_i
   a.w = w; a.bias = bias; a.out = out; a.ld_out = ld_out; a.coff_out = coff_out; a.stats = stats_partial;
   a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout; a.accumulate = accumulate;
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
-  a.skip_halo_taps = g_skip_halo_taps;
   hipStream_t st = (hipStream_t)stream;
   switch (pick_tile(cout)) {
     case 128: return launch_conv<128, 128, 2, 2>(a, st);
@@ -477,10 +497,11 @@ int drs_conv_wgrad_splits(int B, int S, int k, int cin, int cout) {
   const int tr = pick_wgrad_rows(k * k * cin), to = pick_tile(cout);
   const int ntile = ((k * k * cin + tr - 1) / tr) * (cout / to);
   const int nchunks = (int)((M + 31) / 32);
-  // fill the 256 CUs evenly: the largest split count whose workgroup total stays within 6 per CU (rounding up
-  // instead would leave most CUs idle while a few run a 7th workgroup)
-  int want = 1536 / ntile;
-  int maxs = (nchunks + 31) / 32;                   // at least 32 chunks (1024 pixels) per split
+  // about 12 workgroups per CU (4 rounds at 3 resident): with the all-halo chunks skipped the workgroups of a launch differ in
+  // length by up to a quarter, and 2 rounds quantise that away (measured: conv6 3.48 -> 3.01 ms, conv8 5.19 -> 4.85 going from 6
+  // to 12 per CU); but never less than 96 chunks (3072 pixels) per split, below which the fixed cost of a workgroup shows
+  int want = g_wgrad_target / ntile;
+  int maxs = nchunks / 96;
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
@@ -506,6 +527,7 @@ int drs_conv_wgrad(const float* x, int B, int S, int Px, int ld_x, int coff_x, c
   const int nchunks = (int)((M + 31) / 32);
   a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
+  a.skip_halo = drs_g_skip_halo_taps;
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (tr == 128 && to == 128) rc = launch_wgrad<128, 128>(a, nsplit, st);

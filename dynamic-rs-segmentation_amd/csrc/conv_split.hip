@@ -462,6 +462,7 @@ struct SplitWgradArgs {
   int chunks_per_split;
   int ntr, nto;
   int o_base;                // first output column of this launch (Cout = 192 runs as a 128-wide and a 64-wide launch)
+  int skip_halo;
   float rcpS, rcpSS;
 };
 
@@ -526,20 +527,28 @@ __global__ __launch_bounds__((TR / 64) * (TO / 64) * 64) void wgrad_split_kernel
   int cend = cbeg + a.chunks_per_split;
   cend = cend < nchunks_total ? cend : nchunks_total;
 
-  auto fill_tables = [&](int chunk) {
+  // chunks whose pixel rows meet only halo zeros for this tile's tap rows are jumped over (wgrad_kernel in conv_mfma.hip)
+  int live_lo, live_hi;
+  {
+    const int rlast = (R0 + TR < rows_all ? R0 + TR : rows_all) - 1;
+    live_pixel_range(R0, rlast, a.Cin, a.k, a.rate, a.pad, a.S, a.skip_halo, live_lo, live_hi);
+  }
+  const int S2 = a.S * a.S;
+  auto next_chunk = [&](int c) { return next_live_chunk(c, S2, a.rcpSS, live_lo, live_hi); };
+  auto fill_tables = [&](int chunk, int slot) {
     if (t < BP && chunk < cend) {
       const int p = chunk * BP + t;
       const int pc = p < a.M ? p : a.M - 1;
-      tabx[chunk & 1][t] = padded_pixel_off(pc, a.S, a.Px, a.ld_x, a.rcpS, a.rcpSS, -a.pad, -a.pad);
-      tabg[chunk & 1][t] = padded_pixel_off(pc, a.S, a.Pg, a.ld_g, a.rcpS, a.rcpSS, 0, 0) | (p < a.M ? 0u : 0x80000000u);
+      tabx[slot][t] = padded_pixel_off(pc, a.S, a.Px, a.ld_x, a.rcpS, a.rcpSS, -a.pad, -a.pad);
+      tabg[slot][t] = padded_pixel_off(pc, a.S, a.Pg, a.ld_g, a.rcpS, a.rcpSS, 0, 0) | (p < a.M ? 0u : 0x80000000u);
     }
   };
 
   u32x4 rx[NS][NX], rg[NS][NG];
   uint32_t gflag[NG];
-  auto gload = [&](int chunk) {
-    const uint32_t* tx = tabx[chunk & 1];
-    const uint32_t* tg = tabg[chunk & 1];
+  auto gload = [&](int slot) {
+    const uint32_t* tx = tabx[slot];
+    const uint32_t* tg = tabg[slot];
     uint32_t ox[NX], og[NG];
 #pragma unroll
     for (int i = 0; i < NX; ++i) ox[i] = tx[xpix + XPS * i];
@@ -569,11 +578,13 @@ __global__ __launch_bounds__((TR / 64) * (TO / 64) * 64) void wgrad_split_kernel
     }
   };
 
-  if (cbeg < cend) {
-    fill_tables(cbeg);
-    fill_tables(cbeg + 1);
+  int ck0 = next_chunk(cbeg - 1);
+  if (ck0 < cend) {
+    int ck1 = next_chunk(ck0);
+    fill_tables(ck0, 0);
+    fill_tables(ck1, 1);
     __syncthreads();
-    gload(cbeg);
+    gload(0);
     lstore();
     __syncthreads();
     // transposing-read lane roles: group = lane>>4 -> channel block (group&1)*16, pixel block (group>>1)*8;
@@ -583,9 +594,10 @@ __global__ __launch_bounds__((TR / 64) * (TO / 64) * 64) void wgrad_split_kernel
     const int tcol = ((lane >> 4) & 1) * 16 + (l16 & 3) * 4;
     const uint16_t* xbase = Xs + trow * LDX + wr * 64 + tcol;
     const uint16_t* gbase = Gs + trow * LDG + wc * 64 + tcol;
-    for (int ch = cbeg; ch < cend; ++ch) {
-      if (ch + 1 < cend) gload(ch + 1);
-      fill_tables(ch + 2);
+    for (int it = 0; ck0 < cend; ++it) {
+      const int ck2 = next_chunk(ck1);
+      if (ck1 < cend) gload((it + 1) & 1);
+      fill_tables(ck2, it & 1);
 #pragma unroll
       for (int kk = 0; kk < BP / 16; ++kk) {
         bf16x8 fa[NS][2], fb[NS][2];
@@ -613,7 +625,9 @@ __global__ __launch_bounds__((TR / 64) * (TO / 64) * 64) void wgrad_split_kernel
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][mi], fb[d - i][ni], acc[mi][ni], 0, 0, 0);
       }
       __syncthreads();
-      if (ch + 1 < cend) { lstore(); __syncthreads(); }
+      if (ck1 < cend) { lstore(); __syncthreads(); }
+      ck0 = ck1;
+      ck1 = ck2;
     }
   }
   const size_t rows_total = (size_t)rows_all;
@@ -707,17 +721,25 @@ __global__ __launch_bounds__((TO / 64) * 128) void wgrad_split_dma_kernel(const 
   int cend = cbeg + a.chunks_per_split;
   cend = cend < nchunks_total ? cend : nchunks_total;
 
-  auto fill_tables = [&](int chunk) {
+  // chunks whose pixel rows meet only halo zeros for this tile's tap rows are jumped over (wgrad_kernel in conv_mfma.hip)
+  int live_lo, live_hi;
+  {
+    const int rlast = (R0 + TR < rows_all ? R0 + TR : rows_all) - 1;
+    live_pixel_range(R0, rlast, a.Cin, a.k, a.rate, a.pad, a.S, a.skip_halo, live_lo, live_hi);
+  }
+  const int S2 = a.S * a.S;
+  auto next_chunk = [&](int c) { return next_live_chunk(c, S2, a.rcpSS, live_lo, live_hi); };
+  auto fill_tables = [&](int chunk, int slot) {
     if (t < BP && chunk < cend) {
       const int p = chunk * BP + t;
       const int pc = p < a.M ? p : a.M - 1;
-      tabx[chunk & 1][t] = padded_pixel_off(pc, a.S, a.Px, a.ld_x, a.rcpS, a.rcpSS, -a.pad, -a.pad);
-      tabg[chunk & 1][t] = p < a.M ? padded_pixel_off(pc, a.S, a.Pg, a.ld_g, a.rcpS, a.rcpSS, 0, 0) : 0u;   // 0 = a halo pixel: zeros
+      tabx[slot][t] = padded_pixel_off(pc, a.S, a.Px, a.ld_x, a.rcpS, a.rcpSS, -a.pad, -a.pad);
+      tabg[slot][t] = p < a.M ? padded_pixel_off(pc, a.S, a.Pg, a.ld_g, a.rcpS, a.rcpSS, 0, 0) : 0u;   // 0 = a halo pixel: zeros
     }
   };
-  auto issue = [&](int chunk, int stage) {
-    const uint32_t* tx = tabx[chunk & 1];
-    const uint32_t* tg = tabg[chunk & 1];
+  auto issue = [&](int slot, int stage) {       // table slot == LDS stage == parity of the iteration that consumes the chunk
+    const uint32_t* tx = tabx[slot];
+    const uint32_t* tg = tabg[slot];
     unsigned char* sb = lds + stage * STAGE;
     uint32_t ox[IX], og[IG];
 #pragma unroll
@@ -737,7 +759,9 @@ __global__ __launch_bounds__((TO / 64) * 128) void wgrad_split_dma_kernel(const 
     }
   };
 
-  if (cbeg < cend) {
+  int ck0 = next_chunk(cbeg - 1);
+  if (ck0 < cend) {
+    int ck1 = next_chunk(ck0);
     // transposing-read offsets (bytes inside a term tile, kk = 0): lane 4q+p of a 16-lane group addresses pixel row
     // r0 + q, 16-byte chunk c0 + (p >> 1), half p & 1, with r0 = 16 kk + 8 h + 4 j2 and c0 = the group's 16 columns
     const int l16 = lane & 15, q = l16 >> 2, pp = l16 & 3, g1 = (lane >> 4) & 1;
@@ -758,15 +782,16 @@ __global__ __launch_bounds__((TO / 64) * 128) void wgrad_split_dma_kernel(const 
           go[m][j2] = (uint32_t)(GROW * row + 16 * chg + 8 * (pp & 1));
         }
       }
-    fill_tables(cbeg);
-    fill_tables(cbeg + 1);
+    fill_tables(ck0, 0);
+    fill_tables(ck1, 1);
     __syncthreads();
-    issue(cbeg, 0);
+    issue(0, 0);
     __syncthreads();
-    for (int ch = cbeg; ch < cend; ++ch) {
-      const int stage = (ch - cbeg) & 1;
-      if (ch + 1 < cend) issue(ch + 1, stage ^ 1);
-      fill_tables(ch + 2);
+    for (int it = 0; ck0 < cend; ++it) {
+      const int stage = it & 1;
+      const int ck2 = next_chunk(ck1);
+      if (ck1 < cend) issue(stage ^ 1, stage ^ 1);
+      fill_tables(ck2, stage);
       const uint16_t* sx = reinterpret_cast<const uint16_t*>(lds + stage * STAGE);
       const uint16_t* sg = reinterpret_cast<const uint16_t*>(lds + stage * STAGE + NS * XT);
 #pragma unroll
@@ -792,6 +817,8 @@ __global__ __launch_bounds__((TO / 64) * 128) void wgrad_split_dma_kernel(const 
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][mi], fb[d - i][ni], acc[mi][ni], 0, 0, 0);
       }
       __syncthreads();
+      ck0 = ck1;
+      ck1 = ck2;
     }
   }
   const size_t rows_total = (size_t)rows_all;
@@ -894,8 +921,8 @@ int drs_conv_wgrad_split_splits(int B, int S, int k, int cin, int cout, int Pg, 
   int ntile = ((k * k * cin + tr - 1) / tr) * (cout / to);
   if (wgrad_dma(nterms, Pg) && to == 64 && cout > 64) ntile = ((k * k * cin + tr - 1) / tr) * ((cout / 128) + 1);   // 128-wide tiles + one 64-wide
   const int nchunks = (int)((M + 31) / 32);
-  int want = 1536 / ntile;
-  int maxs = (nchunks + 31) / 32;
+  int want = 3072 / ntile;           // see drs_conv_wgrad_splits (conv_mfma.hip)
+  int maxs = nchunks / 96;
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
@@ -923,6 +950,7 @@ int drs_conv_wgrad_split(const unsigned short* x, int B, int S, int Px, int ld_x
   a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
   a.o_base = 0;
+  a.skip_halo = drs_g_skip_halo_taps;
   hipStream_t st = (hipStream_t)stream;
   int rc = DRS_OK;
   if (wgrad_dma(nsplit_terms, Pg)) {

@@ -81,6 +81,32 @@ __device__ __forceinline__ void live_tap_rows(int m0, int BM, int M, int S, int 
   if (lo >= hi) { lo = 0; hi = k; }        // cannot happen for SAME padding (the centre taps always land inside); stay safe
 }
 
+// Filter gradient: a tile of filter rows belongs to tap rows u_first .. u_last; pixel rows y whose shifted rows y + u*rate - pad
+// all fall outside the image meet only halo zeros in X.  [lo, hi) = the pixel range (inside one image of S*S pixels) of the rows
+// that do meet image data; everything outside contributes exact zeros and is never fetched.
+__device__ __forceinline__ void live_pixel_range(int row_first, int row_last, int Cin, int k, int rate, int pad, int S, int enable,
+                                                 int& lo, int& hi) {
+  const int dy_min = (row_first / Cin / k) * rate - pad, dy_max = (row_last / Cin / k) * rate - pad;
+  int ylo = -dy_max > 0 ? -dy_max : 0;
+  int yhi = S - dy_min < S ? S - dy_min : S;
+  if (!enable || ylo >= yhi) { ylo = 0; yhi = S; }
+  lo = ylo * S;
+  hi = yhi * S;
+}
+
+// first 32-pixel chunk after chunk c that contains a pixel of some image's live range [b*S2 + lo, b*S2 + hi)
+__device__ __forceinline__ int next_live_chunk(int c, int S2, float rcpSS, int lo, int hi) {
+  const int p = 32 * (c + 1);
+  int b, r;
+  divmod24(p, S2, rcpSS, b, r);
+  if (r + 31 >= lo && r < hi) return c + 1;           // meets the live rows of image b
+  if (r + 31 >= S2 + lo) return c + 1;                // ... or reaches into those of image b + 1
+  return ((r < lo ? b : b + 1) * S2 + lo) >> 5;       // the chunk holding the first live pixel ahead
+}
+
+// development switch shared by the convolution kernels (drs_debug_skip_taps): 0 = multiply the all-halo taps / chunks too
+extern int drs_g_skip_halo_taps;
+
 // Bijective XCD-aware remap of a 1-D grid: blocks b and b+8 share an XCD (round-robin dispatch), so give every
 // XCD one contiguous chunk of the logical tile order (neighbouring tiles then share that XCD's 4 MiB L2).
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

@@ -58,6 +58,26 @@ def main(B=128, S=64, net="dilated_grsl_rate8", which="fwd,dgrad,wgrad"):
                     res[v].append(timeit(f, reps=3))
             _lib.load().drs_debug_skip_taps(1)
             row += " fwd all taps %6.3f ms | skipping halo tap rows %6.3f ms (%+.1f %%)" % (min(res[0]), min(res[1]), 100 * (min(res[1]) / min(res[0]) - 1))
+        if "wsp" in which:      # filter-gradient time against the number of workgroups the pixel split aims at
+            for target in (1536, 2304, 3072, 4608):
+                _lib.load().drs_debug_wgrad_target(target)
+                ns2 = _lib.query("drs_conv_wgrad_splits", B, S, L.k, L.cin_k, L.cout)
+                slab2 = torch.zeros(ns2 * L.k * L.k * L.cin_k * L.cout, device=DEV)
+                ms = timeit(lambda: _lib.call("drs_conv_wgrad", x.data_ptr(), B, S, P, L.cin_k, 0, g.data_ptr(), P, L.cout, 0, L.k, L.rate, L.pad_b,
+                                              L.cin_k, L.cin_k, L.cout, slab2.data_ptr(), gw.data_ptr(), st), reps=5)
+                row += " | %d: %d splits %6.3f ms" % (target, ns2, ms)
+                del slab2
+            _lib.load().drs_debug_wgrad_target(3072)
+        if "wab" in which:      # A/B of skipping the all-halo pixel chunks in the filter gradient, inside one process
+            f = lambda: _lib.call("drs_conv_wgrad", x.data_ptr(), B, S, P, L.cin_k, 0, g.data_ptr(), P, L.cout, 0, L.k, L.rate, L.pad_b,
+                                  L.cin_k, L.cin_k, L.cout, slab.data_ptr(), gw.data_ptr(), st)
+            res = {0: [], 1: []}
+            for rep in range(4):
+                for v in (0, 1):
+                    _lib.load().drs_debug_skip_taps(v)
+                    res[v].append(timeit(f, reps=3))
+            _lib.load().drs_debug_skip_taps(1)
+            row += " wgrad all chunks %6.3f ms | skipping all-halo chunks %6.3f ms (%+.1f %%)" % (min(res[0]), min(res[1]), 100 * (min(res[1]) / min(res[0]) - 1))
         if "fwd" in which:
             ms = timeit(lambda: _lib.call("drs_conv_forward", x.data_ptr(), B, S, P, L.cin_k, 0, w.data_ptr(), bias.data_ptr(), L.k, L.rate,
                                           L.pad_b, L.cin_k, L.cout, z.data_ptr(), L.cout, 0, 0, stats.data_ptr(), st))
