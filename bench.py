@@ -98,9 +98,27 @@ def cpu_baseline(seconds_budget=25.0):
         if step >= 2 and (time.time() - t_start > seconds_budget or len(times) >= 5):
             break
     med = float(np.median(times))
-    return dict(value=B / med, unit="patches/s", cores=ncores, kind="port",
+    # one-thread figure: one more step of the same batch with a single intra-op thread
+    torch.set_num_threads(1)
+    rows = inst[:B]
+    t0 = time.time()
+    x, y, m = H.dynamically_create_patches([tile], [lab], rows, PATCH, is_train=True)
+    H.normalize_images(x, mean, std)
+    _, pred = net.train_step(x.astype(np.float32), y, LR, WD)
+    H.calc_accuracy_by_crop(y, pred, track, m, CLASSES)
+    one = time.time() - t0
+    torch.set_num_threads(ncores)
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return dict(value=B / med, unit="patches/s", cores=ncores, kind="port", cpu_model=model, value_1_thread=round(B / one, 3),
                 sample="%d timed steps (1 warm-up) of batch %d, same net / 64x64x5 patches / host crop+augment+normalise+"
-                       "confusion; median step %.2f s" % (len(times), B, med))
+                       "confusion; median step %.2f s; one further step with 1 thread %.2f s" % (len(times), B, med, one))
 
 
 def main():
