@@ -32,10 +32,14 @@ struct ConvArgs {
   float* stats;         // [mtiles][Cout][2] partial (sum, sumsq) of the output rows of each M tile, or null
   int k, rate, pad, Cin, Cout;
   int accumulate;
+  int skip_halo;
   float rcpS, rcpSS;
 };
 
-template <int BM, int BN, int WM, int WN>
+// PACK: the input has fewer than 32 channels (conv1: 3..5 bands in an 8-channel slab).  A K-step is then 32 / Cin consecutive
+// filter taps x Cin channels instead of one tap x 32 channels, so the contraction is k*k*Cin long rather than k*k*32 (conv1: 224
+// instead of 800); every thread adds the offset of ITS tap.  The filter is [round_up(k*k*Cin, 32)][Cout] with zero tail rows.
+template <int BM, int BN, int WM, int WN, bool PACK = false>
 __global__ __launch_bounds__(256, BM == 256 ? 3 : 1) void conv_igemm_kernel(const ConvArgs a) {   // 256-row tiles: hold the allocation to 3 waves per SIMD
   static_assert(WM * WN == 4, "4 waves");
   constexpr int LDB = BN + 4;
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(256, BM == 256 ? 3 : 1) void conv_igemm_kernel(cons
   for (int i = 0; i < NA; ++i) {
     int p = m0 + (t >> 3) + 32 * i;
     p = p < a.M ? p : a.M - 1;
-    offA[i] = padded_pixel_off(p, a.S, a.P, a.ld_in, a.rcpS, a.rcpSS, -a.pad, -a.pad) + (uint32_t)(a.coff_in + (t & 7) * 4);
+    offA[i] = padded_pixel_off(p, a.S, a.P, a.ld_in, a.rcpS, a.rcpSS, -a.pad, -a.pad) + (uint32_t)(a.coff_in + (PACK ? 0 : (t & 7) * 4));
   }
   const int brow = t / (BN / 4), bcol = (t % (BN / 4)) * 4;
 
@@ -83,19 +87,30 @@ __global__ __launch_bounds__(256, BM == 256 ? 3 : 1) void conv_igemm_kernel(cons
   // tap rows that fall entirely into the zero halo for this tile's pixel rows are not multiplied at all (exact zeros)
   int u_lo, u_hi;
   live_tap_rows(m0, BM, a.M, a.S, a.k, a.rate, a.pad, a.rcpS, a.rcpSS, u_lo, u_hi);
-  const int nks = (u_hi - u_lo) * a.k * cpt;                           // K-steps of the live tap rows, counted from 0
+  if (PACK || !a.skip_halo) { u_lo = 0; u_hi = a.k; }
+  const int nks = PACK ? (a.k * a.k * a.Cin + BK - 1) / BK : (u_hi - u_lo) * a.k * cpt;   // K-steps (of the live tap rows), from 0
   const float* wlive = a.w + (size_t)u_lo * a.k * a.Cin * a.Cout;      // filter rows of the first live tap row
   f32x4 ra[NA], rb[NB];
   int lu = u_lo, lv = 0, lc = 0;              // (tap row, tap col, channel chunk) of the next K-step to fetch
 
   auto gload = [&](int ks) {
-    const uint32_t soff = (uint32_t)((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK);
+    uint32_t soff;
+    if (PACK) {     // this thread's 4 channels belong to tap (32 ks + 4 (t & 7)) / Cin; taps past the last meet zero filter rows
+      const int kidx = ks * BK + (t & 7) * 4;
+      int tap = kidx / a.Cin;
+      const int c = kidx - tap * a.Cin;
+      tap = tap < a.k * a.k ? tap : a.k * a.k - 1;
+      const int u = tap / a.k, v = tap - u * a.k;
+      soff = (uint32_t)((u * a.rate * Sp + v * a.rate) * a.ld_in + c);
+    } else {
+      soff = (uint32_t)((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK);
+    }
 #pragma unroll
     for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a.in + offA[i] + soff);
 #pragma unroll
     for (int i = 0; i < NB; ++i)
       rb[i] = *reinterpret_cast<const f32x4*>(wlive + (size_t)(ks * BK + brow + BROWS * i) * a.Cout + n0 + bcol);
-    if (++lc == cpt) { lc = 0; if (++lv == a.k) { lv = 0; ++lu; } }
+    if (!PACK) { if (++lc == cpt) { lc = 0; if (++lv == a.k) { lv = 0; ++lu; } } }
   };
   auto lstore = [&]() {
 #pragma unroll
@@ -428,7 +443,8 @@ __global__ void pad_cin_kernel(const float* __restrict__ w, float* __restrict__ 
 template <int BM, int BN, int WM, int WN>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
   const int mt = (a.M + BM - 1) / BM, nt = a.Cout / BN;
-  DRS_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN>), dim3(mt * nt), dim3(256), 0, st, a);
+  if (a.Cin < BK) DRS_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, true>), dim3(mt * nt), dim3(256), 0, st, a);
+  else DRS_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN>), dim3(mt * nt), dim3(256), 0, st, a);
   return DRS_LAUNCH_CHECK();
 }
 
@@ -445,7 +461,7 @@ int drs_g_skip_halo_taps = 1;
 
 namespace {
 
-int g_wgrad_target = 3072;   // workgroups the pixel split of the filter gradient aims at (development switch drs_debug_wgrad_target)
+int g_wgrad_target = 1536;   // workgroups the pixel split of the filter gradient aims at (development switch drs_debug_wgrad_target)
 
 int pick_tile(int c) { return c % 128 == 0 ? 128 : (c % 64 == 0 ? 64 : 32); }
 
@@ -473,7 +489,9 @@ int drs_conv_mtile(int cout) { return pick_tile(cout) == 128 ? 128 : 256; }
 int drs_conv_forward(const float* in, int B, int S, int P, int ld_in, int coff_in, const float* w, const float* bias,
                      int k, int rate, int pad_before, int cin, int cout, float* out, int ld_out, int coff_out,
                      int accumulate, float* stats_partial, void* stream) {
-  if (!in || !w || !out || cin % 32 || cout % 32 || k < 1 || rate < 1 || P < pad_before) return DRS_ERR_ARG;
+  // cin: a multiple of 32, or 8 / 16 (few-band input: several taps share a K-step; w then has round_up(k*k*cin, 32) rows)
+  if (!in || !w || !out || (cin % 32 && cin != 8 && cin != 16) || cout % 32 || k < 1 || rate < 1 || P < pad_before) return DRS_ERR_ARG;
+  if (cin < 32 && (ld_in % 4 || coff_in % 4)) return DRS_ERR_ARG;
   if (P < (k - 1) * rate - pad_before) return DRS_ERR_ARG;          // halo must cover pad_after too
   const long long M = (long long)B * S * S;
   if (M <= 0 || M >= (1 << 24)) return DRS_ERR_ARG;
@@ -483,6 +501,7 @@ int drs_conv_forward(const float* in, int B, int S, int P, int ld_in, int coff_i
   a.w = w; a.bias = bias; a.out = out; a.ld_out = ld_out; a.coff_out = coff_out; a.stats = stats_partial;
   a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout; a.accumulate = accumulate;
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
+  a.skip_halo = drs_skip_halo_taps_fwd(M, cout);
   hipStream_t st = (hipStream_t)stream;
   switch (pick_tile(cout)) {
     case 128: return launch_conv<128, 128, 2, 2>(a, st);
@@ -497,11 +516,13 @@ int drs_conv_wgrad_splits(int B, int S, int k, int cin, int cout) {
   const int tr = pick_wgrad_rows(k * k * cin), to = pick_tile(cout);
   const int ntile = ((k * k * cin + tr - 1) / tr) * (cout / to);
   const int nchunks = (int)((M + 31) / 32);
-  // about 12 workgroups per CU (4 rounds at 3 resident): with the all-halo chunks skipped the workgroups of a launch differ in
-  // length by up to a quarter, and 2 rounds quantise that away (measured: conv6 3.48 -> 3.01 ms, conv8 5.19 -> 4.85 going from 6
-  // to 12 per CU); but never less than 96 chunks (3072 pixels) per split, below which the fixed cost of a workgroup shows
-  int want = g_wgrad_target / ntile;
-  int maxs = nchunks / 96;
+  // fill the 256 CUs evenly.  6 workgroups per CU (2 rounds at 3 resident) where a launch has few tiles or few pixels; twice that
+  // where it has many tiles and pixels: with the all-halo chunks skipped its workgroups differ in length by up to a quarter and 2
+  // rounds quantise the gain away (measured at B = 128: conv6 3.48 -> 3.01 ms, conv8 5.19 -> 4.85; conv3, 8 tiles, loses 6 %).
+  // Never less than 32 chunks (1024 pixels) per split.
+  const int target = (ntile >= 24 && nchunks >= 8192) ? 2 * g_wgrad_target : g_wgrad_target;
+  int want = target / ntile;
+  int maxs = (nchunks + 31) / 32;
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
@@ -512,7 +533,7 @@ int drs_conv_wgrad_splits(int B, int S, int k, int cin, int cout) {
 int drs_conv_wgrad(const float* x, int B, int S, int Px, int ld_x, int coff_x, const float* g, int Pg, int ld_g,
                    int coff_g, int k, int rate, int pad_before, int cin, int cin_real, int cout, float* slab,
                    float* grad, void* stream) {
-  if (!x || !g || !slab || !grad || cin % 32 || cout % 32 || cin_real > cin) return DRS_ERR_ARG;
+  if (!x || !g || !slab || !grad || (cin % 32 && cin != 8 && cin != 16) || cout % 32 || cin_real > cin) return DRS_ERR_ARG;
   const long long M = (long long)B * S * S;
   if (M <= 0 || M >= (1 << 24)) return DRS_ERR_ARG;
   if ((long long)B * (S + 2 * Px) * (S + 2 * Px) * ld_x >= (1LL << 32)) return DRS_ERR_ARG;     // 32-bit element offsets
@@ -527,7 +548,7 @@ int drs_conv_wgrad(const float* x, int B, int S, int Px, int ld_x, int coff_x, c
   const int nchunks = (int)((M + 31) / 32);
   a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
-  a.skip_halo = drs_g_skip_halo_taps;
+  a.skip_halo = drs_skip_halo_taps_wgrad(M);
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (tr == 128 && to == 128) rc = launch_wgrad<128, 128>(a, nsplit, st);

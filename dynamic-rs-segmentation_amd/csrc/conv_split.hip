@@ -106,6 +106,7 @@ struct SplitConvArgs {
   float* stats;
   int k, rate, pad, Cin, Cout;
   int accumulate;
+  int skip_halo;
   float rcpS, rcpSS;
 };
 
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const SplitConvArgs a) 
   const int cpt = a.Cin / BK;
   int u_lo, u_hi;                               // tap rows that are not entirely in the zero halo for this tile (drs_common.hpp)
   live_tap_rows(m0, BM, a.M, a.S, a.k, a.rate, a.pad, a.rcpS, a.rcpSS, u_lo, u_hi);
+  if (!a.skip_halo) { u_lo = 0; u_hi = a.k; }
   const int ks0 = u_lo * a.k * cpt;
   const int nks = u_hi * a.k * cpt;
   u32x4 ra[NS][NA], rb[NS][NB];
@@ -320,6 +322,7 @@ __global__ __launch_bounds__(256) void conv_split_dma_kernel(const SplitConvArgs
   const int cpt = a.Cin / BK;
   int u_lo, u_hi;                               // tap rows that are not entirely in the zero halo for this tile (drs_common.hpp)
   live_tap_rows(m0, BM, a.M, a.S, a.k, a.rate, a.pad, a.rcpS, a.rcpSS, u_lo, u_hi);
+  if (!a.skip_halo) { u_lo = 0; u_hi = a.k; }
   const int ks0 = u_lo * a.k * cpt;
   const int nks = u_hi * a.k * cpt;
   int lu = u_lo, lv = 0, lc = 0;
@@ -911,6 +914,7 @@ int drs_conv_forward_split(const unsigned short* in, int B, int S, int P, int ld
   a.w = w; a.bias = bias; a.out = out; a.ld_out = ld_out; a.coff_out = coff_out;
   a.stats = stats_partial; a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout; a.accumulate = accumulate;
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
+  a.skip_halo = drs_skip_halo_taps_fwd(M, cout);
   hipStream_t st = (hipStream_t)stream;
   return nsplit == 2 ? dispatch_split<2>(a, st) : dispatch_split<3>(a, st);
 }
@@ -921,8 +925,8 @@ int drs_conv_wgrad_split_splits(int B, int S, int k, int cin, int cout, int Pg, 
   int ntile = ((k * k * cin + tr - 1) / tr) * (cout / to);
   if (wgrad_dma(nterms, Pg) && to == 64 && cout > 64) ntile = ((k * k * cin + tr - 1) / tr) * ((cout / 128) + 1);   // 128-wide tiles + one 64-wide
   const int nchunks = (int)((M + 31) / 32);
-  int want = 3072 / ntile;           // see drs_conv_wgrad_splits (conv_mfma.hip)
-  int maxs = nchunks / 96;
+  int want = ((ntile >= 24 && nchunks >= 8192) ? 3072 : 1536) / ntile;      // see drs_conv_wgrad_splits (conv_mfma.hip)
+  int maxs = (nchunks + 31) / 32;
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
@@ -950,7 +954,7 @@ int drs_conv_wgrad_split(const unsigned short* x, int B, int S, int Px, int ld_x
   a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
   a.o_base = 0;
-  a.skip_halo = drs_g_skip_halo_taps;
+  a.skip_halo = drs_skip_halo_taps_wgrad(M);
   hipStream_t st = (hipStream_t)stream;
   int rc = DRS_OK;
   if (wgrad_dma(nsplit_terms, Pg)) {

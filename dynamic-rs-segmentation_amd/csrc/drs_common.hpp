@@ -104,8 +104,22 @@ __device__ __forceinline__ int next_live_chunk(int c, int S2, float rcpSS, int l
   return ((r < lo ? b : b + 1) * S2 + lo) >> 5;       // the chunk holding the first live pixel ahead
 }
 
-// development switch shared by the convolution kernels (drs_debug_skip_taps): 0 = multiply the all-halo taps / chunks too
+// development switch shared by the convolution kernels (drs_debug_skip_taps): 0 = multiply the all-halo taps / chunks too,
+// 1 = skip them where it pays, 2 = skip them always
 extern int drs_g_skip_halo_taps;
+// Skipping makes the workgroups of a launch unequal, and that only pays on a grid of many rounds: in-process A/B at 64x64,
+// forward conv8 -6 % at 8192 workgroups (B = 128), -4.6 % at 4096, +3 % at 2048, +12 % at 1024 (B = 16); filter gradient
+// -1..-4 % at B = 128, +6..18 % on several layers at B = 32.  So: forward / input gradient from 4096 workgroups (128-row
+// tiles assumed), filter gradient from 2^19 pixels.
+static inline int drs_skip_halo_taps_fwd(long long M, int cout) {
+  if (drs_g_skip_halo_taps != 1) return drs_g_skip_halo_taps == 2;
+  const long long wgs = ((M + 127) / 128) * ((cout + 127) / 128);
+  return wgs >= 4096;
+}
+static inline int drs_skip_halo_taps_wgrad(long long M) {
+  if (drs_g_skip_halo_taps != 1) return drs_g_skip_halo_taps == 2;
+  return M >= (1LL << 19);
+}
 
 // Bijective XCD-aware remap of a 1-D grid: blocks b and b+8 share an XCD (round-robin dispatch), so give every
 // XCD one contiguous chunk of the logical tile order (neighbouring tiles then share that XCD's 4 MiB L2).

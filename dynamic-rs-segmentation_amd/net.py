@@ -78,7 +78,7 @@ class DilatedNet(object):
         if arith not in ARITH_TERMS:
             raise ValueError("arith must be one of %s" % sorted(ARITH_TERMS))
         self.arith, self.ns = arith, ARITH_TERMS[arith]
-        self.plan = Plan(net_type, channels, num_classes)
+        self.plan = Plan(net_type, channels, num_classes, first_cin_pad=32 if self.ns else 8)
         self.wd = float(weight_decay)
         self.b_max, self.s_max = int(b_max), int(s_max)
         self.dev = torch.device(device)
@@ -225,7 +225,8 @@ class DilatedNet(object):
             slab = max([slab] + [_lib.query("drs_conv_wgrad_split_splits", B, S, L.k, L.cin_k, L.cout, L.halo, self.ns) * L.k * L.k * L.cin_k * L.cout
                                  for i, L in enumerate(p.layers) if self._split_fwd(i)])
         self.slab = torch.zeros(slab, **f32)
-        self.w0pad = torch.zeros(L0.k * L0.k * L0.cin_k * L0.cout, **f32)
+        # conv1's filter with the bands padded to cin_k; with cin_k < 32 its rows are padded (zeros) to a whole number of K-steps
+        self.w0pad = torch.zeros(-(-L0.k * L0.k * L0.cin_k // 32) * 32 * L0.cout, **f32)
         self.wt = [None] + [torch.zeros(L.k * L.k * L.cin * L.cout, **f32) for L in p.layers[1:]]
         crow = _lib.query("drs_classifier_rows", B, S)
         self.dw_partial = torch.zeros(crow * p.c_last * p.K, **f32)

@@ -92,7 +92,9 @@ def round_up(v, m):
 class Plan(object):
     """Static description of one net for given (bands, classes)."""
 
-    def __init__(self, net_type, channels, num_classes):
+    def __init__(self, net_type, channels, num_classes, first_cin_pad=8):
+        """first_cin_pad: channel count the image bands are padded to in the conv1 input slab: 8 (several filter taps share a
+        32-deep K-step of the fp32 kernels) or 32 (one tap per K-step; what the split-bf16 kernels take)."""
         self.net_type = resolve(net_type)
         act, pool, topo, self.c_last, convs = _TABLES[self.net_type]
         self.dense = topo is True
@@ -103,7 +105,7 @@ class Plan(object):
         # A chain gives every block its own output slab; the dense net (isprs:921-948) and the squeeze net (isprs:737-742)
         # concatenate by writing channel slices of a shared slab, so no concat copy exists.
         blocks = []        # (name, k, cin, cout, rate, src, dst, dst_coff)
-        chan = {"x0": round_up(channels, 32)}
+        chan = {"x0": round_up(channels, first_cin_pad if channels <= first_cin_pad else 32)}
         if topo == "squeeze":
             name, k, _, co, r = convs[0]
             blocks.append((name, k, channels, co, r, "x0", "c1", 0))
@@ -136,7 +138,8 @@ class Plan(object):
         for (name, k, ci, co, r, src, dst, coff) in blocks:
             pb, pa = same_pad(k, r)
             halo[src] = max(halo[src], pb, pa)          # a slab's halo must cover every conv that reads it
-            self.layers.append(Layer(name, k, ci, round_up(ci, 32), co, r, pb, pa, max(pb, pa), src, dst, coff))
+            cin_k = chan["x0"] if src == "x0" else round_up(ci, 32)
+            self.layers.append(Layer(name, k, ci, cin_k, co, r, pb, pa, max(pb, pa), src, dst, coff))
         self.buffers = {n: (chan[n], halo[n]) for n in chan}
         # flat parameter layout: every kernel (HWIO), then every bias; the classifier last in both groups
         self.offsets = {}

@@ -82,6 +82,69 @@ def test_conv_forward_dgrad_wgrad(lib, k, rate, cin, cout, B, S):
     assert rel_err(gw.cpu().numpy().reshape(k, k, cin, cout), gw_ref) < 1e-5
 
 
+@pytest.mark.parametrize("k,rate,cin,cout,B,S", [(3, 8, 64, 128, 3, 20), (3, 7, 64, 64, 2, 33), (4, 3, 64, 128, 5, 9), (5, 2, 32, 64, 2, 16),
+                                                  (3, 5, 128, 192, 2, 27)])
+def test_halo_tap_skipping_is_bitwise_neutral(lib, k, rate, cin, cout, B, S):
+    """Filter taps / pixel chunks that meet only the zero halo are not executed on large grids (drs_common.hpp); forcing the
+    skip on (2) and off (0) at small sizes must give bitwise identical forward, input-gradient and filter-gradient results, in
+    the exact-fp32 and in the split-bf16 kernels (tiles crossing image boundaries, ragged chunks, odd S included)."""
+    rng = np.random.default_rng(S * 7 + cout)
+    x = rng.normal(size=(B, S, S, cin)).astype(np.float32)
+    w = (rng.normal(size=(k, k, cin, cout)) * 0.05).astype(np.float32)
+    g = rng.normal(size=(B, S, S, cout)).astype(np.float32)
+    pb, pa = onets.same_pad(k, rate)
+    P = max(pb, pa)
+    M = B * S * S
+    xd, gd, wd = padded(x, P), padded(g, P), dev(w)
+    wt = torch.zeros(w.size, dtype=torch.float32, device=DEV)
+    lib.call("drs_filter_flip_transpose", wd.data_ptr(), wt.data_ptr(), k, cin, cout, stream())
+    ns = 2
+    xt = torch.zeros(ns * xd.numel(), dtype=torch.int16, device=DEV)
+    gt = torch.zeros(ns * gd.numel(), dtype=torch.int16, device=DEV)
+    lib.call("drs_split_terms", xd.data_ptr(), xd.numel(), ns, xt.data_ptr(), stream())
+    lib.call("drs_split_terms", gd.data_ptr(), gd.numel(), ns, gt.data_ptr(), stream())
+    wf = torch.zeros(ns * w.size, dtype=torch.int16, device=DEV)
+    wg = torch.zeros(ns * w.size, dtype=torch.int16, device=DEV)
+    lib.call("drs_filter_split", wd.data_ptr(), k, cin, cin, cout, ns, wf.data_ptr(), wg.data_ptr() if cin % 64 == 0 else None, stream())
+    res = {}
+    raw = lib.load()
+    try:
+        for mode in (0, 2):
+            raw.drs_debug_skip_taps(mode)
+            out = torch.zeros(M * cout, dtype=torch.float32, device=DEV)
+            gx = torch.zeros(M * cin, dtype=torch.float32, device=DEV)
+            gw = torch.zeros(w.size, dtype=torch.float32, device=DEV)
+            lib.call("drs_conv_forward", xd.data_ptr(), B, S, P, cin, 0, wd.data_ptr(), None, k, rate, pb, cin, cout, out.data_ptr(), cout,
+                     0, 0, None, stream())
+            lib.call("drs_conv_forward", gd.data_ptr(), B, S, P, cout, 0, wt.data_ptr(), None, k, rate, pa, cout, cin, gx.data_ptr(), cin,
+                     0, 0, None, stream())
+            nsp = lib.query("drs_conv_wgrad_splits", B, S, k, cin, cout)
+            slab = torch.zeros(nsp * w.size, dtype=torch.float32, device=DEV)
+            lib.call("drs_conv_wgrad", xd.data_ptr(), B, S, P, cin, 0, gd.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout,
+                     slab.data_ptr(), gw.data_ptr(), stream())
+            out2 = torch.zeros(M * cout, dtype=torch.float32, device=DEV)
+            gw2 = torch.zeros(w.size, dtype=torch.float32, device=DEV)
+            gx2 = torch.zeros(M * cin, dtype=torch.float32, device=DEV)
+            if cout % 64 == 0:
+                lib.call("drs_conv_forward_split", xt.data_ptr(), B, S, P, cin, 0, wf.data_ptr(), None, k, rate, pb, cin, cout,
+                         out2.data_ptr(), cout, 0, 0, None, ns, stream())
+                nsp2 = lib.query("drs_conv_wgrad_split_splits", B, S, k, cin, cout, P, ns)
+                slab2 = torch.zeros(nsp2 * w.size, dtype=torch.float32, device=DEV)
+                lib.call("drs_conv_wgrad_split", xt.data_ptr(), B, S, P, cin, 0, gt.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout,
+                         slab2.data_ptr(), gw2.data_ptr(), ns, stream())
+                if cin % 64 == 0:
+                    lib.call("drs_conv_forward_split", gt.data_ptr(), B, S, P, cout, 0, wg.data_ptr(), None, k, rate, pa, cout, cin,
+                             gx2.data_ptr(), cin, 0, 0, None, ns, stream())
+            torch.cuda.synchronize()
+            res[mode] = [t.cpu().numpy() for t in (out, gx, gw, out2, gx2, gw2)]
+    finally:
+        raw.drs_debug_skip_taps(1)
+    for a, b, name in zip(res[0], res[2], ("fwd", "dgrad", "wgrad", "fwd split", "dgrad split", "wgrad split")):
+        np.testing.assert_array_equal(a, b, err_msg=name)
+    ref = T.conv2d_same(x.astype(np.float64), w.astype(np.float64), rate)
+    assert rel_err(res[2][0].reshape(B, S, S, cout), ref) < 1e-5
+
+
 def test_conv1_band_padding(lib):
     """3..5 image bands ride the 32-channel K-step: padded filter rows are zero, wgrad drops them again."""
     rng = np.random.default_rng(5)
@@ -106,6 +169,42 @@ def test_conv1_band_padding(lib):
     ref = T.conv2d_same(x.astype(np.float64), w.astype(np.float64), 1)
     _, gw_ref = T.conv2d_same_bwd(x.astype(np.float64), w.astype(np.float64), 1, g.astype(np.float64))
     assert rel_err(out.cpu().numpy().reshape(B, S, S, cout), ref) < 1e-5
+    assert rel_err(gw.cpu().numpy().reshape(k, k, C, cout), gw_ref) < 1e-5
+
+
+@pytest.mark.parametrize("C,cout,k,rate,B,S", [(5, 64, 5, 1, 2, 11), (3, 64, 5, 1, 1, 25), (4, 32, 5, 1, 2, 13), (5, 64, 3, 2, 2, 9)])
+def test_conv1_packed_taps(lib, C, cout, k, rate, B, S):
+    """the few-band input of conv1 in an 8-channel slab: 32 / 8 filter taps share a K-step (k*k*8 rows, padded to a multiple of 32
+    with zero filter rows) instead of one tap per 32-channel K-step; wgrad works on the same 8-channel rows."""
+    rng = np.random.default_rng(C * 100 + cout + S)
+    x = rng.normal(size=(B, S, S, C)).astype(np.float32)
+    w = rng.normal(size=(k, k, C, cout)).astype(np.float32) * 0.1
+    g = rng.normal(size=(B, S, S, cout)).astype(np.float32)
+    pb, pa = onets.same_pad(k, rate)
+    P = max(pb, pa)
+    xd = padded(x, P, ld=8, coff=0)
+    rows = -(-k * k * 8 // 32) * 32
+    wp = torch.zeros(rows * cout, dtype=torch.float32, device=DEV)
+    lib.call("drs_filter_pad_cin", dev(w).data_ptr(), wp.data_ptr(), k, C, 8, cout, stream())
+    M = B * S * S
+    out = torch.zeros(M * cout, dtype=torch.float32, device=DEV)
+    mt = lib.query("drs_conv_mtile", cout)
+    nrow = (M + mt - 1) // mt
+    stats = torch.zeros(nrow * cout * 2, dtype=torch.float32, device=DEV)
+    lib.call("drs_conv_forward", xd.data_ptr(), B, S, P, 8, 0, wp.data_ptr(), None, k, rate, pb, 8, cout, out.data_ptr(), cout, 0, 0,
+             stats.data_ptr(), stream())
+    gd = padded(g, P)
+    nsplit = lib.query("drs_conv_wgrad_splits", B, S, k, 8, cout)
+    slab = torch.zeros(nsplit * k * k * 8 * cout, dtype=torch.float32, device=DEV)
+    gw = torch.zeros(k * k * C * cout, dtype=torch.float32, device=DEV)
+    lib.call("drs_conv_wgrad", xd.data_ptr(), B, S, P, 8, 0, gd.data_ptr(), P, cout, 0, k, rate, pb, 8, C, cout, slab.data_ptr(),
+             gw.data_ptr(), stream())
+    torch.cuda.synchronize()
+    ref = T.conv2d_same(x.astype(np.float64), w.astype(np.float64), rate)
+    _, gw_ref = T.conv2d_same_bwd(x.astype(np.float64), w.astype(np.float64), rate, g.astype(np.float64))
+    assert rel_err(out.cpu().numpy().reshape(B, S, S, cout), ref) < 1e-5
+    st = stats.cpu().numpy().reshape(nrow, cout, 2).astype(np.float64).sum(axis=0)
+    assert np.abs(st[:, 0] - ref.reshape(-1, cout).sum(axis=0)).max() < 1e-5 * np.abs(ref).sum(axis=(0, 1, 2)).max()
     assert rel_err(gw.cpu().numpy().reshape(k, k, C, cout), gw_ref) < 1e-5
 
 

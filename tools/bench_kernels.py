@@ -29,7 +29,7 @@ def timeit(fn, reps=7):
 
 def main(B=128, S=64, net="dilated_grsl_rate8", which="fwd,dgrad,wgrad"):
     _lib.load()
-    plan = Plan(net, 5, 6)
+    plan = Plan(net, 5, 6, first_cin_pad=32)
     st = torch.cuda.current_stream(DEV).cuda_stream
     M = B * S * S
     tot = {}
@@ -54,12 +54,12 @@ def main(B=128, S=64, net="dilated_grsl_rate8", which="fwd,dgrad,wgrad"):
             res = {0: [], 1: []}
             for rep in range(4):
                 for v in (0, 1):
-                    _lib.load().drs_debug_skip_taps(v)
+                    _lib.load().drs_debug_skip_taps(2 * v)
                     res[v].append(timeit(f, reps=3))
             _lib.load().drs_debug_skip_taps(1)
             row += " fwd all taps %6.3f ms | skipping halo tap rows %6.3f ms (%+.1f %%)" % (min(res[0]), min(res[1]), 100 * (min(res[1]) / min(res[0]) - 1))
         if "wsp" in which:      # filter-gradient time against the number of workgroups the pixel split aims at
-            for target in (1536, 2304, 3072, 4608):
+            for target in (768, 1152, 1536, 2304):
                 _lib.load().drs_debug_wgrad_target(target)
                 ns2 = _lib.query("drs_conv_wgrad_splits", B, S, L.k, L.cin_k, L.cout)
                 slab2 = torch.zeros(ns2 * L.k * L.k * L.cin_k * L.cout, device=DEV)
@@ -67,14 +67,14 @@ def main(B=128, S=64, net="dilated_grsl_rate8", which="fwd,dgrad,wgrad"):
                                               L.cin_k, L.cin_k, L.cout, slab2.data_ptr(), gw.data_ptr(), st), reps=5)
                 row += " | %d: %d splits %6.3f ms" % (target, ns2, ms)
                 del slab2
-            _lib.load().drs_debug_wgrad_target(3072)
+            _lib.load().drs_debug_wgrad_target(1536)
         if "wab" in which:      # A/B of skipping the all-halo pixel chunks in the filter gradient, inside one process
             f = lambda: _lib.call("drs_conv_wgrad", x.data_ptr(), B, S, P, L.cin_k, 0, g.data_ptr(), P, L.cout, 0, L.k, L.rate, L.pad_b,
                                   L.cin_k, L.cin_k, L.cout, slab.data_ptr(), gw.data_ptr(), st)
             res = {0: [], 1: []}
             for rep in range(4):
                 for v in (0, 1):
-                    _lib.load().drs_debug_skip_taps(v)
+                    _lib.load().drs_debug_skip_taps(2 * v)
                     res[v].append(timeit(f, reps=3))
             _lib.load().drs_debug_skip_taps(1)
             row += " wgrad all chunks %6.3f ms | skipping all-halo chunks %6.3f ms (%+.1f %%)" % (min(res[0]), min(res[1]), 100 * (min(res[1]) / min(res[0]) - 1))

@@ -29,7 +29,7 @@ def timeit(fn, reps=7):
 
 def main(B=128, S=64, net="dilated_grsl_rate8", layers=None):
     _lib.load()
-    plan = Plan(net, 5, 6)
+    plan = Plan(net, 5, 6, first_cin_pad=32)
     st = torch.cuda.current_stream(DEV).cuda_stream
     M = B * S * S
     tot = {}

@@ -8,7 +8,7 @@ from drs_amd.nets import Plan
 DEV = "cuda:0"
 def main(B=128, S=64, layers="4,8", reps=3):
     _lib.load()
-    plan = Plan("dilated_grsl_rate8", 5, 6)
+    plan = Plan("dilated_grsl_rate8", 5, 6, first_cin_pad=32)
     st = torch.cuda.current_stream(DEV).cuda_stream
     for i, L in enumerate(plan.layers):
         if str(i + 1) not in layers.split(","):
