@@ -27,9 +27,9 @@ def timeit(fn, reps=7):
     return float(np.median(ts))
 
 
-def main(B=128, S=64, net="dilated_grsl_rate8", which="fwd,dgrad,wgrad"):
+def main(B=128, S=64, net="dilated_grsl_rate8", which="fwd,dgrad,wgrad", pad0=32):
     _lib.load()
-    plan = Plan(net, 5, 6, first_cin_pad=32)
+    plan = Plan(net, 5, 6, first_cin_pad=pad0)
     st = torch.cuda.current_stream(DEV).cuda_stream
     M = B * S * S
     tot = {}
@@ -37,7 +37,7 @@ def main(B=128, S=64, net="dilated_grsl_rate8", which="fwd,dgrad,wgrad"):
         P = L.halo
         x = torch.randn(B * (S + 2 * P) ** 2 * L.cin_k, device=DEV)
         g = torch.randn(B * (S + 2 * P) ** 2 * L.cout, device=DEV)
-        w = torch.randn(L.k * L.k * L.cin_k * L.cout, device=DEV) * 0.05
+        w = torch.randn(-(-L.k * L.k * L.cin_k // 32) * 32 * L.cout, device=DEV) * 0.05      # rows padded to whole K-steps (conv1 on 8 channels)
         wt = torch.randn(L.k * L.k * L.cin_k * L.cout, device=DEV) * 0.05
         bias = torch.zeros(L.cout, device=DEV)
         z = torch.zeros(M * max(L.cout, L.cin_k), device=DEV)
@@ -99,4 +99,5 @@ def main(B=128, S=64, net="dilated_grsl_rate8", which="fwd,dgrad,wgrad"):
 
 if __name__ == "__main__":
     kw = dict(a.split("=") for a in sys.argv[1:])
-    main(int(kw.get("B", 128)), int(kw.get("S", 64)), kw.get("net", "dilated_grsl_rate8"), kw.get("which", "fwd,dgrad,wgrad"))
+    main(int(kw.get("B", 128)), int(kw.get("S", 64)), kw.get("net", "dilated_grsl_rate8"), kw.get("which", "fwd,dgrad,wgrad"),
+         int(kw.get("pad0", 32)))
