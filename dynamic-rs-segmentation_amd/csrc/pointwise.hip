@@ -587,15 +587,16 @@ struct ClsArgs {
   float rcpS, rcpSS;
 };
 
-template <int CI>   // CI = C / 64
+// CI = C / 64; KM = class slots carried per lane: the exact class count for the reference's 2 / 6 / 7 classes (no masked
+// slots, no wasted multiplies), 8 otherwise
+template <int CI, int KM>
 __global__ __launch_bounds__(256) void classifier_loss_kernel(const ClsArgs a) {
-  constexpr int KM = 8;
   __shared__ float red[4][CI * 64 * KM];
   __shared__ float redb[4][KM];
   __shared__ double redl[4];
   __shared__ unsigned int confs[KM * KM];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int K = a.K;
+  const int K = KM < 8 ? KM : a.K;      // exact instantiations know their class count at compile time
   // a lane owns its CI channels in groups of V consecutive ones, so that a pixel's features move as 16- / 8-byte accesses
   // (1 KiB / 512 B per wave-instruction instead of 256 B): channel of slot i = (i / V) * 64 V + lane * V + i % V
   constexpr int V = CI % 4 == 0 ? 4 : (CI % 2 == 0 ? 2 : 1);
@@ -625,12 +626,14 @@ __global__ __launch_bounds__(256) void classifier_loss_kernel(const ClsArgs a) {
     // the KM = 8 per-lane partial dot products are summed over the 64 lanes by a halving butterfly: at distance 32 / 16 / 8 a lane
     // hands its partner the half of its values the partner keeps (4 + 2 + 1 exchanges), then three plain steps finish the one
     // value left (class 4*b5 + 2*b4 + b3 of the lane id); 10 cross-lane moves per pixel instead of 48, summation order fixed
-    float v8[KM];
+    float v8[8];
 #pragma unroll
-    for (int k = 0; k < KM; ++k) {
+    for (int k = 0; k < 8; ++k) {
       float s = 0.f;
+      if (k < KM) {
 #pragma unroll
-      for (int i = 0; i < CI; ++i) s += f[i] * wr[i][k];
+        for (int i = 0; i < CI; ++i) s += f[i] * wr[i][k];
+      }
       v8[k] = s;
     }
     float v4[4], v2[2], v1;
@@ -678,7 +681,7 @@ __global__ __launch_bounds__(256) void classifier_loss_kernel(const ClsArgs a) {
     const bool in_loss = !a.loss_mask || a.loss_mask[p];
     float ex[KM], se = 0.f;
 #pragma unroll
-    for (int k = 0; k < KM; ++k) { ex[k] = k < K ? expf(lg[k] - mx) : 0.f; se += ex[k]; }
+    for (int k = 0; k < KM; ++k) { ex[k] = k < K ? __expf(lg[k] - mx) : 0.f; se += ex[k]; }
     const float inv = 1.0f / se;
     float ly = 0.f;
     float dl[KM];
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(256) void classifier_loss_kernel(const ClsArgs a) {
       dl[k] = in_loss && k < K ? (pk - (k == y ? 1.f : 0.f)) * a.inv_n : 0.f;
       if (k == y) ly = lg[k];
     }
-    if (in_loss) lsum += (double)(logf(se) + mx - ly);
+    if (in_loss) lsum += (double)(__logf(se) + mx - ly);
     if (a.gfeat) {
 #pragma unroll
       for (int gi = 0; gi < CI / V; ++gi) {
@@ -974,15 +977,12 @@ int drs_classifier_loss(const float* feat, int B, int S, int P, int ld, int coff
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
   const int nblk = drs_classifier_rows(B, S);
   hipStream_t st = (hipStream_t)stream;
-  switch (C / 64) {
-    case 1: DRS_LAUNCH(classifier_loss_kernel<1>, dim3(nblk), dim3(256), 0, st, a); break;
-    case 2: DRS_LAUNCH(classifier_loss_kernel<2>, dim3(nblk), dim3(256), 0, st, a); break;
-    case 3: DRS_LAUNCH(classifier_loss_kernel<3>, dim3(nblk), dim3(256), 0, st, a); break;
-    case 4: DRS_LAUNCH(classifier_loss_kernel<4>, dim3(nblk), dim3(256), 0, st, a); break;
-    case 5: DRS_LAUNCH(classifier_loss_kernel<5>, dim3(nblk), dim3(256), 0, st, a); break;
-    case 6: DRS_LAUNCH(classifier_loss_kernel<6>, dim3(nblk), dim3(256), 0, st, a); break;
-    default: DRS_LAUNCH(classifier_loss_kernel<7>, dim3(nblk), dim3(256), 0, st, a); break;
-  }
+#define DRS_CLS_CASE(ci, km) DRS_LAUNCH((classifier_loss_kernel<ci, km>), dim3(nblk), dim3(256), 0, st, a)
+#define DRS_CLS_KM(km) switch (C / 64) { case 1: DRS_CLS_CASE(1, km); break; case 2: DRS_CLS_CASE(2, km); break; case 3: DRS_CLS_CASE(3, km); break; \
+    case 4: DRS_CLS_CASE(4, km); break; case 5: DRS_CLS_CASE(5, km); break; case 6: DRS_CLS_CASE(6, km); break; default: DRS_CLS_CASE(7, km); break; }
+  if (K == 2) DRS_CLS_KM(2) else if (K == 6) DRS_CLS_KM(6) else if (K == 7) DRS_CLS_KM(7) else DRS_CLS_KM(8)
+#undef DRS_CLS_KM
+#undef DRS_CLS_CASE
   return DRS_LAUNCH_CHECK();
 }
 
