@@ -865,9 +865,11 @@ static int bn_act_pool_forward_impl(const float* z, int B, int S, int C, const f
   dim3 grid((per_row + 255) / 256, B * Sp);
   ActView v = mkview(out, S, P_out, ld_out, coff_out);
   v.terms = terms; v.nt = terms ? nterms : 0;
+  const bool halo_is_zero = (pool & 2) != 0;     // the caller vouches for the halo (same B, S, P as the call that last zeroed it)
+  pool &= 1;
   if (pool && C / 4 <= 256) {
     const SlideCfg c = slide_cfg(B, S, C);
-    if (P_out > 0) DRS_LAUNCH(zero_halo_kernel, grid, dim3(256), 0, (hipStream_t)stream, v, B, C);
+    if (P_out > 0 && !halo_is_zero) DRS_LAUNCH(zero_halo_kernel, grid, dim3(256), 0, (hipStream_t)stream, v, B, C);
     DRS_LAUNCH(bn_act_pool_fwd_slide_kernel, dim3(c.ncol, B * c.nstrips), dim3(c.TX * (C / 4)), 0, (hipStream_t)stream, z, B, S, C,
                mean_rstd, alpha, v, argmax, c.nstrips, c.rps);
   } else if (pool)

@@ -363,6 +363,7 @@ class DilatedNet(object):
         M = B * S * S
         self._prepare_weights(st, training)
         self._touch_f32("x0")
+        halo_ok = self.__dict__.setdefault("_halo_zeroed", {})     # slab -> (B, S) of the pooling call that last zeroed its halo
         for i, L in enumerate(p.layers):
             xin, Pin, ldin, cin_off = self._in_view(i)
             stats = self.partial if training else None
@@ -406,13 +407,19 @@ class DilatedNet(object):
                 # if someone needs it); channel slices of a shared slab (dense / squeeze nets) go through drs_split_terms
                 keep = L.dst in self.f32_slabs
                 self.terms_stale.discard(L.dst)
+                hz = 2 if (mx and halo_ok.get(L.dst) == (B, S, keep)) else 0
+                halo_ok[L.dst] = (B, S, keep) if mx else None
                 self._k("bn_act_pool_fwd", M * L.cout * ((5.0 if (training and mx) else 4.0) + 2.0 * self.ns + (4.0 if keep else 0.0)),
                         "drs_bn_act_pool_forward_terms", _ptr(self.z[i]), B, S, L.cout, _ptr(self.mean_rstd[i]), p.alpha,
-                        1 if mx else 0, _ptr(out) if keep else None, Pout, ldout, coff,
+                        (1 if mx else 0) | hz, _ptr(out) if keep else None, Pout, ldout, coff,
                         _ptr(self.idx[i]) if (training and mx) else None, _ptr(self.aplanes[L.dst]), self.ns, st)
             else:
+                # the halo of a slab this block owns alone stays zero between calls of the same geometry: do not rewrite it
+                whole = ldout == L.cout and coff == 0
+                hz = 2 if (mx and whole and halo_ok.get(L.dst) == (B, S, True)) else 0
+                halo_ok[L.dst] = (B, S, True) if (mx and whole) else None
                 self._k("bn_act_pool_fwd", M * L.cout * (9.0 if (training and mx) else 8.0), "drs_bn_act_pool_forward",
-                        _ptr(self.z[i]), B, S, L.cout, _ptr(self.mean_rstd[i]), p.alpha, 1 if mx else 0, _ptr(out), Pout, ldout,
+                        _ptr(self.z[i]), B, S, L.cout, _ptr(self.mean_rstd[i]), p.alpha, (1 if mx else 0) | hz, _ptr(out), Pout, ldout,
                         coff, _ptr(self.idx[i]) if (training and mx) else None, st)
                 self._touch_f32(L.dst)
 

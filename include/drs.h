@@ -103,6 +103,8 @@ int drs_bn_eval_coeffs(const float* moving_mean, const float* moving_var, int C,
 
 /* ---- normalise + tf.nn.relu | tf.maximum(0.1x, x) + tf.nn.max_pool(3x3, stride 1, SAME) ------------------
  * (isprs:715-721, 620-621, 745-746, 1001).  z: [B*S*S][C] raw conv output; alpha = 0 (ReLU) or 0.1;
+ * pool: bit 0 = apply the 3x3 max-pool; bit 1 = the halo of `out` is known to be zero already (a previous call on this slab with
+ * the same B, S, P_out wrote it and nothing else has written the slab since) and need not be rewritten (pooling path only).
  * out: haloed view (the halo zeros are written here); argmax (pool only, may be NULL): [B*S*S][C] window
  * position 0..8 of the first maximum, which the backward pass routes gradients to (TF MaxPoolGrad). */
 int drs_bn_act_pool_forward(const float* z, int B, int S, int C, const float* mean_rstd, float alpha, int pool,
