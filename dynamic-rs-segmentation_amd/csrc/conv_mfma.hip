@@ -410,8 +410,17 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
     const int c = rc % cin_real, tap = rc / cin_real;
     const size_t src = ((size_t)tap * cin_pad + c) * cout + o;
     const size_t stride = (size_t)taps * cin_pad * cout;
+    // the sum runs in split order (fixed, so a step is reproducible); the loads of 8 splits are in flight together
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += slab[k * stride + src];
+    int k = 0;
+    for (; k + 8 <= nsplit; k += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = slab[(size_t)(k + j) * stride + src];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; k < nsplit; ++k) s += slab[(size_t)k * stride + src];
     grad[i] = s;
   }
 }
