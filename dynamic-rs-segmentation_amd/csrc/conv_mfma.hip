@@ -296,8 +296,13 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
 
   // the pixel -> padded-offset arithmetic (two divisions per pixel) is done once per chunk by BP threads, not by
   // every thread for every load: the first BP threads fill the tables for chunk `chunk` into slot `slot`
+  // when the patch side is a multiple of 32 a chunk is 32 consecutive pixels of one image row: its offsets are an affine function
+  // of the first pixel's and need no table (chunk_of[slot] = the chunk staged in that table slot)
+  const bool affine = (a.S & 31) == 0;
+  int chunk_of[2] = {0, 0};
   auto fill_tables = [&](int chunk, int slot) {
-    if (t < BP && chunk < cend) {
+    chunk_of[slot] = chunk;
+    if (!affine && t < BP && chunk < cend) {
       const int p = chunk * BP + t;
       const int pc = p < a.M ? p : a.M - 1;                    // clamped X rows meet a zero G row
       tabx[slot][t] = padded_pixel_off(pc, a.S, a.Px, a.ld_x, a.rcpS, a.rcpSS, -a.pad, -a.pad);
@@ -316,10 +321,20 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
     const uint32_t* tx = tabx[slot];
     const uint32_t* tg = tabg[slot];
     uint32_t ox[NX], og[NG];
+    if (affine) {
+      const int p0 = chunk_of[slot] * BP;
+      const uint32_t bx = padded_pixel_off(p0, a.S, a.Px, a.ld_x, a.rcpS, a.rcpSS, -a.pad, -a.pad);
+      const uint32_t bg = padded_pixel_off(p0, a.S, a.Pg, a.ld_g, a.rcpS, a.rcpSS, 0, 0);
 #pragma unroll
-    for (int i = 0; i < NX; ++i) ox[i] = tx[xpix + XPS * i];
+      for (int i = 0; i < NX; ++i) ox[i] = bx + (uint32_t)((xpix + XPS * i) * a.ld_x);
 #pragma unroll
-    for (int i = 0; i < NG; ++i) og[i] = tg[gpix + GPS * i];
+      for (int i = 0; i < NG; ++i) og[i] = bg + (uint32_t)((gpix + GPS * i) * a.ld_g);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) ox[i] = tx[xpix + XPS * i];
+#pragma unroll
+      for (int i = 0; i < NG; ++i) og[i] = tg[gpix + GPS * i];
+    }
 #pragma unroll
     for (int i = 0; i < NX; ++i) rx[i] = *reinterpret_cast<const f32x4*>(a.x + ox[i] + xconst);
 #pragma unroll
