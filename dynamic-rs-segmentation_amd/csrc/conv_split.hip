@@ -2,7 +2,7 @@
 //
 // Same operator as conv_mfma.hip (tf.nn.atrous_conv2d / tf.nn.conv2d + bias_add and their gradients,
 // /root/reference/isprs_dilated_random.py:710-713); what differs is the arithmetic.  Every fp32 operand x is stored
-// as NS bf16 planes x = x_0 + x_1 (+ x_2) (+ residual), each plane the round-to-nearest bf16 of what the previous
+// as NS bf16 terms x = x_0 + x_1 (+ x_2) (+ residual), each term the round-to-nearest bf16 of what the previous
 // ones left, and a product a*b is evaluated on the bf16 MFMA pipe (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA
 // rate; this file uses the 16x16x32 form in the LDS-DMA kernel) as the partial products a_i*b_j with i + j < NS, accumulated in fp32:
 //   NS = 2 ("bf16x3"):  a0 b0 + a0 b1 + a1 b0                         relative error of a product <= ~2^-16
