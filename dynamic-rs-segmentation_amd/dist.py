@@ -23,7 +23,10 @@ class TorchComm(object):
         if init and not dist.is_initialized():
             backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend=backend)
+            if backend == "nccl":       # bind the communicator to this rank's GPU at once (the caller has already set the device)
+                dist.init_process_group(backend=backend, device_id=torch.device("cuda", torch.cuda.current_device()))
+            else:
+                dist.init_process_group(backend=backend)
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
 
