@@ -29,6 +29,9 @@ def timeit(fn, reps=7):
 
 def main(B=128, S=64, net="dilated_grsl_rate8", layers=None):
     _lib.load()
+    # the slabs below are random INCLUDING their halo (only timing and the arithmetic are of interest here), so the halo-tap
+    # skipping, whose decisions depend on the tile height, must be off for the error column to compare like with like
+    _lib.load().drs_debug_skip_taps(0)
     plan = Plan(net, 5, 6, first_cin_pad=32)
     st = torch.cuda.current_stream(DEV).cuda_stream
     M = B * S * S
