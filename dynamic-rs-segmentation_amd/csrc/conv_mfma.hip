@@ -508,7 +508,7 @@ int drs_debug_skip_taps(int v) { const int old = drs_g_skip_halo_taps; if (v >= 
 int drs_debug_wgrad_target(int v) { const int old = g_wgrad_target; if (v > 0) g_wgrad_target = v; return old; }
 
 // M-tile height the forward/dgrad kernel uses for this Cout (= rows per BN-statistics slab row)
-int drs_conv_mtile(int cout) { return pick_tile(cout) == 128 ? 128 : 256; }
+int drs_conv_mtile(int cout) { return pick_tile(cout) >= 64 ? 128 : 256; }
 
 int drs_conv_forward(const float* in, int B, int S, int P, int ld_in, int coff_in, const float* w, const float* bias,
                      int k, int rate, int pad_before, int cin, int cout, float* out, int ld_out, int coff_out,
@@ -529,7 +529,7 @@ int drs_conv_forward(const float* in, int B, int S, int P, int ld_in, int coff_i
   hipStream_t st = (hipStream_t)stream;
   switch (pick_tile(cout)) {
     case 128: return launch_conv<128, 128, 2, 2>(a, st);
-    case 64:  return launch_conv<256, 64, 4, 1>(a, st);
+    case 64:  return launch_conv<128, 64, 2, 2>(a, st);     // in-process A/B against 256 x 64: -4..-9 % at B = 128, -2..-12 % at B = 16
     default:  return launch_conv<256, 32, 4, 1>(a, st);
   }
 }
