@@ -445,7 +445,7 @@ template <int NS>
 int dispatch_split(const SplitConvArgs& a, hipStream_t st) {
   if (a.Cout % 128 == 0) return launch_split<128, 128, 2, 2, NS>(a, st);
   if (a.Cout % 192 == 0) return launch_split<128, 192, 2, 2, NS>(a, st);
-  return launch_split<256, 64, 4, 1, NS>(a, st);
+  return launch_split<128, 64, 2, 2, NS>(a, st);
 }
 
 // ------------------------------------------------------------------------------------------------ wgrad
@@ -886,7 +886,7 @@ extern "C" {
 /* development switch between kernel variants (not part of the documented ABI) */
 int drs_debug_variant(int v) { const int old = g_variant; if (v >= 0) g_variant = v; return old; }
 
-int drs_split_conv_mtile(int cout) { return (cout % 128 == 0 || cout % 192 == 0) ? 128 : 256; }
+int drs_split_conv_mtile(int cout) { (void)cout; return 128; }
 
 int drs_split_terms(const float* src, size_t n, int nterms, unsigned short* terms, void* stream) {
   if (!src || !terms || (n & 31) || (nterms != 2 && nterms != 3)) return DRS_ERR_ARG;

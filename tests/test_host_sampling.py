@@ -154,5 +154,5 @@ def test_entry_points_reject_bad_arguments_before_any_launch():
         with pytest.raises(_lib.DrsError):
             _lib.call(name, *args)
     assert _lib.query("drs_split_conv_mtile", 256) == 128 and _lib.query("drs_split_conv_mtile", 192) == 128
-    assert _lib.query("drs_split_conv_mtile", 64) == 256
+    assert _lib.query("drs_split_conv_mtile", 64) == 128
     assert _lib.query("drs_conv_wgrad_split_splits", 64, 64, 3, 256, 256, 8, 2) >= 1
