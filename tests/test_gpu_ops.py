@@ -172,9 +172,10 @@ def test_conv1_band_padding(lib):
     assert rel_err(gw.cpu().numpy().reshape(k, k, C, cout), gw_ref) < 1e-5
 
 
-@pytest.mark.parametrize("C,cout,k,rate,B,S", [(5, 64, 5, 1, 2, 11), (3, 64, 5, 1, 1, 25), (4, 32, 5, 1, 2, 13), (5, 64, 3, 2, 2, 9)])
-def test_conv1_packed_taps(lib, C, cout, k, rate, B, S):
-    """the few-band input of conv1 in an 8-channel slab: 32 / 8 filter taps share a K-step (k*k*8 rows, padded to a multiple of 32
+@pytest.mark.parametrize("C,cout,k,rate,B,S,CP", [(5, 64, 5, 1, 2, 11, 8), (3, 64, 5, 1, 1, 25, 8), (4, 32, 5, 1, 2, 13, 8), (5, 64, 3, 2, 2, 9, 8),
+                                                     (12, 64, 5, 1, 2, 10, 16), (9, 128, 3, 3, 1, 14, 16)])
+def test_conv1_packed_taps(lib, C, cout, k, rate, B, S, CP):
+    """the few-band input of conv1 in an 8- (or 16-) channel slab: 32 / 8 filter taps share a K-step (k*k*8 rows, padded to a multiple of 32
     with zero filter rows) instead of one tap per 32-channel K-step; wgrad works on the same 8-channel rows."""
     rng = np.random.default_rng(C * 100 + cout + S)
     x = rng.normal(size=(B, S, S, C)).astype(np.float32)
@@ -182,22 +183,22 @@ def test_conv1_packed_taps(lib, C, cout, k, rate, B, S):
     g = rng.normal(size=(B, S, S, cout)).astype(np.float32)
     pb, pa = onets.same_pad(k, rate)
     P = max(pb, pa)
-    xd = padded(x, P, ld=8, coff=0)
-    rows = -(-k * k * 8 // 32) * 32
+    xd = padded(x, P, ld=CP, coff=0)
+    rows = -(-k * k * CP // 32) * 32
     wp = torch.zeros(rows * cout, dtype=torch.float32, device=DEV)
-    lib.call("drs_filter_pad_cin", dev(w).data_ptr(), wp.data_ptr(), k, C, 8, cout, stream())
+    lib.call("drs_filter_pad_cin", dev(w).data_ptr(), wp.data_ptr(), k, C, CP, cout, stream())
     M = B * S * S
     out = torch.zeros(M * cout, dtype=torch.float32, device=DEV)
     mt = lib.query("drs_conv_mtile", cout)
     nrow = (M + mt - 1) // mt
     stats = torch.zeros(nrow * cout * 2, dtype=torch.float32, device=DEV)
-    lib.call("drs_conv_forward", xd.data_ptr(), B, S, P, 8, 0, wp.data_ptr(), None, k, rate, pb, 8, cout, out.data_ptr(), cout, 0, 0,
+    lib.call("drs_conv_forward", xd.data_ptr(), B, S, P, CP, 0, wp.data_ptr(), None, k, rate, pb, CP, cout, out.data_ptr(), cout, 0, 0,
              stats.data_ptr(), stream())
     gd = padded(g, P)
-    nsplit = lib.query("drs_conv_wgrad_splits", B, S, k, 8, cout)
-    slab = torch.zeros(nsplit * k * k * 8 * cout, dtype=torch.float32, device=DEV)
+    nsplit = lib.query("drs_conv_wgrad_splits", B, S, k, CP, cout)
+    slab = torch.zeros(nsplit * k * k * CP * cout, dtype=torch.float32, device=DEV)
     gw = torch.zeros(k * k * C * cout, dtype=torch.float32, device=DEV)
-    lib.call("drs_conv_wgrad", xd.data_ptr(), B, S, P, 8, 0, gd.data_ptr(), P, cout, 0, k, rate, pb, 8, C, cout, slab.data_ptr(),
+    lib.call("drs_conv_wgrad", xd.data_ptr(), B, S, P, CP, 0, gd.data_ptr(), P, cout, 0, k, rate, pb, CP, C, cout, slab.data_ptr(),
              gw.data_ptr(), stream())
     torch.cuda.synchronize()
     ref = T.conv2d_same(x.astype(np.float64), w.astype(np.float64), rate)
