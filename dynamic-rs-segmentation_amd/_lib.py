@@ -25,6 +25,8 @@ SIGNATURES = {
     "drs_conv_wgrad_split": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p]),
     "drs_colsum_scratch_doubles": (_i, [_i]),
     "drs_stats_reduce": (_i, [_p, _i, _i, _p, _p, _p]),
+    "drs_conv_stats_reduce": (_i, [_p, _i, _i, _i, _p, _p, _p]),
+    "drs_conv_stats_finish": (_i, [_p, _i, _i, _i, _d, _p, _p, _p, _d, _i, _p, _p]),
     "drs_bn_finish": (_i, [_p, _d, _i, _p, _p, _p, _d, _i, _p]),
     "drs_bn_eval_coeffs": (_i, [_p, _p, _i, _p, _p]),
     "drs_bn_act_pool_forward": (_i, [_p, _i, _i, _i, _p, _f, _i, _p, _i, _i, _i, _p, _p]),

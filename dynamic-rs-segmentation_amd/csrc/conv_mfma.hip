@@ -40,7 +40,7 @@ struct ConvArgs {
 // filter taps x Cin channels instead of one tap x 32 channels, so the contraction is k*k*Cin long rather than k*k*32 (conv1: 224
 // instead of 800); every thread adds the offset of ITS tap.  The filter is [round_up(k*k*Cin, 32)][Cout] with zero tail rows.
 template <int BM, int BN, int WM, int WN, bool PACK = false>
-__global__ __launch_bounds__(256, BM == 256 ? 3 : 1) void conv_igemm_kernel(const ConvArgs a) {   // 256-row tiles: hold the allocation to 3 waves per SIMD
+__global__ __launch_bounds__(256, (BM == 256 || BN == 128) ? 3 : 1) void conv_igemm_kernel(const ConvArgs a) {   // 256-row and 128x128 tiles: hold the allocation to 3 waves per SIMD
   static_assert(WM * WN == 4, "4 waves");
   constexpr int LDB = BN + 4;
   constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
@@ -172,51 +172,40 @@ __global__ __launch_bounds__(256, BM == 256 ? 3 : 1) void conv_igemm_kernel(cons
   }
 
   // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  float s1[TN], s2[TN];
-#pragma unroll
-  for (int ni = 0; ni < TN; ++ni) { s1[ni] = 0.f; s2[ni] = 0.f; }
+  float bv[TN];
 #pragma unroll
   for (int ni = 0; ni < TN; ++ni) {
     const int col = n0 + wn * WTN + ni * 32 + li;
-    const float bv = a.bias ? a.bias[col] : 0.f;
+    bv[ni] = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row < a.M) {
-          float v = acc[mi][ni][r] + bv;
+          float v = acc[mi][ni][r] + bv[ni];
           float* dst = a.out + (size_t)row * a.ld_out + a.coff_out + col;
           if (a.accumulate) v += *dst;
           *dst = v;
-          s1[ni] += v;
-          s2[ni] += v * v;
         }
       }
     }
   }
   if (a.stats) {
-    // fixed-order reduction: lane halves, then the WM waves that share these columns; one slab row per M tile
-    float* red = lds;   // [WM][BN][2], aliases the (finished) A tile
+    // batch-norm statistics of the tile (never together with accumulate): fixed-order reduction over the lane halves, then
+    // over the WM waves that share a column; one slab row per M tile; lds aliases the (finished) A tile
+    const int rem = a.M - m0;
+    tile_column_stats<TN, WM, BN>(
+        lds, t, wm, h == 0, (float)(rem < BM ? rem : BM), [&](int ni) { return wn * WTN + ni * 32 + li; },
+        [](float s) { return s + __shfl_xor(s, 32); },
+        [&](int ni, auto f) {
 #pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-      s1[ni] += __shfl_xor(s1[ni], 32);
-      s2[ni] += __shfl_xor(s2[ni], 32);
-      if (h == 0) {
-        const int c = wn * WTN + ni * 32 + li;
-        red[(wm * BN + c) * 2 + 0] = s1[ni];
-        red[(wm * BN + c) * 2 + 1] = s2[ni];
-      }
-    }
-    __syncthreads();
-    if (t < BN) {
-      float u1 = 0.f, u2 = 0.f;
+          for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-      for (int w = 0; w < WM; ++w) { u1 += red[(w * BN + t) * 2]; u2 += red[(w * BN + t) * 2 + 1]; }
-      float* dst = a.stats + ((size_t)(m0 / BM) * a.Cout + n0 + t) * 2;
-      dst[0] = u1;
-      dst[1] = u2;
-    }
+            for (int r = 0; r < 16; ++r)
+              if (m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < a.M) f(acc[mi][ni][r] + bv[ni]);
+        },
+        a.stats + ((size_t)(m0 / BM) * a.Cout + n0) * 2);
   }
 }
 
@@ -516,6 +505,7 @@ int drs_conv_forward(const float* in, int B, int S, int P, int ld_in, int coff_i
   // cin: a multiple of 32, or 8 / 16 (few-band input: several taps share a K-step; w then has round_up(k*k*cin, 32) rows)
   if (!in || !w || !out || (cin % 32 && cin != 8 && cin != 16) || cout % 32 || k < 1 || rate < 1 || P < pad_before) return DRS_ERR_ARG;
   if (cin < 32 && (ld_in % 4 || coff_in % 4)) return DRS_ERR_ARG;
+  if (accumulate && stats_partial) return DRS_ERR_ARG;              // the tile statistics are those of this call's own sums
   if (P < (k - 1) * rate - pad_before) return DRS_ERR_ARG;          // halo must cover pad_after too
   const long long M = (long long)B * S * S;
   if (M <= 0 || M >= (1 << 24)) return DRS_ERR_ARG;

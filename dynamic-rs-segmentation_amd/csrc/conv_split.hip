@@ -218,50 +218,38 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const SplitConvArgs a) 
   }
 
   // ---- epilogue (as conv_igemm_kernel): C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  float s1[TN], s2[TN];
-#pragma unroll
-  for (int ni = 0; ni < TN; ++ni) { s1[ni] = 0.f; s2[ni] = 0.f; }
+  float bv[TN];
 #pragma unroll
   for (int ni = 0; ni < TN; ++ni) {
     const int col = n0 + wn * WTN + ni * 32 + li;
-    const float bv = a.bias ? a.bias[col] : 0.f;
+    bv[ni] = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row < a.M) {
-          float v = acc[mi][ni][r] + bv;
+          float v = acc[mi][ni][r] + bv[ni];
           float* dst = a.out + (size_t)row * a.ld_out + a.coff_out + col;
           if (a.accumulate) v += *dst;
           *dst = v;
-          s1[ni] += v;
-          s2[ni] += v * v;
         }
       }
     }
   }
-  if (a.stats) {
-    float* red = reinterpret_cast<float*>(lds);   // [WM][BN][2], aliases the (finished) A tile
+  if (a.stats) {      // two-pass tile statistics, see tile_column_stats (drs_common.hpp); lds aliases the (finished) A tile
+    const int rem = a.M - m0;
+    tile_column_stats<TN, WM, BN>(
+        reinterpret_cast<float*>(lds), t, wm, h == 0, (float)(rem < BM ? rem : BM), [&](int ni) { return wn * WTN + ni * 32 + li; },
+        [](float s) { return s + __shfl_xor(s, 32); },
+        [&](int ni, auto f) {
 #pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-      s1[ni] += __shfl_xor(s1[ni], 32);
-      s2[ni] += __shfl_xor(s2[ni], 32);
-      if (h == 0) {
-        const int c = wn * WTN + ni * 32 + li;
-        red[(wm * BN + c) * 2 + 0] = s1[ni];
-        red[(wm * BN + c) * 2 + 1] = s2[ni];
-      }
-    }
-    __syncthreads();
-    if (t < BN) {
-      float u1 = 0.f, u2 = 0.f;
+          for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-      for (int w = 0; w < WM; ++w) { u1 += red[(w * BN + t) * 2]; u2 += red[(w * BN + t) * 2 + 1]; }
-      float* dst = a.stats + ((size_t)(m0 / BM) * a.Cout + n0 + t) * 2;
-      dst[0] = u1;
-      dst[1] = u2;
-    }
+            for (int r = 0; r < 16; ++r)
+              if (m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < a.M) f(acc[mi][ni][r] + bv[ni]);
+        },
+        a.stats + ((size_t)(m0 / BM) * a.Cout + n0) * 2);
   }
 }
 
@@ -379,52 +367,38 @@ __global__ __launch_bounds__(256) void conv_split_dma_kernel(const SplitConvArgs
     __syncthreads();
   }
 
-  float s1[TN], s2[TN];
-#pragma unroll
-  for (int ni = 0; ni < TN; ++ni) { s1[ni] = 0.f; s2[ni] = 0.f; }
+  float bv[TN];
 #pragma unroll
   for (int ni = 0; ni < TN; ++ni) {
     const int col = n0 + wn * WTN + ni * 16 + li;
-    const float bv = a.bias ? a.bias[col] : 0.f;
+    bv[ni] = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wm * WTM + mi * 16 + 4 * h + r;
         if (row < a.M) {
-          float v = acc[mi][ni][r] + bv;
+          float v = acc[mi][ni][r] + bv[ni];
           float* dst = a.out + (size_t)row * a.ld_out + a.coff_out + col;
           if (a.accumulate) v += *dst;
           *dst = v;
-          s1[ni] += v;
-          s2[ni] += v * v;
         }
       }
     }
   }
-  if (a.stats) {
-    float* red = reinterpret_cast<float*>(lds);
+  if (a.stats) {      // two-pass tile statistics, see tile_column_stats (drs_common.hpp); the 16x16 C/D map puts a column in 4 lanes
+    const int rem = a.M - m0;
+    tile_column_stats<TN, WM, BN>(
+        reinterpret_cast<float*>(lds), t, wm, h == 0, (float)(rem < BM ? rem : BM), [&](int ni) { return wn * WTN + ni * 16 + li; },
+        [](float s) { s += __shfl_xor(s, 16); return s + __shfl_xor(s, 32); },
+        [&](int ni, auto f) {
 #pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-      s1[ni] += __shfl_xor(s1[ni], 16);
-      s2[ni] += __shfl_xor(s2[ni], 16);
-      s1[ni] += __shfl_xor(s1[ni], 32);
-      s2[ni] += __shfl_xor(s2[ni], 32);
-      if (h == 0) {
-        const int c = wn * WTN + ni * 16 + li;
-        red[(wm * BN + c) * 2 + 0] = s1[ni];
-        red[(wm * BN + c) * 2 + 1] = s2[ni];
-      }
-    }
-    __syncthreads();
-    if (t < BN) {
-      float u1 = 0.f, u2 = 0.f;
+          for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-      for (int w = 0; w < WM; ++w) { u1 += red[(w * BN + t) * 2]; u2 += red[(w * BN + t) * 2 + 1]; }
-      float* dst = a.stats + ((size_t)(m0 / BM) * a.Cout + n0 + t) * 2;
-      dst[0] = u1;
-      dst[1] = u2;
-    }
+            for (int r = 0; r < 4; ++r)
+              if (m0 + wm * WTM + mi * 16 + 4 * h + r < a.M) f(acc[mi][ni][r] + bv[ni]);
+        },
+        a.stats + ((size_t)(m0 / BM) * a.Cout + n0) * 2);
   }
 #endif
 }
@@ -913,6 +887,7 @@ int drs_conv_forward_split(const unsigned short* in, int B, int S, int P, int ld
                            int coff_out, int accumulate, float* stats_partial, int nsplit, void* stream) {
   if (!in || !w || !out || cin % 32 || cout % 64 || k < 1 || rate < 1 || P < pad_before) return DRS_ERR_ARG;
   if (P < (k - 1) * rate - pad_before || (ld_in & 31) || (coff_in & 31) || (nsplit != 2 && nsplit != 3)) return DRS_ERR_ARG;
+  if (accumulate && stats_partial) return DRS_ERR_ARG;
   const long long M = (long long)B * S * S;
   if (M <= 0 || M >= (1 << 24)) return DRS_ERR_ARG;
   // the kernels address with 32-bit element offsets: the whole term image of the input slab and the filter must stay below 2^32

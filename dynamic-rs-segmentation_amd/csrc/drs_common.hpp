@@ -104,6 +104,49 @@ __device__ __forceinline__ int next_live_chunk(int c, int S2, float rcpSS, int l
   return ((r < lo ? b : b + 1) * S2 + lo) >> 5;       // the chunk holding the first live pixel ahead
 }
 
+// Train-mode batch-norm statistics of one output tile of a convolution kernel (the first half of isprs:655-663), taken in the
+// epilogue from the accumulator registers: per tile column (sum v, M2 = sum (v - tile mean)^2), TWO-PASS inside the tile as
+// TensorFlow's batch_norm is two-pass over the batch.  The tiles are combined in fp64 by Chan's formula
+// (drs_conv_stats_reduce: sum z^2 = sum_i (M2_i + s_i^2 / n_i)), so nothing is lost to cancellation in fp32 whatever
+// |mean| / std is; a plain per-tile (sum v, sum v^2) loses ~(mean/std)^2 * 2^-24 of the variance.
+//   NSLOT column slots per lane; slot ni is tile column col(ni); `lanesum` adds the lanes of a wave that hold the same column
+//   (a fixed butterfly); the WM waves that share a column are added through LDS in wave order; `each(ni, f)` calls f(v) for
+//   every valid value this lane holds of slot ni; `writer` = this lane writes its wave's column totals;
+//   red: 2 * WM * BN floats of LDS no wave reads any more; dst: this tile's [BN][2] run of the statistics slab row.
+template <int NSLOT, int WM, int BN, class Col, class LaneSum, class Each>
+__device__ __forceinline__ void tile_column_stats(float* red, int t, int wm, bool writer, float n_tile, Col col, LaneSum lanesum,
+                                                  Each each, float* dst) {
+  float* red2 = red + WM * BN;
+#pragma unroll
+  for (int ni = 0; ni < NSLOT; ++ni) {
+    float s = 0.f;
+    each(ni, [&](float v) { s += v; });
+    s = lanesum(s);
+    if (writer) red[wm * BN + col(ni)] = s;
+  }
+  __syncthreads();
+  const float rn = 1.0f / n_tile;
+#pragma unroll
+  for (int ni = 0; ni < NSLOT; ++ni) {
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) tot += red[w * BN + col(ni)];
+    const float mean = tot * rn;
+    float q = 0.f;
+    each(ni, [&](float v) { const float d = v - mean; q += d * d; });
+    q = lanesum(q);
+    if (writer) red2[wm * BN + col(ni)] = q;
+  }
+  __syncthreads();
+  if (t < BN) {
+    float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) { u1 += red[w * BN + t]; u2 += red2[w * BN + t]; }
+    dst[2 * t] = u1;
+    dst[2 * t + 1] = u2;
+  }
+}
+
 // development switch shared by the convolution kernels (drs_debug_skip_taps): 0 = multiply the all-halo taps / chunks too,
 // 1 = skip them where it pays, 2 = skip them always
 extern int drs_g_skip_halo_taps;

@@ -50,6 +50,63 @@ __global__ void colsum_l2_kernel(const double* __restrict__ scratch, int ncols, 
   out[c] = (OUT)s;
 }
 
+// Single-launch form for the batch-norm statistic slabs [nrows][C][2]: one workgroup per 4 channels, 64 row lanes, fp64
+// accumulation, a fixed halving tree in LDS (bitwise reproducible).  CHAN: the slab comes from a convolution epilogue
+// (tile_column_stats): row r holds per channel (s_r, M2_r) over n_r = min(mtile, M - r*mtile) pixels and the rows combine by
+// Chan's formula, sum z^2 = sum_r (M2_r + s_r^2 / n_r); otherwise both columns are plain sums (the backward pass's
+// (sum g, sum g*xhat)).  With mean_rstd != null the workgroup also finishes the batch norm of its channels (bn_finish_kernel's
+// arithmetic): statistics reduction and finish are then ONE launch (single-rank case; under data parallelism the all-reduce of
+// `sums` sits between the two).
+constexpr int STAT_CH = 4, STAT_LANES = 64;
+template <bool CHAN>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ partial, int nrows, int C, int M, int mtile,
+                                                       double* __restrict__ sums, double count, float* __restrict__ mean_rstd,
+                                                       float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                                                       float one_minus_decay, int bessel) {
+  __shared__ double sh[STAT_LANES][STAT_CH][2];
+  const int ch = threadIdx.x & (STAT_CH - 1), rl = threadIdx.x / STAT_CH;
+  const int c = blockIdx.x * STAT_CH + ch;
+  double a0 = 0.0, a1 = 0.0;
+  if (c < C) {
+    const float2* src = reinterpret_cast<const float2*>(partial) + c;
+#pragma unroll 8
+    for (int r = rl; r < nrows; r += STAT_LANES) {
+      const float2 v = src[(size_t)r * C];
+      const double s = (double)v.x;
+      a0 += s;
+      if (CHAN) {
+        const int rem = M - r * mtile;
+        a1 += (double)v.y + s * s / (double)(rem < mtile ? rem : mtile);
+      } else {
+        a1 += (double)v.y;
+      }
+    }
+  }
+  sh[rl][ch][0] = a0;
+  sh[rl][ch][1] = a1;
+  __syncthreads();
+  for (int d = STAT_LANES / 2; d >= 1; d >>= 1) {
+    if (rl < d) { sh[rl][ch][0] += sh[rl + d][ch][0]; sh[rl][ch][1] += sh[rl + d][ch][1]; }
+    __syncthreads();
+  }
+  if (rl != 0 || c >= C) return;
+  const double s0 = sh[0][ch][0], s1 = sh[0][ch][1];
+  if (sums) { sums[2 * c] = s0; sums[2 * c + 1] = s1; }
+  if (mean_rstd) {
+    const double m = s0 / count;
+    double var = s1 / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)m, vf = (float)var;
+    mean_rstd[2 * c] = mf;
+    mean_rstd[2 * c + 1] = 1.0f / sqrtf(vf + BN_EPS);
+    if (moving_mean) {
+      const float vu = bessel && count > 1.0 ? (float)(var * (count / (count - 1.0))) : vf;
+      moving_mean[c] = moving_mean[c] - (moving_mean[c] - mf) * one_minus_decay;
+      moving_var[c] = moving_var[c] - (moving_var[c] - vu) * one_minus_decay;
+    }
+  }
+}
+
 // sums (global over the batch, all ranks) -> mean, rstd; moving averages updated as
 // moving -= (moving - value) * (1 - decay)  (tf assign_moving_average); the moving variance takes the
 // Bessel-corrected batch variance (TF fused batch norm), the normalisation the biased one.
@@ -832,10 +889,26 @@ extern "C" {
 int drs_colsum_scratch_doubles(int ncols) { return COLSUM_BLOCKS * ncols; }
 
 int drs_stats_reduce(const float* partial, int nrows, int C, double* sums, double* scratch, void* stream) {
-  if (!partial || !sums || !scratch || nrows < 1) return DRS_ERR_ARG;
-  const int ncols = 2 * C;
-  DRS_LAUNCH(colsum_l1_kernel, dim3((ncols + 63) / 64, COLSUM_BLOCKS), dim3(256), 0, (hipStream_t)stream, partial, nrows, ncols, scratch);
-  DRS_LAUNCH(colsum_l2_kernel<double>, dim3((ncols + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, ncols, sums);
+  (void)scratch;      // kept in the signature: earlier revisions reduced in two launches through it
+  if (!partial || !sums || nrows < 1 || C < 1) return DRS_ERR_ARG;
+  DRS_LAUNCH(bn_stats_kernel<false>, dim3((C + STAT_CH - 1) / STAT_CH), dim3(256), 0, (hipStream_t)stream, partial, nrows, C, 0, 1, sums,
+             1.0, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f, 0);
+  return DRS_LAUNCH_CHECK();
+}
+
+int drs_conv_stats_reduce(const float* partial, int M, int mtile, int C, double* sums, double* scratch, void* stream) {
+  (void)scratch;
+  if (!partial || !sums || M < 1 || mtile < 1 || C < 1) return DRS_ERR_ARG;
+  DRS_LAUNCH(bn_stats_kernel<true>, dim3((C + STAT_CH - 1) / STAT_CH), dim3(256), 0, (hipStream_t)stream, partial, (M + mtile - 1) / mtile, C,
+             M, mtile, sums, 1.0, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f, 0);
+  return DRS_LAUNCH_CHECK();
+}
+
+int drs_conv_stats_finish(const float* partial, int M, int mtile, int C, double count, float* mean_rstd, float* moving_mean,
+                          float* moving_var, double decay, int bessel, double* sums, void* stream) {
+  if (!partial || !mean_rstd || M < 1 || mtile < 1 || C < 1 || count < 1.0) return DRS_ERR_ARG;
+  DRS_LAUNCH(bn_stats_kernel<true>, dim3((C + STAT_CH - 1) / STAT_CH), dim3(256), 0, (hipStream_t)stream, partial, (M + mtile - 1) / mtile, C,
+             M, mtile, sums, count, mean_rstd, moving_mean, moving_var, (float)(1.0 - decay), bessel);
   return DRS_LAUNCH_CHECK();
 }
 

@@ -378,9 +378,12 @@ class DilatedNet(object):
                         L.k, L.rate, L.pad_b, L.cin_k, L.cout, _ptr(self.z[i]), L.cout, 0, 0, _ptr(stats), st)
             bo = p.bn_offsets[L.name]
             mm, mv = self.bn[bo:bo + L.cout], self.bn[bo + L.cout:bo + 2 * L.cout]
-            if training:
-                mt = self._mtile(i)
-                _lib.call("drs_stats_reduce", _ptr(self.partial), (M + mt - 1) // mt, L.cout, _ptr(self.sums), _ptr(self.colsum_scratch), st)
+            if training and self.comm.world == 1:
+                # tile statistics -> (mean, rstd) and the moving averages in one launch
+                _lib.call("drs_conv_stats_finish", _ptr(self.partial), M, self._mtile(i), L.cout, float(count), _ptr(self.mean_rstd[i]),
+                          _ptr(mm), _ptr(mv), BN_DECAY, self.bessel, None, st)
+            elif training:
+                _lib.call("drs_conv_stats_reduce", _ptr(self.partial), M, self._mtile(i), L.cout, _ptr(self.sums), None, st)
                 self.comm.all_reduce_sum(self.sums[:2 * L.cout])           # sync batch norm over the global batch
                 _lib.call("drs_bn_finish", _ptr(self.sums), float(count), L.cout, _ptr(self.mean_rstd[i]), _ptr(mm), _ptr(mv),
                           BN_DECAY, self.bessel, st)

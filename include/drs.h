@@ -37,8 +37,10 @@ extern "C" {
  * out[p, coff_out + o] (=|+=) sum_{u,v,c} in[p + (u,v)*rate - pad_before, c] * w[u][v][c][o] + bias[o]
  * `in` is a haloed view with P >= max(pad_before, pad_after); cin, cout multiples of 32 (conv1's 3..5 bands
  * are zero-padded to 32 by drs_crop_normalize / drs_filter_pad_cin).  `out` is [B*S*S][ld_out].
- * stats_partial (or NULL): [ceil(B*S*S / drs_conv_mtile(cout))][cout][2] per-tile (sum, sum of squares) of
- * the outputs, the first half of train-mode batch norm (isprs:658-660).
+ * stats_partial (or NULL; not together with accumulate): [ceil(B*S*S / drs_conv_mtile(cout))][cout][2], per M tile and
+ * output channel (s, M2) = (sum of the tile's outputs, sum of their squared deviations from the TILE's mean): the first half
+ * of train-mode batch norm (isprs:658-660), two-pass inside the tile as TensorFlow is two-pass over the batch;
+ * drs_conv_stats_reduce combines the tiles.
  * The input-gradient pass is this same call on the haloed output gradient with the filter from
  * drs_filter_flip_transpose and pad_before := pad_after. */
 int drs_conv_mtile(int cout);
@@ -89,14 +91,22 @@ int drs_conv_wgrad_split(const unsigned short* x, int B, int S, int Px, int ld_x
                          float* slab, float* grad, int nterms, void* stream);
 
 /* ---- tf.contrib.layers.batch_norm(center=False, scale=False, eps=1e-3, decay=0.999)  (isprs:655-663) -----
- * drs_stats_reduce : partial[nrows][C][2] (fp32) -> sums[C][2] (fp64), fixed order; scratch holds
- *                    drs_colsum_scratch_doubles(2*C) doubles.  Under data parallelism the caller all-reduces
- *                    `sums` between this call and the next (sync batch norm).
+ * drs_stats_reduce : partial[nrows][C][2] (fp32) plain column sums -> sums[C][2] (fp64), fixed order (the backward
+ *                    pass's (sum g, sum g*xhat) slabs); scratch is unused (kept in the signature).
+ * drs_conv_stats_reduce : the statistics slab of drs_conv_forward (M = B*S*S pixels, mtile = drs_conv_mtile(cout) or
+ *                    drs_split_conv_mtile(cout)) -> sums[C][2] = (sum z, sum z^2) in fp64 by Chan's combination
+ *                    sum z^2 = sum_tiles (M2 + s^2 / n_tile): no cancellation in fp32 whatever |mean| / std is.
+ *                    Under data parallelism the caller all-reduces `sums` between this call and drs_bn_finish
+ *                    (sync batch norm over the global batch).
+ * drs_conv_stats_finish : drs_conv_stats_reduce + drs_bn_finish in ONE launch (single rank); sums may be NULL.
  * drs_bn_finish    : sums, count -> mean_rstd[C][2] = (mean, 1/sqrt(biased var + eps)); if moving_* != NULL,
  *                    moving -= (moving - batch) * (1 - decay) with the Bessel-corrected variance when bessel.
  * drs_bn_eval_coeffs: is_training=False branch: mean_rstd from the moving statistics. */
 int drs_colsum_scratch_doubles(int ncols);
 int drs_stats_reduce(const float* partial, int nrows, int C, double* sums, double* scratch, void* stream);
+int drs_conv_stats_reduce(const float* partial, int M, int mtile, int C, double* sums, double* scratch, void* stream);
+int drs_conv_stats_finish(const float* partial, int M, int mtile, int C, double count, float* mean_rstd, float* moving_mean,
+                          float* moving_var, double decay, int bessel, double* sums, void* stream);
 int drs_bn_finish(const double* sums, double count, int C, float* mean_rstd, float* moving_mean, float* moving_var,
                   double decay, int bessel, void* stream);
 int drs_bn_eval_coeffs(const float* moving_mean, const float* moving_var, int C, float* mean_rstd, void* stream);

@@ -36,3 +36,12 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
+
+
+def conv_stats_moments(lib, stats, M, mt, cout):
+    """statistics slab of a convolution epilogue (per tile (sum, M2 about the tile mean)) -> numpy [cout, 2] = (sum z, sum z^2),
+    through drs_conv_stats_reduce (Chan combination in fp64)."""
+    sums = torch.zeros(2 * cout, dtype=torch.float64, device=DEV)
+    lib.call("drs_conv_stats_reduce", stats.data_ptr(), M, mt, cout, sums.data_ptr(), None, stream())
+    torch.cuda.synchronize()
+    return sums.cpu().numpy().reshape(cout, 2)

@@ -1,0 +1,250 @@
+"""-m gpu: the BASELINE.json configurations whose sizes change the kernels' behaviour, on the HIP path against the oracle.
+
+  * configs[2] / [3] (`uniform` over [25, 85] at batch 128, `multinomial` up to 100): patch sides above 64 are where the
+    halo-tap skip (drs_common.hpp: >= 4096 workgroups / >= 2^19 pixels), the table (non-affine, S % 32 != 0) form of the
+    filter-gradient kernel and ragged M tiles meet.  Convolutions at B = 128, S in {65, 77, 85} and B = 16, S = 100 are
+    compared with the fp64 oracle on sampled patches (outputs are per-patch independent), the filter gradient exactly (on
+    a gradient that is zero outside the sampled patches) and by adjointness (on a dense one), plus skip-on / skip-off
+    bitwise equality at these sizes.
+  * a `loops.train` run with distribution_type="uniform" over [25, 85] at batch 128 (isprs:1727-1737, 1757-1763).
+  * configs[4]: Dilated8Pooling sliding-window inference at 64 / stride 32 against `host_ref.stitch_tile` over oracle
+    forwards (interior, border and shift-back windows), and one full 6000 x 6000 property run.
+"""
+import random
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import host_ref as H
+from oracle import nets as onets
+from oracle import tf_ops as T
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV, conv_stats_moments, rel_err, stream   # noqa: E402
+
+
+def _padded(x, P):
+    return torch.nn.functional.pad(x, (0, 0, P, P, P, P)).contiguous()
+
+
+# conv8, conv3 (4x4, asymmetric pad 4/5), conv6 (Cout 192: the 128x64 tile) of Dilated8Pooling
+SHAPES = [(3, 8, 256, 256), (4, 3, 64, 128), (3, 6, 192, 192)]
+SIZES = [(128, 65), (128, 77), (128, 85), (16, 100)]
+
+
+@pytest.mark.parametrize("B,S", SIZES)
+@pytest.mark.parametrize("k,rate,cin,cout", SHAPES)
+def test_conv_above_64_matches_oracle_on_sampled_patches(k, rate, cin, cout, B, S):
+    from drs_amd import _lib
+    M = B * S * S
+    g0 = torch.Generator(device=DEV).manual_seed(1000 * k + 10 * rate + S)
+    pb, pa = onets.same_pad(k, rate)
+    P = max(pb, pa)
+    x = torch.randn(B, S, S, cin, device=DEV, generator=g0)
+    g = torch.randn(B, S, S, cout, device=DEV, generator=g0)
+    w = torch.randn(k, k, cin, cout, device=DEV, generator=g0) / (k * k * cin) ** 0.5
+    bias = torch.randn(cout, device=DEV, generator=g0)
+    xp, gp = _padded(x, P), _padded(g, P)
+    st = stream()
+    raw = _lib.load()
+    wt = torch.empty(w.numel(), device=DEV)
+    _lib.call("drs_filter_flip_transpose", w.data_ptr(), wt.data_ptr(), k, cin, cout, st)
+    ns = _lib.query("drs_conv_wgrad_splits", B, S, k, cin, cout)
+    slab = torch.empty(ns * w.numel(), device=DEV)
+    mt = _lib.query("drs_conv_mtile", cout)
+    rows = (M + mt - 1) // mt
+    sample = sorted({0, B // 2, B - 1})
+    gs = torch.zeros_like(g)
+    gs[sample] = g[sample]
+    gsp = _padded(gs, P)
+
+    def run():
+        y = torch.empty(M, cout, device=DEV)
+        stats = torch.zeros(rows * cout * 2, device=DEV)
+        _lib.call("drs_conv_forward", xp.data_ptr(), B, S, P, cin, 0, w.data_ptr(), bias.data_ptr(), k, rate, pb, cin, cout, y.data_ptr(),
+                  cout, 0, 0, stats.data_ptr(), st)
+        gx = torch.empty(M, cin, device=DEV)
+        _lib.call("drs_conv_forward", gp.data_ptr(), B, S, P, cout, 0, wt.data_ptr(), None, k, rate, pa, cout, cin, gx.data_ptr(), cin, 0, 0,
+                  None, st)
+        gw = torch.empty(w.numel(), device=DEV)
+        _lib.call("drs_conv_wgrad", xp.data_ptr(), B, S, P, cin, 0, gp.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout, slab.data_ptr(),
+                  gw.data_ptr(), st)
+        gws = torch.empty(w.numel(), device=DEV)
+        _lib.call("drs_conv_wgrad", xp.data_ptr(), B, S, P, cin, 0, gsp.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout, slab.data_ptr(),
+                  gws.data_ptr(), st)
+        torch.cuda.synchronize()
+        return y, stats, gx, gw, gws
+
+    res = {}
+    try:
+        for mode in (0, 2, 1):          # every tap / chunk multiplied; the all-halo ones skipped; the product's own rule (last)
+            raw.drs_debug_skip_taps(mode)
+            res[mode] = run()
+    finally:
+        raw.drs_debug_skip_taps(1)
+    for a, b, c in zip(res[0], res[2], res[1]):
+        assert torch.equal(a, b) and torch.equal(a, c)          # skipped products are exact zeros: bitwise neutral
+    y, stats, gx, gw, gws = res[1]
+    # (1) forward and input gradient on the sampled patches against the fp64 oracle
+    w64, b64 = w.cpu().numpy().astype(np.float64), bias.cpu().numpy().astype(np.float64)
+    xs, gsn = x[sample].cpu().numpy().astype(np.float64), g[sample].cpu().numpy().astype(np.float64)
+    ref = T.conv2d_same(xs, w64, rate) + b64
+    gx_ref, gw_ref = T.conv2d_same_bwd(xs, w64, rate, gsn)
+    assert rel_err(y.view(B, S, S, cout)[sample].cpu().numpy(), ref) < 1e-5
+    assert rel_err(gx.view(B, S, S, cin)[sample].cpu().numpy(), gx_ref) < 1e-5
+    # (2) the filter gradient of the sampled patches (same grid, splits and chunk walk as the dense one), exactly
+    assert rel_err(gws.view(k, k, cin, cout).cpu().numpy(), gw_ref) < 1e-5
+    # (3) dense filter gradient and dense input gradient by adjointness with the (checked) forward
+    yb = y.double() - bias.double()
+    a = (yb * g.reshape(M, cout).double()).sum().item()
+    b = (x.reshape(M, cin).double() * gx.double()).sum().item()
+    c = (w.reshape(-1).double() * gw.double()).sum().item()
+    scale = (yb.norm() * g.double().norm()).item()
+    assert abs(a - b) < 1e-6 * scale and abs(a - c) < 1e-6 * scale, (a, b, c)
+    # (4) batch-norm statistics of the epilogue: per-tile sums reduce to the moments of y (ragged last M tile included)
+    sv = conv_stats_moments(_lib, stats, M, mt, cout)
+    y64 = y.double()
+    mean = y64.mean(0).cpu().numpy()
+    var = y64.var(0, unbiased=False).cpu().numpy()
+    np.testing.assert_allclose(sv[:, 0] / M, mean, rtol=0, atol=1e-6 * np.abs(mean).max() + 1e-7)
+    np.testing.assert_allclose(sv[:, 1] / M - (sv[:, 0] / M) ** 2, var, rtol=2e-6)
+
+
+def test_uniform_size_training_loop_config3(tmp_path, capsys):
+    """BASELINE configs[2]: dilated_grsl_rate8, `uniform` over [25, 85], batch 128 (isprs:1727-1737: every integer size of
+    the interval can be drawn; the score arrays are indexed by size - values[0], isprs:1757-1763)."""
+    from drs_amd import loops, sampling as SP
+    from drs_amd.cli import init_size_scores
+    from drs_amd.synthetic import make_tile
+    a, b = make_tile(420, 400, 5, 6, seed=31, n_seeds=60), make_tile(300, 300, 5, 6, seed=32, n_seeds=40)
+    random.seed(5)
+    np.random.seed(5)
+    dist = SP.create_distributions_over_classes([a[1]], 25, 10)
+    tdist = SP.create_distributions_over_classes([b[1]], 25, 25)
+    rot = SP.create_rotation_distribution(dist)
+    values = [25, 85]
+    acc, occ, chosen, probs = init_size_scores("uniform", values)
+    assert len(acc) == 61 and probs is None
+    steps, B = 36, 128
+    out = str(tmp_path) + "/"
+    net = loops.train([a[0]], [a[1]], dist, rot, [b[0]], [b[1]], tdist, ["b"], 0.01, B, steps, 0.005, [0.4] * 5, [0.2] * 5, "acc",
+                      "uniform", values, acc, occ, chosen, probs, 20, out, 12, "dilated_grsl_rate8", "vaihingen", "none",
+                      device=DEV, val_cache_dir=str(tmp_path))
+    text = capsys.readouterr().out
+    assert net.global_step == steps and net.s_max == 85
+    sizes = [int(t) for t in text.split("\n") if t.strip().isdigit()]
+    assert len(sizes) == steps and min(sizes) >= 25 and max(sizes) <= 85
+    assert max(sizes) > 64 and len(set(sizes)) > 10                     # the upper half of the interval was trained on
+    want = np.bincount(np.asarray(sizes) - 25, minlength=61)
+    occ_before_val = np.load(out + "patch_occur_step_%d.npy" % steps)
+    np.testing.assert_array_equal(occ_before_val, want)                 # every step scored its own size, once
+    score = np.load(out + "patch_acc_loss_step_%d.npy" % steps)
+    assert np.all(score[want == 0] == 0) and np.all(score[want > 0] > 0) and np.all(score <= want + 1e-6)   # normalised accuracies
+    assert np.all(np.isfinite(net.params.cpu().numpy()))
+    losses = [float(t.split("Loss= ")[1].split()[0]) for t in text.split("\n") if "Training Minibatch" in t]
+    assert len(losses) == 3 and all(np.isfinite(losses)) and losses[-1] < 1.5 * losses[0]       # sizes differ per step: no monotonic claim
+    assert "Validation: Overall Accuracy=" in text
+    best = int(text.split("Current patch size ")[1].split()[0])
+    assert best == 25 + int(np.argmax(score / np.maximum(want, 1)))     # select_best_patch_size, isprs:549-608
+
+
+def _oracle_tile(o, tile, lab, S, bs, mean, std, K):
+    st = H.stride_for(S)
+    h, w = tile.shape[:2]
+    nh, nw = H.window_counts(h, w, S, st)
+    batches = []
+    for i in range(-(-nh * nw // bs)):
+        p, _, pos = H.create_patches_per_map(tile, lab, S, st, i, bs)
+        p = p.copy()
+        H.normalize_images(p, mean, std)
+        batches.append((o.forward(p.astype(np.float32).astype(np.float64), False).astype(np.float32), pos))
+    return H.stitch_tile(h, w, K, S, batches)
+
+
+def test_config5_sliding_window_dilated8_at_64_matches_oracle():
+    """BASELINE configs[4] at the real window geometry (Dilated8Pooling, 64 x 64, stride 32, isprs:1241-1284) on a mosaic
+    small enough for the fp64 oracle: interior windows, windows on all four borders and the shifted-back last row / column."""
+    from drs_amd import loops, patches as P
+    from drs_amd.net import DilatedNet
+    from drs_amd.synthetic import make_tile
+    net_type, ch, K, S, bs = "dilated_grsl_rate8", 5, 6, 64, 6
+    h, w = 130, 141                          # (130-64) % 32 != 0 and (141-64) % 32 != 0: both axes end on a shifted-back window
+    tile, lab = make_tile(h, w, ch, K, seed=17, n_seeds=30)
+    mean, std = np.array([0.5, 0.5, 0.5, 0, 0]), np.array([0.25, 0.25, 0.25, 1, 1])
+    d = DilatedNet(net_type, ch, K, 0.005, b_max=bs, s_max=S, device=DEV, seed=3)
+    rng = np.random.default_rng(4)
+    for L in d.plan.layers:                  # non-trivial moving statistics (a trained net's eval path)
+        d.set_variable(L.name + "/moving_mean", rng.normal(size=L.cout) * 0.1)
+        d.set_variable(L.name + "/moving_variance", rng.uniform(0.5, 1.5, size=L.cout))
+    o = T.OracleNet(net_type, ch, K, seed=3)
+    for n in d.variable_names():
+        o.p[n] = d.get_variable(n).astype(np.float64)
+    pool = P.TilePool([tile], [lab], DEV)
+    nh, nw = P.window_counts(h, w, S, 32)
+    assert (nh, nw) == (4, 4)
+    pos_all = P.window_positions(h, w, S, 32, 0, nh * nw)
+    assert pos_all[:, 0].max() == h - S and pos_all[:, 1].max() == w - S and (h - S) % 32 and (w - S) % 32
+    prob_d, occ_d, total = loops.predict_tile(d, pool, 0, S, bs, mean, std, return_sums=True)
+    pred, _ = loops.predict_tile(d, pool, 0, S, bs, mean, std)
+    torch.cuda.synchronize()
+    assert total == 16
+    prob, occur, am = _oracle_tile(o, tile, lab, S, bs, mean, std, K)
+    np.testing.assert_array_equal(occ_d.view(h, w).cpu().numpy(), occur[..., 0] if occur.ndim == 3 else occur)
+    got_prob = prob_d.view(h, w, K).cpu().numpy()
+    assert rel_err(got_prob, prob) < 1e-3                       # north-star tolerance on summed logits
+    avg = prob / occur
+    srt = np.sort(avg, axis=2)
+    clear = (srt[..., -1] - srt[..., -2]) > 1e-3 * np.abs(avg).max()
+    assert clear.mean() > 0.95
+    np.testing.assert_array_equal(pred.cpu().numpy()[clear], am[clear])
+
+
+def test_config5_full_6000x6000_mosaic_properties():
+    """BASELINE configs[4] at full size: 34 969 windows of 64 x 64 at stride 32 over a 6000 x 6000 x 5 mosaic.  Properties that
+    do not need the oracle: the overlap counts equal the window coverage (product of the per-axis coverages, shifted-back last
+    window included), every pixel is covered, the label map is the arg-max of the summed logits, a repeat is bitwise equal."""
+    from drs_amd import loops, patches as P, _lib
+    from drs_amd.net import DilatedNet
+    n, S, Bw, K = 6000, 64, 256, 6
+    g0 = torch.Generator(device=DEV).manual_seed(5)
+    tile = torch.rand(n * n * 5, device=DEV, generator=g0)
+    pool = P.TilePool([np.zeros((S, S, 5), dtype=np.float32)], None, DEV, dtype=np.float32)     # shell; the mosaic is made on the device
+    pool.tiles, pool.labels = tile, torch.zeros(n * n, dtype=torch.uint8, device=DEV)
+    pool.h, pool.w = [n], [n]
+    pool.tile_h = torch.tensor([n], dtype=torch.int32, device=DEV)
+    pool.tile_w = torch.tensor([n], dtype=torch.int32, device=DEV)
+    net = DilatedNet("dilated_grsl_rate8", 5, K, 0.005, b_max=Bw, s_max=S, device=DEV, seed=42)
+    mean, std = [0.5] * 3, [0.29] * 3
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    prob, occ, total = loops.predict_tile(net, pool, 0, S, Bw, mean, std, return_sums=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nh, nw = P.window_counts(n, n, S, 32)
+    assert (nh, nw) == (187, 187) and total == 34969
+    print("config 5 full size: %d windows in %.2f s = %.1f M window-pixels/s" % (total, dt, total * S * S / dt / 1e6))
+    cov1 = np.zeros(n, dtype=np.int64)
+    for i in range(nh):
+        x0 = min(i * 32, n - S)
+        cov1[x0:x0 + S] += 1
+    assert cov1.min() >= 1
+    c = torch.from_numpy(cov1).to(DEV)
+    assert torch.equal(occ.view(n, n).long(), c[:, None] * c[None, :])
+    out = torch.zeros(n * n, dtype=torch.uint8, device=DEV)
+    _lib.call("drs_stitch_finalize", prob.data_ptr(), occ.data_ptr(), n, n, K, out.data_ptr(), stream())
+    torch.cuda.synchronize()
+    avg = prob.view(n * n, K) / occ.view(-1, 1).float()
+    assert torch.equal(out.long(), avg.argmax(1))
+    assert bool(torch.isfinite(prob).all())
+    # the corner window is exactly the forward pass of that window alone
+    P.crop_to_net(net, pool, np.array([[0, 0, 0]]), S, mean, std)
+    _, lg = net.forward(1, S)
+    torch.cuda.synchronize()
+    assert torch.equal(prob.view(n, n, K)[:32, :32], lg[0, :32, :32])       # pixels covered by the first window only
+    del avg
+    prob2, occ2, _ = loops.predict_tile(net, pool, 0, S, Bw, mean, std, return_sums=True)
+    torch.cuda.synchronize()
+    assert torch.equal(prob, prob2) and torch.equal(occ, occ2)

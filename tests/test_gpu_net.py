@@ -56,6 +56,35 @@ def _decisions(d, B, S):
     return out
 
 
+def _check_decision_margins(o, dec, tol=1e-4, max_frac=2e-3):
+    """The decision-aligned oracle follows the device's ReLU signs and pool winners, so a kernel that took a clearly wrong
+    decision would be followed, not caught.  This closes that: after a FREE-running fp64 pass (o._cache), every device
+    decision that differs from the fp64 one must sit on a near-tie of the fp64 values -- |xhat| below `tol` for a sign, the
+    device's winner within `tol` of the window maximum for a pool (xhat is normalised, so `tol` is absolute in units of one
+    standard deviation; fp32 rounding through 8 layers is ~1e-5) -- and such elements must be rare."""
+    worst_sign = worst_pool = 0.0
+    for li, dc in enumerate(dec):
+        inp, z, mean, var, xh, idx_free, _ = o._cache[li]
+        flip = dc["pos"] != (xh > 0)
+        assert flip.mean() <= max_frac, (li, flip.mean())
+        if flip.any():
+            worst_sign = max(worst_sign, float(np.abs(xh[flip]).max()))
+        if "idx" in dc and o.spec["pool"]:
+            a = T.act_fwd(xh, o.spec["act"])
+            B, H, W, C = a.shape
+            ap = np.full((B, H + 2, W + 2, C), -np.inf)
+            ap[:, 1:-1, 1:-1, :] = a
+            stack = np.stack([ap[:, dy:dy + H, dx:dx + W, :] for dy in range(3) for dx in range(3)], axis=0)
+            didx = dc["idx"].astype(np.int64)
+            assert didx.max() <= 8
+            at_dev = np.take_along_axis(stack, didx[None], axis=0)[0]
+            margin = stack.max(axis=0) - at_dev                  # 0 where the device picked an fp64 maximum; inf if it picked padding
+            diff = didx != idx_free.astype(np.int64)
+            assert diff.mean() <= max_frac, (li, diff.mean())
+            worst_pool = max(worst_pool, float(margin.max()))
+    assert worst_sign < tol and worst_pool < tol, (worst_sign, worst_pool)
+
+
 def _argmax_agrees(pred, logits64):
     srt = np.sort(logits64, axis=-1)
     margin = srt[..., -1] - srt[..., -2]
@@ -91,9 +120,11 @@ def _check_eval_and_train(net, ch, K, B, S, arith):
     loss_free, _, _, logits_free = o.loss_and_grads(x.astype(np.float64), y, 0.005)
     assert rel_err(d.logits[:B * S * S * K].cpu().numpy().reshape(B, S, S, K), logits_free) < 1e-3
     assert abs(d.loss_value(out["loss_parts"]) - loss_free) < 1e-4 * abs(loss_free)
+    dec = _decisions(d, B, S)
+    _check_decision_margins(o, dec, tol=2e-3 if arith == "bf16x3" else 1e-4)    # the device's discrete decisions are the fp64 ones except on near-ties
     o.p.update(mm0)
     # (b) decision-aligned oracle (same ReLU signs / pool winners as the device): gradients compare tightly
-    loss_ref, pred_ref, g_ref, logits_ref = o.loss_and_grads(x.astype(np.float64), y, 0.005, decisions=_decisions(d, B, S))
+    loss_ref, pred_ref, g_ref, logits_ref = o.loss_and_grads(x.astype(np.float64), y, 0.005, decisions=dec)
     assert abs(d.loss_value(out["loss_parts"]) - loss_ref) < 1e-4 * abs(loss_ref)
     lg = d.logits[:B * S * S * K].cpu().numpy().reshape(B, S, S, K)
     assert rel_err(lg, logits_ref) < 1e-3

@@ -10,7 +10,7 @@ from oracle import nets as onets
 
 pytestmark = pytest.mark.gpu
 
-from gpu_util import DEV, dev, padded, rel_err, stream, unpad   # noqa: E402
+from gpu_util import DEV, conv_stats_moments, dev, padded, rel_err, stream, unpad   # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -53,7 +53,7 @@ def test_conv_forward_dgrad_wgrad(lib, k, rate, cin, cout, B, S):
     got = out.cpu().numpy()
     assert rel_err(got[:, 32:].reshape(B, S, S, cout), ref) < 1e-5
     assert np.all(got[:, :32] == -3.0)                      # neighbouring channels untouched
-    st = stats.cpu().numpy().reshape(rows, cout, 2).astype(np.float64).sum(axis=0)
+    st = conv_stats_moments(lib, stats, M, mt, cout)
     r2 = ref.reshape(-1, cout)
     assert np.abs(st[:, 0] - r2.sum(axis=0)).max() < 1e-5 * np.abs(r2).sum(axis=0).max()
     assert rel_err(st[:, 1], (r2 ** 2).sum(axis=0)) < 1e-5
@@ -204,7 +204,7 @@ def test_conv1_packed_taps(lib, C, cout, k, rate, B, S, CP):
     ref = T.conv2d_same(x.astype(np.float64), w.astype(np.float64), rate)
     _, gw_ref = T.conv2d_same_bwd(x.astype(np.float64), w.astype(np.float64), rate, g.astype(np.float64))
     assert rel_err(out.cpu().numpy().reshape(B, S, S, cout), ref) < 1e-5
-    st = stats.cpu().numpy().reshape(nrow, cout, 2).astype(np.float64).sum(axis=0)
+    st = conv_stats_moments(lib, stats, M, mt, cout)
     assert np.abs(st[:, 0] - ref.reshape(-1, cout).sum(axis=0)).max() < 1e-5 * np.abs(ref).sum(axis=(0, 1, 2)).max()
     assert rel_err(gw.cpu().numpy().reshape(k, k, C, cout), gw_ref) < 1e-5
 
@@ -388,3 +388,43 @@ def test_momentum_l2_confusion(lib):
     keep = (m > 0) & (y != 6)
     np.add.at(cm, (y[keep], p[keep]), 1)
     np.testing.assert_array_equal(conf.cpu().numpy().reshape(K, K), cm)
+
+
+@pytest.mark.parametrize("cout,B,S,ratio", [(128, 3, 21, 500.0), (64, 2, 30, 300.0), (32, 2, 19, 1000.0), (256, 1, 40, 2000.0)])
+def test_bn_statistics_survive_a_large_mean(lib, cout, B, S, ratio):
+    """TensorFlow's batch_norm is two-pass (isprs:655-663): its variance does not degrade when |mean| >> std.  The conv
+    epilogue's tile statistics (two-pass inside the tile, Chan combination in fp64) must not either: channels with
+    |mean| / std up to `ratio`, every tile shape of the fp32 kernel, ragged last M tile, one- and two-launch forms."""
+    k, rate, cin = 3, 2, 32
+    rng = np.random.default_rng(int(cout + ratio))
+    x = rng.normal(size=(B, S, S, cin)).astype(np.float32)
+    w = (rng.normal(size=(k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)       # conv output std ~ 1
+    bias = (np.linspace(-1.0, 1.0, cout) * ratio).astype(np.float32)                           # channel means up to +-ratio
+    pb, pa = onets.same_pad(k, rate)
+    P = max(pb, pa)
+    M = B * S * S
+    xd, wd, bd = padded(x, P), dev(w), dev(bias)
+    z = torch.zeros(M, cout, dtype=torch.float32, device=DEV)
+    mt = lib.query("drs_conv_mtile", cout)
+    rows = (M + mt - 1) // mt
+    assert M % mt != 0
+    stats = torch.zeros(rows * cout * 2, dtype=torch.float32, device=DEV)
+    lib.call("drs_conv_forward", xd.data_ptr(), B, S, P, cin, 0, wd.data_ptr(), bd.data_ptr(), k, rate, pb, cin, cout, z.data_ptr(),
+             cout, 0, 0, stats.data_ptr(), stream())
+    mr = torch.zeros(cout * 2, dtype=torch.float32, device=DEV)
+    mm = torch.zeros(cout, dtype=torch.float32, device=DEV)
+    mv = torch.ones(cout, dtype=torch.float32, device=DEV)
+    lib.call("drs_conv_stats_finish", stats.data_ptr(), M, mt, cout, float(M), mr.data_ptr(), mm.data_ptr(), mv.data_ptr(), 0.999, 1, None,
+             stream())
+    sv = conv_stats_moments(lib, stats, M, mt, cout)
+    torch.cuda.synchronize()
+    z64 = z.cpu().numpy().astype(np.float64)                  # the moments of the tensor the device actually produced
+    mean, var = z64.mean(axis=0), z64.var(axis=0)
+    assert np.abs(mean).max() / np.sqrt(var.min()) > 0.8 * ratio
+    h = mr.cpu().numpy().reshape(cout, 2).astype(np.float64)
+    got_var = 1.0 / h[:, 1] ** 2 - 1e-3
+    assert np.abs(h[:, 0] - mean).max() < 1e-6 * np.abs(mean).max()
+    assert np.abs(got_var / var - 1.0).max() < 2e-5, np.abs(got_var / var - 1.0).max()       # the plain (sum, sum of squares) form is off by ~1e-2 here
+    two_launch = sv[:, 1] / M - (sv[:, 0] / M) ** 2
+    assert np.abs(two_launch / var - 1.0).max() < 2e-5
+    assert rel_err(mv.cpu().numpy(), T.moving_update(np.ones(cout), var * M / (M - 1.0))) < 1e-5
