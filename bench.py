@@ -183,7 +183,7 @@ def main():
         rows = inst[batch]
         aug = P.draw_augmentation(rows, PATCH, CHANNELS, noise="device")       # every rank draws the whole batch
         mine = P.Augmentation(B_local)
-        mine.rot_on, mine.rot, mine.noise_on, mine.flip, mine.seed = aug.rot_on[sl], aug.rot[sl], aug.noise_on[sl], aug.flip[sl], aug.seed + rank
+        mine.rot_on, mine.rot, mine.noise_on, mine.flip, mine.seed, mine.index0 = aug.rot_on[sl], aug.rot[sl], aug.noise_on[sl], aug.flip[sl], aug.seed, sl.start
         P.crop_to_net(net, pool, rows[sl], PATCH, mean, std, mine)
         out = net.train_step(B_local, PATCH, LR)
         epoch_cm.add_(out["conf"])

@@ -18,6 +18,7 @@ import zlib
 import numpy as np
 
 from . import loops, patches as P, sampling as SP
+from .net import NoComm
 from .nets import resolve
 from .synthetic import make_tile
 
@@ -68,20 +69,24 @@ def init_size_scores(distribution_type, values, occur_init=0):
     return (np.zeros(n, dtype=np.float32), np.full(n, occur_init, dtype=np.int32), np.zeros(n, dtype=np.int32), probs)
 
 
-def cached(path, make):
-    """cwd .npy caches of the reference (isprs:2087-2115)."""
-    if os.path.isfile(path):
-        return np.load(path, allow_pickle=True)
-    v = make()
-    np.save(path, np.asarray(v, dtype=object) if isinstance(v, list) else v)
-    return v
+def _placement(device, comm):
+    """(device, comm) of this process: what the caller passed, else from the launcher's environment -- under
+    `python -m torch.distributed.run --nproc-per-node N <script> ...` one rank per GPU over RCCL (dist.from_env binds the GPU and
+    forms the process group before anything else touches it); a plain launch is the reference's single process on cuda:0."""
+    if device is not None:
+        return device, comm or NoComm()
+    from .dist import from_env
+    device, comm = from_env()
+    return device, comm or NoComm()
 
 
-def main(argv=None, device="cuda:0", comm=None):
+def main(argv=None, device=None, comm=None):
+    device, comm = _placement(device, comm)
     argv = list(sys.argv if argv is None else argv)
     if len(argv) < len(ISPRS_PARAMS) + 1:
         sys.exit("Usage: " + argv[0] + " " + " ".join(ISPRS_PARAMS))
-    print_params(ISPRS_PARAMS, argv)
+    if comm.rank == 0:
+        print_params(ISPRS_PARAMS, argv)
     (input_path, output_path, former_model_path, tr, te, lr, wd, bs, niter, ref_crop, ref_stride, net_type,
      distribution_type, prob_values, update_type, process) = argv[1:17]
     dataset = input_path[:-1].split("/")[-1].lower()
@@ -108,16 +113,22 @@ def main(argv=None, device="cuda:0", comm=None):
     if process == "training":
         train_dist = SP.create_distributions_over_classes(training_labels, reference_crop_size, reference_stride_crop)
         test_dist = SP.create_distributions_over_classes(testing_labels, reference_crop_size, reference_stride_crop)
+    # the reference's cwd .npy caches (isprs:2087-2115); under data parallelism rank 0 reads / builds / writes them and
+    # every rank receives rank 0's arrays (loops.rank0_cached), so no rank reads a half-written file or skips RNG draws
     rot = None
     if train_dist is not None:
-        rot = cached(tag + "_rotation.npy", lambda: SP.create_rotation_distribution(train_dist))
-    if os.path.isfile(tag + "_mean.npy"):
-        mean_full, std_full = np.load(tag + "_mean.npy"), np.load(tag + "_std.npy")
-    else:
-        dist_for_stats = train_dist or SP.create_distributions_over_classes(training_labels, reference_crop_size, reference_stride_crop)
-        mean_full, std_full = SP.dynamically_calculate_mean_and_std(training_data, dist_for_stats, crop_size=25)   # isprs:2109-2110
-        np.save(tag + "_mean.npy", mean_full)
-        np.save(tag + "_std.npy", std_full)
+        rot = loops.rank0_cached(comm, tag + "_rotation.npy", lambda: SP.create_rotation_distribution(train_dist))
+
+    ms = None
+    if comm.rank == 0:
+        if os.path.isfile(tag + "_mean.npy"):
+            ms = (np.load(tag + "_mean.npy"), np.load(tag + "_std.npy"))
+        else:
+            dist_for_stats = train_dist or SP.create_distributions_over_classes(training_labels, reference_crop_size, reference_stride_crop)
+            ms = SP.dynamically_calculate_mean_and_std(training_data, dist_for_stats, crop_size=25)   # isprs:2109-2110
+            np.save(tag + "_mean.npy", ms[0])
+            np.save(tag + "_std.npy", ms[1])
+    mean_full, std_full = comm.broadcast_object(ms)
 
     if process == "training":
         return loops.train(training_data, training_labels, train_dist, rot, testing_data, testing_labels, test_dist,
@@ -163,13 +174,15 @@ def _load_stack(path, num_classes, seed0):
     return list(imgs), [np.squeeze(m).astype(np.uint8) for m in masks]
 
 
-def main_coffee(argv=None, device="cuda:0", comm=None):
+def main_coffee(argv=None, device=None, comm=None):
     """coffee_dilated_random.py:1105-1150: 2 classes, 3 bands, errorAcc_/errorOccur_/chosenValues_ side files."""
     from . import loops_indexed as LI
+    device, comm = _placement(device, comm)
     argv = list(sys.argv if argv is None else argv)
     if len(argv) < len(COFFEE_PARAMS) + 1:
         sys.exit("Usage: " + argv[0] + " " + " ".join(COFFEE_PARAMS))
-    print_params(COFFEE_PARAMS, argv)
+    if comm.rank == 0:
+        print_params(COFFEE_PARAMS, argv)
     path_train, path_test, output_path, current_model, lr, wd, bs, niter, ref_crop, ref_stride, net_type, dist, pv, update_type = argv[1:15]
     values = [int(i) for i in pv.split(",")]
     resolve(net_type)
@@ -183,13 +196,15 @@ def main_coffee(argv=None, device="cuda:0", comm=None):
                     side_names=("errorAcc_step_", "errorOccur_step_", "chosenValues_step_"), device=device, comm=comm)
 
 
-def main_contest(argv=None, device="cuda:0", comm=None):
+def main_contest(argv=None, device=None, comm=None):
     """contest_dilated_random.py:1228-1313: 7 classes + void label 7, 3 bands, operation train | test."""
     from . import datasets, loops_indexed as LI
+    device, comm = _placement(device, comm)
     argv = list(sys.argv if argv is None else argv)
     if len(argv) < len(CONTEST_PARAMS) + 1:
         sys.exit("Usage: " + argv[0] + " " + " ".join(CONTEST_PARAMS))
-    print_params(CONTEST_PARAMS, argv)
+    if comm.rank == 0:
+        print_params(CONTEST_PARAMS, argv)
     path, output_path, current_model, lr, wd, bs, niter, crop, stride, net_type, dist, pv, update_type, operation = argv[1:15]
     values = [int(i) for i in pv.split(",")]
     resolve(net_type)

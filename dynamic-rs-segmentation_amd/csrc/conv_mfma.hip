@@ -65,15 +65,22 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 128) ? 3 : 1) void conv_ig
   const int n0 = (tile % ntn) * BN;
 
   const int Sp = a.S + 2 * a.P;
-  // per-thread A source offsets (element units, < 2^32): pixel part + slice + this thread's 4-channel column
+  // Addressing without per-K-step vector arithmetic: every load is (wave-uniform base in SGPRs) + (loop-invariant 32-bit byte
+  // offset of this thread), i.e. `global_load_dwordx4 v, voff, s[base]`.  The K loop then issues nothing on the vector ALU
+  // besides the MFMAs: VALU instructions of any wave on a SIMD take issue slots from that SIMD's matrix pipe (measured on the
+  // filter-gradient kernel: its ~200 address / select instructions per chunk cost 10-15 % of the MFMA rate).
+  // per-thread A source byte offsets: pixel part + slice + this thread's 4-channel column (slab bytes < 2^32, checked by the host)
   uint32_t offA[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     int p = m0 + (t >> 3) + 32 * i;
     p = p < a.M ? p : a.M - 1;
-    offA[i] = padded_pixel_off(p, a.S, a.P, a.ld_in, a.rcpS, a.rcpSS, -a.pad, -a.pad) + (uint32_t)(a.coff_in + (PACK ? 0 : (t & 7) * 4));
+    offA[i] = (padded_pixel_off(p, a.S, a.P, a.ld_in, a.rcpS, a.rcpSS, -a.pad, -a.pad) + (uint32_t)(a.coff_in + (PACK ? 0 : (t & 7) * 4))) * 4u;
   }
   const int brow = t / (BN / 4), bcol = (t % (BN / 4)) * 4;
+  uint32_t offB[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) offB[i] = (uint32_t)((brow + BROWS * i) * a.Cout + n0 + bcol) * 4u;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -88,28 +95,32 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 128) ? 3 : 1) void conv_ig
   int u_lo, u_hi;
   live_tap_rows(m0, BM, a.M, a.S, a.k, a.rate, a.pad, a.rcpS, a.rcpSS, u_lo, u_hi);
   if (PACK || !a.skip_halo) { u_lo = 0; u_hi = a.k; }
+  u_lo = __builtin_amdgcn_readfirstlane(u_lo);
+  u_hi = __builtin_amdgcn_readfirstlane(u_hi);
   const int nks = PACK ? (a.k * a.k * a.Cin + BK - 1) / BK : (u_hi - u_lo) * a.k * cpt;   // K-steps (of the live tap rows), from 0
-  const float* wlive = a.w + (size_t)u_lo * a.k * a.Cin * a.Cout;      // filter rows of the first live tap row
+  const char* wlive = reinterpret_cast<const char*>(a.w + (size_t)u_lo * a.k * a.Cin * a.Cout);      // filter rows of the first live tap row
+  const char* inb = reinterpret_cast<const char*>(a.in);
   f32x4 ra[NA], rb[NB];
-  int lu = u_lo, lv = 0, lc = 0;              // (tap row, tap col, channel chunk) of the next K-step to fetch
+  int lu = u_lo, lv = 0, lc = 0;              // (tap row, tap col, channel chunk) of the next K-step to fetch: wave-uniform, in SGPRs
 
   auto gload = [&](int ks) {
-    uint32_t soff;
     if (PACK) {     // this thread's 4 channels belong to tap (32 ks + 4 (t & 7)) / Cin; taps past the last meet zero filter rows
       const int kidx = ks * BK + (t & 7) * 4;
       int tap = kidx / a.Cin;
       const int c = kidx - tap * a.Cin;
       tap = tap < a.k * a.k ? tap : a.k * a.k - 1;
       const int u = tap / a.k, v = tap - u * a.k;
-      soff = (uint32_t)((u * a.rate * Sp + v * a.rate) * a.ld_in + c);
+      const uint32_t soff = (uint32_t)((u * a.rate * Sp + v * a.rate) * a.ld_in + c) * 4u;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(inb + (offA[i] + soff));
     } else {
-      soff = (uint32_t)((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK);
+      const char* ab = inb + (size_t)(uint32_t)((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK) * 4u;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) { uint32_t o = offA[i]; asm volatile("" : "+v"(o)); ra[i] = *reinterpret_cast<const f32x4*>(ab + o); }   // (opaque: keeps the 32-bit offset form, global_load v, voff, s[base])
     }
+    const char* wb = wlive + (size_t)(uint32_t)(ks * BK) * (uint32_t)a.Cout * 4u;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a.in + offA[i] + soff);
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-      rb[i] = *reinterpret_cast<const f32x4*>(wlive + (size_t)(ks * BK + brow + BROWS * i) * a.Cout + n0 + bcol);
+    for (int i = 0; i < NB; ++i) { uint32_t o = offB[i]; asm volatile("" : "+v"(o)); rb[i] = *reinterpret_cast<const f32x4*>(wb + o); }
     if (!PACK) { if (++lc == cpt) { lc = 0; if (++lv == a.k) { lv = 0; ++lu; } } }
   };
   auto lstore = [&]() {
@@ -126,26 +137,26 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 128) ? 3 : 1) void conv_ig
   for (int ks = 0; ks < nks; ++ks) {
     if (ks + 1 < nks) gload(ks + 1);
     // K is consumed in the order the wide LDS reads deliver it: lane-half h of read q supplies k = 8q+4h+e at step e.
-    // The fragments of step st+1 are read from LDS BEFORE the MFMAs of step st are issued (register double buffer,
-    // order pinned with sched_group_barrier), so an LDS round trip never sits between two MFMA groups.
+    // The fragments of step st+1 are read from LDS BEFORE the MFMAs of step st are issued (two register sets used in turn, so no
+    // copies; order pinned with sched_group_barrier), so an LDS round trip never sits between two MFMA groups.
     {
       constexpr int NST = BK / 2;             // MFMA k-steps per K-step
-      f32x4 acur[TM], anext[TM];
-      float bcur[TN], bnext[TN];
+      f32x4 af[2][TM];
+      float bf[2][TN];
 #pragma unroll
-      for (int mi = 0; mi < TM; ++mi) acur[mi] = *reinterpret_cast<const f32x4*>(&As[(arow + mi * 32) * LDA + h * 4]);
+      for (int mi = 0; mi < TM; ++mi) af[0][mi] = *reinterpret_cast<const f32x4*>(&As[(arow + mi * 32) * LDA + h * 4]);
 #pragma unroll
-      for (int ni = 0; ni < TN; ++ni) bcur[ni] = Bs[(h * 4) * LDB + bcolw + ni * 32];
+      for (int ni = 0; ni < TN; ++ni) bf[0][ni] = Bs[(h * 4) * LDB + bcolw + ni * 32];
 #pragma unroll
       for (int st = 0; st < NST; ++st) {
         const int e = st & 3;
         if (st + 1 < NST) {
           const int q1 = (st + 1) >> 2, e1 = (st + 1) & 3;
 #pragma unroll
-          for (int ni = 0; ni < TN; ++ni) bnext[ni] = Bs[(q1 * 8 + h * 4 + e1) * LDB + bcolw + ni * 32];
+          for (int ni = 0; ni < TN; ++ni) bf[(st + 1) & 1][ni] = Bs[(q1 * 8 + h * 4 + e1) * LDB + bcolw + ni * 32];
           if (e1 == 0) {
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi) anext[mi] = *reinterpret_cast<const f32x4*>(&As[(arow + mi * 32) * LDA + q1 * 8 + h * 4]);
+            for (int mi = 0; mi < TM; ++mi) af[q1 & 1][mi] = *reinterpret_cast<const f32x4*>(&As[(arow + mi * 32) * LDA + q1 * 8 + h * 4]);
             __builtin_amdgcn_sched_group_barrier(0x100, TN + TM, 0);                  // DS reads of the next step first
           } else {
             __builtin_amdgcn_sched_group_barrier(0x100, TN, 0);
@@ -155,16 +166,8 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 128) ? 3 : 1) void conv_ig
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
           for (int ni = 0; ni < TN; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[mi][e], bcur[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(st >> 2) & 1][mi][e], bf[st & 1][ni], acc[mi][ni], 0, 0, 0);
         __builtin_amdgcn_sched_group_barrier(0x8, TM * TN, 0);                        // then this step's MFMAs
-        if (st + 1 < NST) {
-#pragma unroll
-          for (int ni = 0; ni < TN; ++ni) bcur[ni] = bnext[ni];
-          if (((st + 1) & 3) == 0) {
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi) acur[mi] = anext[mi];
-          }
-        }
       }
     }
     __syncthreads();
@@ -222,6 +225,52 @@ struct WgradArgs {
   float rcpS, rcpSS;
 };
 
+// Walk over the 32-pixel chunks of a pixel range that meet the live rows [lo, hi) of some image (drs_common.hpp), kept entirely in
+// wave-uniform integers: no division after init(), so the walk costs scalar-ALU instructions only.  c = chunk index; (b, r) =
+// image and in-image position of the chunk's first pixel; (y, x0) = its row / column, maintained when S % 32 == 0 (a chunk then
+// lies inside one image row and the chunk holding pixel `lo` starts exactly at it).
+struct ChunkWalk {
+  int c, b, r, y, x0;
+  int S, S2, lo, hi, ylo;
+  __device__ __forceinline__ void init(int cfirst, int S_, float rcpS, float rcpSS, int lo_, int hi_) {
+    S = S_; S2 = S_ * S_; lo = lo_; hi = hi_;
+    int q;
+    divmod24(lo, S, rcpS, ylo, q);
+    c = next_live_chunk(cfirst - 1, S2, rcpSS, lo, hi);
+    divmod24(c * 32, S2, rcpSS, b, r);
+    divmod24(r, S, rcpS, y, x0);
+    c = __builtin_amdgcn_readfirstlane(c); b = __builtin_amdgcn_readfirstlane(b); r = __builtin_amdgcn_readfirstlane(r);
+    y = __builtin_amdgcn_readfirstlane(y); x0 = __builtin_amdgcn_readfirstlane(x0); ylo = __builtin_amdgcn_readfirstlane(ylo);
+  }
+  // to the next chunk that meets a live row; returns the number of chunks advanced
+  __device__ __forceinline__ int advance() {
+    int r1 = r + 32, b1 = b;
+    if (r1 >= S2) { r1 -= S2; ++b1; }
+    if ((r1 + 31 >= lo && r1 < hi) || r1 + 31 >= S2 + lo) {
+      ++c; r = r1; b = b1;
+      x0 += 32;
+      if (x0 >= S) { x0 -= S; ++y; }
+      if (y >= S) y = 0;
+      return 1;
+    }
+    const int tb = r1 < lo ? b1 : b1 + 1;          // image whose live rows come next
+    const int T = tb * S2 + lo, c_old = c;
+    const int f = T & 31;                          // the chunk holding pixel T starts f pixels before it
+    c = T >> 5;
+    if (f <= lo) { b = tb; r = lo - f; } else { b = tb - 1; r = S2 + lo - f; }
+    y = ylo; x0 = 0;                               // (exact when S % 32 == 0: f == 0)
+    return c - c_old;
+  }
+};
+
+// The filter-gradient tile with a K loop that issues no vector-ALU instruction besides its MFMAs: VALU instructions of ANY
+// wave on a SIMD take issue slots from that SIMD's matrix pipe (measured on wgrad_kernel: removing its ~200 address / select
+// instructions per chunk raises the MFMA rate by 10-15 %).  Every global load is (wave-uniform base in SGPRs) + (32-bit byte
+// offset of this thread): loop-invariant when S % 32 == 0, one table read + add otherwise; the chunk walk is scalar
+// (ChunkWalk); rows beyond k*k*Cin are loaded as they are (they only feed accumulator rows that are never stored); pixels
+// beyond the tensor exist only in the last chunk, which alone pays for the select.  Chunk order, tile geometry, slab layout
+// and the order of every sum are those of the first form of this kernel: results are bitwise the same
+// (profiles/r02/wgrad_ablation.txt has the A/B and the ablations).
 template <int TR, int TO>
 __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) void wgrad_kernel(const WgradArgs a) {
   constexpr int WR = TR >= 64 ? 2 : 1, WC = TO >= 64 ? 2 : 1;
@@ -235,7 +284,7 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   constexpr int XPS = NT / XQ, GPS = NT / GQ; // pixel stride between a thread's successive loads
 
   __shared__ __attribute__((aligned(16))) float lds[BP * LDX + BP * LDG];
-  __shared__ uint32_t tabx[2][BP], tabg[2][BP];   // padded element offsets of the chunk's pixels (per-chunk, double-buffered)
+  __shared__ uint32_t tabx[2][BP], tabg[2][BP];   // BYTE offsets of the chunk's pixels (walk with S % 32 != 0), double-buffered
   float* Xs = lds;
   float* Gs = lds + BP * LDX;
 
@@ -246,20 +295,26 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
 
   const int ntile = a.ntr * a.nto;
   const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int split = id / ntile;
-  const int tile = id % ntile;
+  const int split = __builtin_amdgcn_readfirstlane(id / ntile);
+  const int tile = __builtin_amdgcn_readfirstlane(id % ntile);
   const int R0 = (tile / a.nto) * TR;         // first row of the [k*k*Cin] dimension; a tile may span several taps
-  const int o0 = (tile % a.nto) * TO;         // and the last one may be ragged (rows beyond k*k*Cin are zero / not stored)
+  const int o0 = (tile % a.nto) * TO;         // and the last one may be ragged (rows beyond k*k*Cin are not stored)
   const int rows_all = a.k * a.k * a.Cin;
   // this thread always stages the same 4 rows (tap, c..c+3) of the tile: its tap shift is a per-thread constant
   const int myR = R0 + (t % XQ) * 4;
-  const bool row_ok = myR < rows_all;
-  const int tap = (row_ok ? myR : 0) / a.Cin, c0 = (row_ok ? myR : 0) % a.Cin;
+  const int myRc = myR < rows_all ? myR : 0;                 // rows past the end: any valid address will do
+  const int tap = myRc / a.Cin, c0 = myRc % a.Cin;
   const int u = tap / a.k, v = tap % a.k;
-  const int Sxp = a.S + 2 * a.Px;
-  const uint32_t xconst = (uint32_t)((u * a.rate * Sxp + v * a.rate) * a.ld_x + a.coff_x + c0);
-  const uint32_t gconst = (uint32_t)(a.coff_g + o0 + (t % GQ) * 4);
+  const int Sxp = a.S + 2 * a.Px, Sgp = a.S + 2 * a.Pg;
+  const uint32_t xconst = (uint32_t)((u * a.rate * Sxp + v * a.rate) * a.ld_x + a.coff_x + c0) * 4u;
+  const uint32_t gconst = (uint32_t)(a.coff_g + o0 + (t % GQ) * 4) * 4u;
   const int xpix = t / XQ, gpix = t / GQ;
+  const bool affine = (a.S & 31) == 0;
+  uint32_t xoff[NX], goff[NG];                // S % 32 == 0: the whole per-thread part of the address
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xoff[i] = xconst + (affine ? (uint32_t)((xpix + XPS * i) * a.ld_x) * 4u : 0u);
+#pragma unroll
+  for (int i = 0; i < NG; ++i) goff[i] = gconst + (affine ? (uint32_t)((gpix + GPS * i) * a.ld_g) * 4u : 0u);
 
   f32x16 acc[TMr][TNo];
 #pragma unroll
@@ -273,121 +328,121 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   const int cbeg = split * a.chunks_per_split;
   int cend = cbeg + a.chunks_per_split;
   cend = cend < nchunks_total ? cend : nchunks_total;
-  // pixel rows that meet only halo zeros for this tile's tap rows are neither fetched nor multiplied: the chunk sequence jumps
-  // over them (drs_common.hpp); chunks are taken in increasing order, so a step's sums are in the same order as without the jump
+  const int clast = (a.M & 31) ? nchunks_total - 1 : -1;     // the one chunk that holds pixels past the end, if any
   int live_lo, live_hi;
   {
     const int rlast = (R0 + TR < rows_all ? R0 + TR : rows_all) - 1;
     live_pixel_range(R0, rlast, a.Cin, a.k, a.rate, a.pad, a.S, a.skip_halo, live_lo, live_hi);
   }
-  const int S2 = a.S * a.S;
-  auto next_chunk = [&](int c) { return next_live_chunk(c, S2, a.rcpSS, live_lo, live_hi); };
+  ChunkWalk w;
+  w.init(cbeg, a.S, a.rcpS, a.rcpSS, live_lo, live_hi);
 
-  // the pixel -> padded-offset arithmetic (two divisions per pixel) is done once per chunk by BP threads, not by
-  // every thread for every load: the first BP threads fill the tables for chunk `chunk` into slot `slot`
-  // when the patch side is a multiple of 32 a chunk is 32 consecutive pixels of one image row: its offsets are an affine function
-  // of the first pixel's and need no table (chunk_of[slot] = the chunk staged in that table slot)
-  const bool affine = (a.S & 31) == 0;
-  int chunk_of[2] = {0, 0};
-  auto fill_tables = [&](int chunk, int slot) {
-    chunk_of[slot] = chunk;
-    if (!affine && t < BP && chunk < cend) {
-      const int p = chunk * BP + t;
-      const int pc = p < a.M ? p : a.M - 1;                    // clamped X rows meet a zero G row
-      tabx[slot][t] = padded_pixel_off(pc, a.S, a.Px, a.ld_x, a.rcpS, a.rcpSS, -a.pad, -a.pad);
-      // bit 31 flags a pixel past the end (its G row must read as zero); the offset itself stays a valid address
-      tabg[slot][t] = padded_pixel_off(pc, a.S, a.Pg, a.ld_g, a.rcpS, a.rcpSS, 0, 0) | (p < a.M ? 0u : 0x80000000u);
+  // S % 32 != 0: a chunk crosses image rows, so its 32 pixels get a table of byte offsets, written by the first 32 threads.
+  // A thread follows ITS pixel (pb, py, px) through the walk: +32 pixels is a couple of compares; only a jump over dead rows
+  // (once per image and tile) or a pixel past the end pays for the divisions.
+  int pb = 0, py = 0, px = 0;
+  auto pixel_from_index = [&](int p) {
+    int rem;
+    divmod24(p < a.M ? p : a.M - 1, w.S2, a.rcpSS, pb, rem);
+    divmod24(rem, a.S, a.rcpS, py, px);
+  };
+  if (!affine && t < BP) pixel_from_index(w.c * BP + t);
+  auto fill_tables = [&](int slot, int stepped) {      // for chunk w.c; `stepped` = chunks the walk advanced since this thread's pixel was set
+    if (affine || t >= BP || w.c >= cend) return;
+    const int p = w.c * BP + t;
+    if (stepped == 1 && p < a.M && a.S >= 11) {
+      px += 32;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) if (px >= a.S) { px -= a.S; ++py; }
+      if (py >= a.S) { py -= a.S; ++pb; }
+    } else if (stepped != 0) {
+      pixel_from_index(p);
     }
+    tabx[slot][t] = (uint32_t)(((pb * Sxp + py + a.Px - a.pad) * Sxp + px + a.Px - a.pad) * a.ld_x) * 4u;
+    tabg[slot][t] = (uint32_t)(((pb * Sgp + py + a.Pg) * Sgp + px + a.Pg) * a.ld_g) * 4u;
   };
 
+  const char* xbase = reinterpret_cast<const char*>(a.x);
+  const char* gbase = reinterpret_cast<const char*>(a.g);
   f32x4 rx[NX], rg[NG];
-  uint32_t gflag[NG];
-  // branch-free: every offset in the tables is a valid address (rows past the end are clamped); what must be zero
-  // (G rows of pixels >= M, X rows of a ragged tile) is zeroed by a select when the registers are written to LDS, not
-  // here: a select right behind the loads would put the wait for them in front of the MFMAs of the current chunk, i.e.
-  // in front of what the prefetch is there to overlap.  All table reads are issued before the first global load.
+  // global -> registers for the chunk the walk stands on (tables in `slot` when S % 32 != 0)
   auto gload = [&](int slot) {
-    const uint32_t* tx = tabx[slot];
-    const uint32_t* tg = tabg[slot];
-    uint32_t ox[NX], og[NG];
     if (affine) {
-      const int p0 = chunk_of[slot] * BP;
-      const uint32_t bx = padded_pixel_off(p0, a.S, a.Px, a.ld_x, a.rcpS, a.rcpSS, -a.pad, -a.pad);
-      const uint32_t bg = padded_pixel_off(p0, a.S, a.Pg, a.ld_g, a.rcpS, a.rcpSS, 0, 0);
+      const char* xb = xbase + (size_t)(uint32_t)(((w.b * Sxp + w.y + a.Px - a.pad) * Sxp + w.x0 + a.Px - a.pad) * a.ld_x) * 4u;
+      const char* gb = gbase + (size_t)(uint32_t)(((w.b * Sgp + w.y + a.Pg) * Sgp + w.x0 + a.Pg) * a.ld_g) * 4u;
 #pragma unroll
-      for (int i = 0; i < NX; ++i) ox[i] = bx + (uint32_t)((xpix + XPS * i) * a.ld_x);
+      for (int i = 0; i < NX; ++i) { uint32_t o = xoff[i]; asm volatile("" : "+v"(o)); rx[i] = *reinterpret_cast<const f32x4*>(xb + o); }
 #pragma unroll
-      for (int i = 0; i < NG; ++i) og[i] = bg + (uint32_t)((gpix + GPS * i) * a.ld_g);
+      for (int i = 0; i < NG; ++i) { uint32_t o = goff[i]; asm volatile("" : "+v"(o)); rg[i] = *reinterpret_cast<const f32x4*>(gb + o); }
+    } else {
+      uint32_t ox[NX], og[NG];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) ox[i] = tabx[slot][xpix + XPS * i] + xoff[i];
+#pragma unroll
+      for (int i = 0; i < NG; ++i) og[i] = tabg[slot][gpix + GPS * i] + goff[i];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) rx[i] = *reinterpret_cast<const f32x4*>(xbase + ox[i]);
+#pragma unroll
+      for (int i = 0; i < NG; ++i) rg[i] = *reinterpret_cast<const f32x4*>(gbase + og[i]);
+    }
+  };
+  auto lstore = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) *reinterpret_cast<f32x4*>(&Xs[(xpix + XPS * i) * LDX + (t % XQ) * 4]) = rx[i];
+    if (chunk == clast) {                       // pixels past the end were loaded from a clamped address: their G rows are zero
+#pragma unroll
+      for (int i = 0; i < NG; ++i)
+        *reinterpret_cast<f32x4*>(&Gs[(gpix + GPS * i) * LDG + (t % GQ) * 4]) =
+            chunk * BP + gpix + GPS * i < a.M ? rg[i] : f32x4{0.f, 0.f, 0.f, 0.f};
     } else {
 #pragma unroll
-      for (int i = 0; i < NX; ++i) ox[i] = tx[xpix + XPS * i];
-#pragma unroll
-      for (int i = 0; i < NG; ++i) og[i] = tg[gpix + GPS * i];
+      for (int i = 0; i < NG; ++i) *reinterpret_cast<f32x4*>(&Gs[(gpix + GPS * i) * LDG + (t % GQ) * 4]) = rg[i];
     }
-#pragma unroll
-    for (int i = 0; i < NX; ++i) rx[i] = *reinterpret_cast<const f32x4*>(a.x + ox[i] + xconst);
-#pragma unroll
-    for (int i = 0; i < NG; ++i) rg[i] = *reinterpret_cast<const f32x4*>(a.g + (og[i] & 0x7fffffffu) + gconst);
-#pragma unroll
-    for (int i = 0; i < NG; ++i) gflag[i] = og[i] & 0x80000000u;
-  };
-  auto lstore = [&]() {
-#pragma unroll
-    for (int i = 0; i < NX; ++i)
-      *reinterpret_cast<f32x4*>(&Xs[(xpix + XPS * i) * LDX + (t % XQ) * 4]) = row_ok ? rx[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < NG; ++i)
-      *reinterpret_cast<f32x4*>(&Gs[(gpix + GPS * i) * LDG + (t % GQ) * 4]) = gflag[i] ? f32x4{0.f, 0.f, 0.f, 0.f} : rg[i];
   };
 
-  int ck0 = next_chunk(cbeg - 1);
-  if (ck0 < cend) {
-    int ck1 = next_chunk(ck0);
-    fill_tables(ck0, 0);
-    fill_tables(ck1, 1);
+  int cA = w.c;                                  // chunk in LDS / being multiplied
+  if (cA < cend) {
+    fill_tables(0, 0);
     __syncthreads();
     gload(0);
-    lstore();
+    int stepped = w.advance();                   // the walk now stands on B, the chunk to prefetch next
+    int cB = w.c;
+    fill_tables(1, stepped);
+    lstore(cA);
     __syncthreads();
     const int xr = wr * WTR + li, gc = wc * WTO + li;
-    for (int it = 0; ck0 < cend; ++it) {
-      const int ck2 = next_chunk(ck1);
-      if (ck1 < cend) gload((it + 1) & 1);        // table slot filled one iteration ago
-      fill_tables(ck2, it & 1);                   // overwrites the slot last read (for chunk ck0) one iteration ago
+    for (int it = 0; cA < cend; ++it) {
+      if (cB < cend) gload((it + 1) & 1);         // table slot filled one iteration ago
+      stepped = w.advance();                      // ... and on C, whose table goes into the slot last read one iteration ago
+      fill_tables(it & 1, stepped);
       {
-        // fragments of pixel pair s+1 are read before the MFMAs of pair s are issued (see conv_igemm_kernel)
-        float acur[TMr], bcur[TNo], anext[TMr], bnext[TNo];
+        // fragments of pixel pair s+1 are read before the MFMAs of pair s are issued (two register sets used in turn)
+        float af[2][TMr], bf[2][TNo];
 #pragma unroll
-        for (int mi = 0; mi < TMr; ++mi) acur[mi] = Xs[h * LDX + xr + mi * 32];
+        for (int mi = 0; mi < TMr; ++mi) af[0][mi] = Xs[h * LDX + xr + mi * 32];
 #pragma unroll
-        for (int ni = 0; ni < TNo; ++ni) bcur[ni] = Gs[h * LDG + gc + ni * 32];
+        for (int ni = 0; ni < TNo; ++ni) bf[0][ni] = Gs[h * LDG + gc + ni * 32];
 #pragma unroll
         for (int s = 0; s < BP / 2; ++s) {
           if (s + 1 < BP / 2) {
 #pragma unroll
-            for (int mi = 0; mi < TMr; ++mi) anext[mi] = Xs[(2 * s + 2 + h) * LDX + xr + mi * 32];
+            for (int mi = 0; mi < TMr; ++mi) af[(s + 1) & 1][mi] = Xs[(2 * s + 2 + h) * LDX + xr + mi * 32];
 #pragma unroll
-            for (int ni = 0; ni < TNo; ++ni) bnext[ni] = Gs[(2 * s + 2 + h) * LDG + gc + ni * 32];
+            for (int ni = 0; ni < TNo; ++ni) bf[(s + 1) & 1][ni] = Gs[(2 * s + 2 + h) * LDG + gc + ni * 32];
             __builtin_amdgcn_sched_group_barrier(0x100, TMr + TNo, 0);
           }
 #pragma unroll
           for (int mi = 0; mi < TMr; ++mi)
 #pragma unroll
             for (int ni = 0; ni < TNo; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[mi], bcur[ni], acc[mi][ni], 0, 0, 0);
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][mi], bf[s & 1][ni], acc[mi][ni], 0, 0, 0);
           __builtin_amdgcn_sched_group_barrier(0x8, TMr * TNo, 0);
-          if (s + 1 < BP / 2) {
-#pragma unroll
-            for (int mi = 0; mi < TMr; ++mi) acur[mi] = anext[mi];
-#pragma unroll
-            for (int ni = 0; ni < TNo; ++ni) bcur[ni] = bnext[ni];
-          }
         }
       }
       __syncthreads();
-      if (ck1 < cend) { lstore(); __syncthreads(); }
-      ck0 = ck1;
-      ck1 = ck2;
+      if (cB < cend) { lstore(cB); __syncthreads(); }
+      cA = cB;
+      cB = w.c;
     }
   }
   const size_t rows_total = (size_t)a.k * a.k * a.Cin;
@@ -509,7 +564,7 @@ int drs_conv_forward(const float* in, int B, int S, int P, int ld_in, int coff_i
   if (P < (k - 1) * rate - pad_before) return DRS_ERR_ARG;          // halo must cover pad_after too
   const long long M = (long long)B * S * S;
   if (M <= 0 || M >= (1 << 24)) return DRS_ERR_ARG;
-  if ((long long)B * (S + 2 * P) * (S + 2 * P) * ld_in >= (1LL << 32)) return DRS_ERR_ARG;      // 32-bit element offsets
+  if ((long long)B * (S + 2 * P) * (S + 2 * P) * ld_in >= (1LL << 30)) return DRS_ERR_ARG;      // 32-bit BYTE offsets (slab < 4 GiB)
   ConvArgs a;
   a.in = in; a.S = S; a.P = P; a.ld_in = ld_in; a.coff_in = coff_in; a.M = (int)M;
   a.w = w; a.bias = bias; a.out = out; a.ld_out = ld_out; a.coff_out = coff_out; a.stats = stats_partial;
@@ -550,8 +605,8 @@ int drs_conv_wgrad(const float* x, int B, int S, int Px, int ld_x, int coff_x, c
   if (!x || !g || !slab || !grad || (cin % 32 && cin != 8 && cin != 16) || cout % 32 || cin_real > cin) return DRS_ERR_ARG;
   const long long M = (long long)B * S * S;
   if (M <= 0 || M >= (1 << 24)) return DRS_ERR_ARG;
-  if ((long long)B * (S + 2 * Px) * (S + 2 * Px) * ld_x >= (1LL << 32)) return DRS_ERR_ARG;     // 32-bit element offsets
-  if ((long long)B * (S + 2 * Pg) * (S + 2 * Pg) * ld_g >= (1LL << 31)) return DRS_ERR_ARG;     // bit 31 flags a row past the end
+  if ((long long)B * (S + 2 * Px) * (S + 2 * Px) * ld_x >= (1LL << 30)) return DRS_ERR_ARG;     // 32-bit BYTE offsets (slabs < 4 GiB)
+  if ((long long)B * (S + 2 * Pg) * (S + 2 * Pg) * ld_g >= (1LL << 30)) return DRS_ERR_ARG;
   WgradArgs a;
   a.x = x; a.S = S; a.Px = Px; a.ld_x = ld_x; a.coff_x = coff_x;
   a.g = g; a.Pg = Pg; a.ld_g = ld_g; a.coff_g = coff_g; a.M = (int)M;

@@ -26,6 +26,7 @@ struct CropArgs {
   const double* noise;          // [B][S][S][C] additive noise (pre-flip coordinates) or null
   const unsigned char* noise_on;  // [B] or null
   unsigned long long seed;      // device noise (Philox) when noise == null and noise_on[b]
+  int b0;                       // index of this call's first patch in the global batch: the noise of a patch does not depend on how the batch is sharded
   int void_label;               // pixels carrying this label are masked out too (contest:235-239); -1 = none
   double mean[3], stdv[3];
   float* out; int S, P, ld;     // conv1 input slab [B][S+2P][S+2P][ld]
@@ -90,10 +91,11 @@ __global__ void crop_kernel(const CropArgs a) {
       double e = valid ? (double)src[c] : 0.0;      // fp64 until the single rounding on the store
       if (noisy) {
         const size_t ne = (((size_t)b * a.S + fi) * a.S + fj) * a.C + c;   // noise is indexed before the flip
+        const size_t ng = ne + (size_t)a.b0 * a.S * a.S * a.C;             // ... and by the patch's place in the GLOBAL batch on the device path
         if (a.noise) e = __dadd_rn(e, a.noise[ne]);
         else {
           unsigned r[4];
-          philox(a.seed, (unsigned long long)ne, r);
+          philox(a.seed, (unsigned long long)ng, r);
           e = __dadd_rn(e, 0.01 * normal_from(r[0], r[1]));
         }
       }
@@ -196,7 +198,7 @@ extern "C" {
 int drs_crop_normalize(const void* tiles, int tiles_are_f64, const unsigned char* labels, const long long* tile_off,
                        const long long* lab_off, const int* tile_h, const int* tile_w, int C, const int* inst,
                        const double* rot, const unsigned char* rot_on, const double* noise, const unsigned char* noise_on,
-                       unsigned long long seed, const double* mean3, const double* std3, int B, int S, int P, int ld,
+                       unsigned long long seed, int noise_index0, const double* mean3, const double* std3, int B, int S, int P, int ld,
                        float* out, unsigned char* out_lab, unsigned char* out_mask, int void_label, void* stream) {
   if (!tiles || !labels || !tile_off || !lab_off || !tile_h || !tile_w || !inst || !out || !mean3 || !std3) return DRS_ERR_ARG;
   if (C < 1 || C > 8 || ld < C || ld % 4) return DRS_ERR_ARG;
@@ -204,7 +206,7 @@ int drs_crop_normalize(const void* tiles, int tiles_are_f64, const unsigned char
   if ((long long)B * Sp > 65535) return DRS_ERR_ARG;
   CropArgs a;
   a.tiles = tiles; a.labels = labels; a.tile_off = tile_off; a.lab_off = lab_off; a.tile_h = tile_h; a.tile_w = tile_w; a.C = C;
-  a.inst = inst; a.rot = rot; a.rot_on = rot ? rot_on : nullptr; a.noise = noise; a.noise_on = noise_on; a.seed = seed; a.void_label = void_label;
+  a.inst = inst; a.rot = rot; a.rot_on = rot ? rot_on : nullptr; a.noise = noise; a.noise_on = noise_on; a.seed = seed; a.b0 = noise_index0; a.void_label = void_label;
   for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.stdv[c] = std3[c]; }
   a.out = out; a.S = S; a.P = P; a.ld = ld; a.out_lab = out_lab; a.out_mask = out_mask;
   dim3 grid((Sp + 63) / 64, B * Sp);

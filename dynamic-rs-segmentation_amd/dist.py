@@ -53,6 +53,32 @@ class TorchComm(object):
         if self.world > 1:
             dist.barrier()
 
+    @property
+    def sync_rng(self):
+        """the step loops re-seed `random` / `numpy.random` from rank 0 at their synchronisation points (loops.sync_rng)"""
+        return self.world > 1
+
+    def broadcast_object(self, obj, src=0):
+        """rank `src`'s picklable object on every rank (index tables, cached .npy contents, RNG seeds)"""
+        if self.world == 1:
+            return obj
+        box = [obj if self.rank == src else None]
+        dist.broadcast_object_list(box, src=src)
+        return box[0]
+
+    def agree(self, values, what="value"):
+        """raise on every rank unless all ranks hold the same integers (a cheap guard of the lock-step host logic)"""
+        if self.world == 1:
+            return
+        t = torch.tensor([int(v) for v in values], dtype=torch.int64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        lo, hi = t.clone(), t.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("ranks disagree on %s: min %s max %s (rank %d has %s)" % (what, lo.tolist(), hi.tolist(), self.rank, t.tolist()))
+
     def max_float(self, v, device):
         t = torch.tensor([float(v)], dtype=torch.float64, device=device)
         if self.world > 1:
@@ -72,3 +98,18 @@ def window_shard(n_windows, batch_size, rank, world):
     """whole batches of consecutive windows per rank, round-robin over batches (inference)."""
     nb = -(-n_windows // batch_size)
     return [i for i in range(nb) if i % world == rank]
+
+
+def from_env(backend=None):
+    """(device, comm) of this process.  Launched by `python -m torch.distributed.run --nproc-per-node N ...` (WORLD_SIZE > 1):
+    bind to GPU LOCAL_RANK and form the process group BEFORE any other GPU call, one rank per GPU over RCCL.  Plain launch:
+    ("cuda:0", None).  DRS_DIST_REHEARSAL=1 puts every rank on cuda:0 over gloo (one-GPU boxes: exercises the N > 1 code path,
+    says nothing about speed)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return "cuda:0", None
+    rehearsal = os.environ.get("DRS_DIST_REHEARSAL") == "1"
+    local = 0 if rehearsal else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    comm = TorchComm(backend or ("gloo" if rehearsal else "nccl"))
+    return "cuda:%d" % local, comm

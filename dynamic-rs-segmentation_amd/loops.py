@@ -125,6 +125,35 @@ def validation(net, test_pool, selected_testing_instances, mean_full, std_full, 
     return cm, n * crop_size * crop_size
 
 
+# ------------------------------------------------------------------------------------------------- data parallelism
+def sync_rng(comm):
+    """Data parallelism runs the same host code on every rank and relies on identical `random` / `numpy.random` streams (size
+    draw, batch indices, augmentation).  Nothing guarantees that by itself -- the reference never seeds, and a rank that loads
+    a cache file skips the draws the rank that built it made -- so at every point where the ranks may have drifted (start of a
+    loop, after a cache was built or loaded) rank 0 draws two seeds from ITS streams and every rank re-seeds from them.
+    A single process is untouched (the reference's stream order)."""
+    if not getattr(comm, "sync_rng", False):
+        return
+    seeds = comm.broadcast_object((random.getrandbits(31), int(np.random.randint(0, 2 ** 31 - 1))))
+    random.seed(seeds[0])
+    np.random.seed(seeds[1])
+
+
+def rank0_cached(comm, path, make):
+    """the reference's cwd / output .npy caches (isprs:1634-1639, 2087-2115) under data parallelism: rank 0 loads or builds and
+    saves, every rank gets rank 0's array (no rank reads a half-written file, every rank takes the same branch)."""
+    v = None
+    if comm.rank == 0:
+        if os.path.isfile(path):
+            v = np.load(path, allow_pickle=True)
+        else:
+            v = make()
+            tmp = path + ".tmp%d.npy" % os.getpid()
+            np.save(tmp, np.asarray(v, dtype=object) if isinstance(v, list) else v)
+            os.replace(tmp, path)                    # atomic: a concurrent reader sees the old state or the whole file
+    return comm.broadcast_object(v)
+
+
 # ------------------------------------------------------------------------------------------------- training
 class _Pending(object):
     """Results of a step that are read back one step late."""
@@ -159,20 +188,16 @@ def train(training_data, training_labels, training_class_distribution, training_
     channels = training_data[0].shape[-1]
     say("channels ", channels)
 
+    if batch_size % comm.world:
+        raise ValueError("batch_size must be divisible by the number of ranks")
+    sync_rng(comm)
     selected_training_instances = SP.select_super_batch_instances(training_class_distribution, training_rotation_distribution,
                                                                   batch_size, super_batch=SUPER_BATCH)
     total_length = len(selected_training_instances)
     cache = os.path.join(val_cache_dir or os.getcwd(), "dataset_" + dataset + ".npy")      # isprs:1634-1639
-    if os.path.isfile(cache):
-        selected_testing_instances = np.load(cache)
-    else:
-        selected_testing_instances = SP.select_super_batch_instances(testing_class_distribution, batch_size=batch_size,
-                                                                     super_batch=SUPER_BATCH)
-        if comm.rank == 0:
-            np.save(cache, selected_testing_instances)
-
-    if batch_size % comm.world:
-        raise ValueError("batch_size must be divisible by the number of ranks")
+    selected_testing_instances = rank0_cached(comm, cache, lambda: SP.select_super_batch_instances(
+        testing_class_distribution, batch_size=batch_size, super_batch=SUPER_BATCH))
+    sync_rng(comm)                                   # rank 0 may just have drawn what the others did not
     b_local = batch_size // comm.world
     sl = shard_slice(batch_size, comm.rank, comm.world)
     s_max = int(values[0]) if distribution_type == "single_fixed" else int(max(values))
@@ -225,12 +250,14 @@ def train(training_data, training_labels, training_class_distribution, training_
         if not quiet_sizes:
             say(cur_patch_size)
         shuffle, batch, it = P.select_batch(shuffle, batch_size, it, total_length)
+        if step - current_iter < 3:                  # the ranks must move in lock step: same size, same instances
+            comm.agree((cur_patch_size, batch[0], batch[-1], it), "patch size / batch indices at step %d" % step)
         rows = selected_training_instances[batch]
         aug = P.draw_augmentation(rows, cur_patch_size, channels, noise=noise)
         mine = P.Augmentation(b_local)
         mine.rot_on, mine.rot, mine.noise_on, mine.flip = aug.rot_on[sl], aug.rot[sl], aug.noise_on[sl], aug.flip[sl]
         mine.noise = aug.noise[sl] if aug.noise is not None else None
-        mine.seed = aug.seed + comm.rank
+        mine.seed, mine.index0 = aug.seed, sl.start      # device noise is keyed by the patch's place in the global batch
         P.crop_to_net(net, train_pool, rows[sl], cur_patch_size, mean_full, std_full, mine)
         out = net.train_step(b_local, cur_patch_size, lr_initial)
         pending.append(_Pending(net, out, cur_size_int, step, epoch_counter))

@@ -61,6 +61,9 @@ def train(training_data, training_labels, test_data, test_labels, class_distribu
           patch_occur, patch_chosen_values, probs, values, *, num_classes, void_label=-1, side_names=None, device="cuda:0",
           comm=None, display_step=50, quiet_sizes=False):
     comm = comm or NoComm()
+    if batch_size % comm.world:
+        raise ValueError("batch_size must be divisible by the number of ranks")
+    loops.sync_rng(comm)                 # every rank walks the same permutation and draws the same sizes
     say = (lambda *a: print(*a)) if comm.rank == 0 else (lambda *a: None)
     side = side_names or ("patch_acc_loss_step_", "patch_occur_step_", "patch_chosen_values_step_")
     channels = training_data[0].shape[-1]
@@ -109,6 +112,8 @@ def train(training_data, training_labels, test_data, test_labels, class_distribu
         if not quiet_sizes:
             say(cur_size)
         shuffle, batch, it = P.select_batch(shuffle, batch_size, it, total)
+        if step - current_iter < 3:
+            comm.agree((cur_size, batch[0], batch[-1], it), "patch size / batch indices at step %d" % step)
         flip = np.where(batch >= 2 * N, 1, np.where(batch >= N, 2, 0))              # kernel codes: 1 = flipud, 2 = fliplr
         rows = dist_arr[batch % N]
         aug = P.Augmentation(b_local)

@@ -70,6 +70,20 @@ class NoComm(object):
     def wait(handles):
         pass
 
+    sync_rng = False
+
+    @staticmethod
+    def broadcast_object(obj, src=0):
+        return obj
+
+    @staticmethod
+    def agree(values, what="value"):
+        pass
+
+    @staticmethod
+    def barrier():
+        pass
+
 
 class DilatedNet(object):
     def __init__(self, net_type, channels, num_classes, weight_decay, b_max, s_max, device="cuda:0", seed=42,

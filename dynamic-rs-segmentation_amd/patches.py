@@ -109,6 +109,7 @@ class Augmentation(object):
         self.flip = np.zeros(B, dtype=np.int32)
         self.noise = None          # [B, S, S, C] float64 when host noise is used
         self.seed = 0
+        self.index0 = 0            # place of the first patch in the global batch (device noise is keyed by the global index)
 
 
 def draw_augmentation(instances, S, C, noise="device"):
@@ -232,7 +233,7 @@ def crop_to_net(net, pool, instances, S, mean, std, aug=None, void_label=-1):
               pool.tile_off.data_ptr(), pool.lab_off.data_ptr(), pool.tile_h.data_ptr(), pool.tile_w.data_ptr(), pool.C,
               p_inst, p_rot if aug is not None else None, p_ron if aug is not None else None,
               None if noise is None else noise.data_ptr(), p_non if aug is not None else None,
-              aug.seed if aug is not None else 0, C.cast(m3c, C.c_void_p), C.cast(s3c, C.c_void_p), B, S, P, ld,
+              aug.seed if aug is not None else 0, aug.index0 if aug is not None else 0, C.cast(m3c, C.c_void_p), C.cast(s3c, C.c_void_p), B, S, P, ld,
               slab.data_ptr(), net.labels.data_ptr(), net.acc_mask.data_ptr(), int(void_label), net._stream())
     net._keep = noise                                            # alive until the stream has consumed it
     return inst[:, 1:3]

@@ -19,7 +19,8 @@
  *     (b, y, x), channel c of the slice lives at base[((b*(S+2P) + y+P)*(S+2P) + x+P)*ld + coff + c];
  *     P = 0 gives the reference's plain [B, S, S, C] tensor; filters are HWIO = [k][k][Cin][Cout] as in the
  *     reference (isprs:706);
- *   - B*S*S must be < 2^24.
+ *   - B*S*S must be < 2^24, and every activation slab a convolution reads must stay below 4 GiB (2^30 floats): the kernels
+ *     address with a wave-uniform 64-bit base plus 32-bit byte offsets.
  */
 #ifndef DRS_H_
 #define DRS_H_
@@ -191,7 +192,8 @@ int drs_confusion(const unsigned char* labels, const unsigned char* pred, const 
 /* ---- dynamically_create_patches + normalize_images  (isprs:245-334, 74-81; tiler isprs:337-400) ----------
  * inst [B][4] = (map, row, col, flip) with the border shift-back already applied (isprs:260-269);
  * rot [B][6] = (m00 m01 m10 m11 off0 off1) of scipy.ndimage.rotate(order=0, reshape=False) when rot_on[b];
- * noise [B][S][S][C] (fp64, reference-exact) or NULL (device Philox N(0, 0.01)) when noise_on[b];
+ * noise [B][S][S][C] (fp64, reference-exact) or NULL (device Philox N(0, 0.01) keyed by (seed, noise_index0 + b, element):
+ * noise_index0 = index of this call's first patch in the global batch, so a sharded batch draws the same noise) when noise_on[b];
  * out: conv1 input slab [B][S+2P][S+2P][ld] (channels C..ld-1 and the halo are zeroed);
  * out_lab / out_mask [B][S][S] (uint8); out_mask is 0 where the rotation pulled in fill or the label equals
  * void_label (contest_dilated_random.py:235-239; -1 = none).  Normalisation touches channels 0,1,2 only.
@@ -199,7 +201,8 @@ int drs_confusion(const unsigned char* labels, const unsigned char* pred, const 
 int drs_crop_normalize(const void* tiles, int tiles_are_f64, const unsigned char* labels, const long long* tile_off,
                        const long long* lab_off, const int* tile_h, const int* tile_w, int C, const int* inst,
                        const double* rot, const unsigned char* rot_on, const double* noise,
-                       const unsigned char* noise_on, unsigned long long seed, const double* mean3, const double* std3,
+                       const unsigned char* noise_on, unsigned long long seed, int noise_index0, const double* mean3,
+                       const double* std3,
                        int B, int S, int P, int ld, float* out, unsigned char* out_lab, unsigned char* out_mask,
                        int void_label, void* stream);
 
