@@ -48,7 +48,7 @@ SIGNATURES = {
     "drs_momentum_update": (_i, [_p, _p, _p, _sz, _sz, _f, _f, _f, _f, _p]),
     "drs_confusion": (_i, [_p, _p, _p, _sz, _i, _i, _p, _p]),
     "drs_crop_normalize": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _u64, _i, _p, _p, _i, _i, _i, _i, _p, _p,
-                                _p, _i, _p]),
+                                _p, _i, _i, _p]),
     "drs_stitch_accumulate": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "drs_stitch_finalize": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "drs_softmax_accumulate": (_i, [_p, _p, _i, _i, _i, _p, _p]),

@@ -193,7 +193,8 @@ def main_coffee(argv=None, device=None, comm=None):
     mean_full, std_full = LI.create_mean_and_std(train_x, int(ref_crop), int(ref_stride))
     return LI.train(train_x, train_y, test_x, test_y, cd, mean_full, std_full, output_path, current_model, float(lr), float(wd),
                     int(bs), int(niter), net_type, dist, update_type, acc, occ, chosen, probs, values, num_classes=2,
-                    side_names=("errorAcc_step_", "errorOccur_step_", "chosenValues_step_"), device=device, comm=comm)
+                    side_names=("errorAcc_step_", "errorOccur_step_", "chosenValues_step_"), device=device, comm=comm,
+                    quantize_f16=True)                      # coffee:293: training patches pass through float16
 
 
 def main_contest(argv=None, device=None, comm=None):
@@ -217,12 +218,12 @@ def main_contest(argv=None, device=None, comm=None):
         train_x = [datasets.read_torch_ascii(path + "TelopsDatasetCityVisible_20cm_Subset.txt")]
         test_x = [datasets.read_torch_ascii(path + "TelopsDatasetCityVisible.txt")]
         train_y, test_y = [datasets.read_pgm(path + "gt8.pgm").astype(np.uint8)], [datasets.read_pgm(path + "gt_ult8.pgm").astype(np.uint8)]
-    cd = LI.create_distributions_over_classes(train_y, int(crop), int(stride), 7)
-    mean_full, std_full = LI.create_mean_and_std(train_x, int(crop), int(stride))
+    cd = LI.create_distributions_over_classes_contest(train_y[0], int(crop), int(stride), 7)       # contest:172-190
+    mean_full, std_full = LI.create_mean_and_std_contest(train_x[0], cd, int(crop))                # contest:99-113
     if operation == "train":
         return LI.train(train_x, train_y, test_x, test_y, cd, mean_full, std_full, output_path, current_model, float(lr), float(wd),
                         int(bs), int(niter), net_type, dist, update_type, acc, occ, chosen, probs, values, num_classes=7,
-                        void_label=7, device=device, comm=comm)
+                        void_label=7, device=device, comm=comm, flavour="contest")
     if operation == "test":
         from .net import DilatedNet
         step = loops.step_from_model_path(current_model)
@@ -233,7 +234,8 @@ def main_contest(argv=None, device=None, comm=None):
         net = DilatedNet(net_type, train_x[0].shape[-1], 7, float(wd), b_max=int(bs), s_max=max(values), device=device, comm=comm)
         loops.load_checkpoint(net, current_model)
         cs = loops.select_best_patch_size(dist, values, acc, occ, update_type, debug=True) if sized else int(values[0])
-        return loops.validate_test(net, test_x, test_y, ["test"], int(bs), mean_full, std_full, cs, step, output_path, comm, ignore_label=7)
+        return loops.validate_test(net, test_x, test_y, ["test"], int(bs), mean_full, std_full, cs, step, output_path, comm, ignore_label=7,
+                                   flavour="contest")
     print(loops.BatchColors.FAIL + "Process " + operation + "not found!" + loops.BatchColors.ENDC)
 
 

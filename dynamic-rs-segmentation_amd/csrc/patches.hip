@@ -26,6 +26,7 @@ struct CropArgs {
   const double* noise;          // [B][S][S][C] additive noise (pre-flip coordinates) or null
   const unsigned char* noise_on;  // [B] or null
   unsigned long long seed;      // device noise (Philox) when noise == null and noise_on[b]
+  int quantize_f16;             // coffee:293 + :67-74: value, (value - mean) and (... / std) each rounded to float16
   int b0;                       // index of this call's first patch in the global batch: the noise of a patch does not depend on how the batch is sharded
   int void_label;               // pixels carrying this label are masked out too (contest:235-239); -1 = none
   double mean[3], stdv[3];
@@ -98,6 +99,15 @@ __global__ void crop_kernel(const CropArgs a) {
           philox(a.seed, (unsigned long long)ng, r);
           e = __dadd_rn(e, 0.01 * normal_from(r[0], r[1]));
         }
+      }
+      if (a.quantize_f16) {       // numpy >= 2: float16 array (op) float32 scalar runs in float32, the assignment rounds to float16
+        float q = (float)(_Float16)(float)e;
+        if (c < 3) {
+          q = (float)(_Float16)(q - (float)a.mean[c]);
+          q = (float)(_Float16)(q / (float)a.stdv[c]);
+        }
+        v[c] = q;
+        continue;
       }
       if (c < 3) e = __ddiv_rn(__dsub_rn(e, a.mean[c]), a.stdv[c]);
       v[c] = (float)e;
@@ -199,14 +209,14 @@ int drs_crop_normalize(const void* tiles, int tiles_are_f64, const unsigned char
                        const long long* lab_off, const int* tile_h, const int* tile_w, int C, const int* inst,
                        const double* rot, const unsigned char* rot_on, const double* noise, const unsigned char* noise_on,
                        unsigned long long seed, int noise_index0, const double* mean3, const double* std3, int B, int S, int P, int ld,
-                       float* out, unsigned char* out_lab, unsigned char* out_mask, int void_label, void* stream) {
+                       float* out, unsigned char* out_lab, unsigned char* out_mask, int void_label, int quantize_f16, void* stream) {
   if (!tiles || !labels || !tile_off || !lab_off || !tile_h || !tile_w || !inst || !out || !mean3 || !std3) return DRS_ERR_ARG;
   if (C < 1 || C > 8 || ld < C || ld % 4) return DRS_ERR_ARG;
   const int Sp = S + 2 * P;
   if ((long long)B * Sp > 65535) return DRS_ERR_ARG;
   CropArgs a;
   a.tiles = tiles; a.labels = labels; a.tile_off = tile_off; a.lab_off = lab_off; a.tile_h = tile_h; a.tile_w = tile_w; a.C = C;
-  a.inst = inst; a.rot = rot; a.rot_on = rot ? rot_on : nullptr; a.noise = noise; a.noise_on = noise_on; a.seed = seed; a.b0 = noise_index0; a.void_label = void_label;
+  a.inst = inst; a.rot = rot; a.rot_on = rot ? rot_on : nullptr; a.noise = noise; a.noise_on = noise_on; a.seed = seed; a.b0 = noise_index0; a.void_label = void_label; a.quantize_f16 = quantize_f16;
   for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.stdv[c] = std3[c]; }
   a.out = out; a.S = S; a.P = P; a.ld = ld; a.out_lab = out_lab; a.out_mask = out_mask;
   dim3 grid((Sp + 63) / 64, B * Sp);

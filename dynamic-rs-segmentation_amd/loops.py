@@ -313,7 +313,7 @@ def train(training_data, training_labels, training_class_distribution, training_
 
 
 # ------------------------------------------------------------------------------------------------- whole tiles
-def predict_tile(net, pool, map_index, crop_size, batch_size, mean_full, std_full, comm=None, return_sums=False):
+def predict_tile(net, pool, map_index, crop_size, batch_size, mean_full, std_full, comm=None, return_sums=False, flavour="isprs"):
     """The inner loop of validate_test / generate_final_maps (isprs:1261-1284, 1925-1949) for one tile: windows at
     stride floor(s/2) (isprs:1243), logits overlap-added in window order, arg-max of the average.  Returns the
     uint8 label map as a DEVICE tensor [h, w].  Under data parallelism batches of windows go round-robin over the
@@ -333,12 +333,14 @@ def predict_tile(net, pool, map_index, crop_size, batch_size, mean_full, std_ful
     for i in range(nb):
         if i % comm.world != comm.rank:
             continue
-        pos = P.window_positions(h, w, crop_size, stride, i, bs)
+        pos = P.window_positions(h, w, crop_size, stride, i, bs, flavour)          # flavour: where batch i starts (patches.window_start)
+        if len(pos) == 0:
+            continue
         inst = np.concatenate([np.full((len(pos), 1), map_index), pos], axis=1)
         P.crop_to_net(net, pool, inst, crop_size, mean_full, std_full)
         _, logits = net.forward(len(pos), crop_size, want_logits=True)
         _lib.call("drs_stitch_accumulate", prob.data_ptr(), occur.data_ptr(), logits.data_ptr(), h, w, K, crop_size, stride,
-                  i * bs, len(pos), st)
+                  P.window_start(h, w, crop_size, stride, i, bs, flavour), len(pos), st)
     if comm.world > 1:
         comm.all_reduce_sum(prob)
         comm.all_reduce_sum(occur)
@@ -381,7 +383,7 @@ def best_sizes(distribution_type, values, patch_acc_loss, patch_occur, update_ty
 
 
 def validate_test(net, testing_data, testing_labels, testing_instances, batch_size, mean_full, std_full, crop_size, step,
-                  output_path=None, comm=None, pool=None, ignore_label=6, crop_sizes=None):
+                  output_path=None, comm=None, pool=None, ignore_label=6, crop_sizes=None, flavour="isprs"):
     """isprs:1241-1344: per tile, sliding-window prediction and scores (label 6 = eroded boundary is skipped,
     isprs:1294).  Returns (all-maps confusion matrix, list of label maps as numpy)."""
     from . import _lib
@@ -397,7 +399,7 @@ def validate_test(net, testing_data, testing_labels, testing_instances, batch_si
         if crop_sizes:      # validate_test_multiscale (isprs:1347-1474): several sizes, softmax maps summed
             pred = predict_tile_multiscale(net, pool, k, crop_sizes, batch_size, mean_full, std_full, comm)
         else:
-            pred, _ = predict_tile(net, pool, k, crop_size, batch_size, mean_full, std_full, comm)
+            pred, _ = predict_tile(net, pool, k, crop_size, batch_size, mean_full, std_full, comm, flavour=flavour)
         h, w = pool.h[k], pool.w[k]
         conf = torch.zeros(K * K, dtype=torch.int32, device=net.dev)
         lab = pool.labels[int(pool.lab_off[k].item()):int(pool.lab_off[k].item()) + h * w]

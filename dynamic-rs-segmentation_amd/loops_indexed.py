@@ -4,8 +4,8 @@ Host mirror of /root/reference/coffee_dilated_random.py `main` :1105-1369 (there
 contest_dilated_random.py `train` :955-1150: no super-batch, no rotation / noise; the permutation runs over 3*N indices and
 the index range encodes the flip ([0,N) as is, [N,2N) left-right, [2N,3N) up-down: coffee:283-291, contest:241-252); LR decay
 factor 0.1; the 'loss' score is the plain batch loss; contest masks the void label out of the loss and the accuracy
-(contest:235-239, 881-901) and starts `patch_occur` at ones.  Deliberately not reproduced: coffee casts its patches to
-float16 before normalising (coffee:293) -- a lossy storage quirk, not part of the algorithm.
+(contest:235-239, 881-901) and starts `patch_occur` at ones.  coffee's training patches pass through float16 (coffee:293) and
+are normalised in that array: `quantize_f16` (drs_crop_normalize), pinned by tests/golden/coffee.npz.
 """
 import random
 
@@ -56,10 +56,35 @@ def create_mean_and_std(training_data, crop_size, stride_crop):
     return np.mean(means, axis=0), np.std(np.asarray(corners), axis=0, ddof=1)
 
 
+def create_distributions_over_classes_contest(labels, crop_size, stride_crop, num_classes=7):
+    """contest:172-190, for its single label map, quirks included: a window is dropped when the HIGHEST class id present in it
+    fills it (`count[-1] == crop^2`: meant for all-void windows, true for any uniform window), and the majority vote runs over
+    `count[:-1]`, i.e. without that highest class.  Rows (0, x, y), buckets concatenated in class order."""
+    buckets = [[] for _ in range(num_classes)]
+    lab = np.squeeze(np.asarray(labels))
+    h, w = lab.shape
+    for i in range(0, h, stride_crop):
+        for j in range(0, w, stride_crop):
+            win = lab[i:i + crop_size, j:j + crop_size]
+            if win.shape == (crop_size, crop_size):
+                count = np.bincount(win.astype(int).flatten())
+                if count[-1] == crop_size * crop_size:
+                    continue
+                buckets[int(np.argmax(count[:-1]))].append((0, i, j))
+    return [w_ for b in buckets for w_ in b]
+
+
+def create_mean_and_std_contest(data, class_distribution, crop_size):
+    """contest:99-113: mean over the class-distribution windows, standard deviation (ddof=1) across them AT PIXEL (0,0)."""
+    means = [data[x:x + crop_size, y:y + crop_size, :].mean(axis=(0, 1), dtype=np.float64) for (_, x, y) in class_distribution]
+    corners = np.asarray([data[x, y, :] for (_, x, y) in class_distribution])
+    return np.mean(means, axis=0), np.std(corners, axis=0, ddof=1)
+
+
 def train(training_data, training_labels, test_data, test_labels, class_distribution, mean_full, std_full, output_path,
           current_model, lr_initial, weight_decay, batch_size, niter, net_type, distribution_type, update_type, patch_acc_loss,
           patch_occur, patch_chosen_values, probs, values, *, num_classes, void_label=-1, side_names=None, device="cuda:0",
-          comm=None, display_step=50, quiet_sizes=False):
+          comm=None, display_step=50, quiet_sizes=False, quantize_f16=False, flavour="isprs"):
     comm = comm or NoComm()
     if batch_size % comm.world:
         raise ValueError("batch_size must be divisible by the number of ranks")
@@ -102,7 +127,7 @@ def train(training_data, training_labels, test_data, test_labels, class_distribu
         cur = (loops.select_best_patch_size(distribution_type, values, patch_acc_loss, patch_occur, update_type, patch_chosen_values,
                                             debug=comm.rank == 0) if sized else int(values[0]))
         return loops.validate_test(net, test_data, test_labels, list(range(len(test_data))), batch_size, mean_full, std_full, cur,
-                                   step, output_path, comm, pool=test_pool, ignore_label=void_label)
+                                   step, output_path, comm, pool=test_pool, ignore_label=void_label, flavour=flavour)
 
     it, epoch_mean = 0, 0.0
     epoch_cm = np.zeros((num_classes, num_classes), dtype=np.uint32)
@@ -118,7 +143,7 @@ def train(training_data, training_labels, test_data, test_labels, class_distribu
         rows = dist_arr[batch % N]
         aug = P.Augmentation(b_local)
         aug.flip = flip[sl].astype(np.int32)
-        P.crop_to_net(net, train_pool, rows[sl], cur_size, mean_full, std_full, aug, void_label=void_label)
+        P.crop_to_net(net, train_pool, rows[sl], cur_size, mean_full, std_full, aug, void_label=void_label, quantize_f16=quantize_f16)
         M = b_local * cur_size * cur_size
         if void_label >= 0:                      # masked mean: the loss averages over the unmasked pixels of the global batch
             cnt = net.acc_mask[:M].sum(dtype=torch.float64).reshape(1)

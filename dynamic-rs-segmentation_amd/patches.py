@@ -67,11 +67,26 @@ def window_counts(h, w, crop_size, stride):
     return n(h), n(w)
 
 
-def window_positions(h, w, crop_size, stride, index, batch_size):
-    """isprs:337-400 without the pixel copies: (x, y) of windows index*batch .. (row-major), the last
+def window_start(h, w, crop_size, stride, index, batch_size, flavour="isprs"):
+    """flat (row-major) index of the first window of batch `index`.  isprs:353-354 starts batch i at window i*batch_size.
+    contest:275-276 divides by the number of window ROWS where the number of columns belongs
+    (`offset_h = int(index*batch_size / total_index_h)`), so on a non-square tile its batches start too early (tall tiles:
+    windows evaluated twice, the bottom rows never) or too late: reproduced for flavour="contest" because the reference's label
+    maps on such tiles are what they are.  coffee:304-309 takes both counts from the height; its tiles are square (500 x 500),
+    where all three agree."""
+    n_h, n_w = window_counts(h, w, crop_size, stride)
+    f = index * batch_size
+    if flavour == "contest":
+        return (f // n_h) * n_w + f % n_w
+    return f
+
+
+def window_positions(h, w, crop_size, stride, index, batch_size, flavour="isprs"):
+    """isprs:337-400 without the pixel copies: (x, y) of the windows of batch `index` (row-major from window_start), the last
     row / column shifted back to end at the border."""
     n_h, n_w = window_counts(h, w, crop_size, stride)
-    f = np.arange(index * batch_size, min((index + 1) * batch_size, n_h * n_w))
+    f0 = window_start(h, w, crop_size, stride, index, batch_size, flavour)
+    f = np.arange(f0, max(f0, min(f0 + batch_size, n_h * n_w)))
     x = np.minimum((f // n_w) * stride, h - crop_size)
     y = np.minimum((f % n_w) * stride, w - crop_size)
     return np.stack([x, y], axis=1).astype(np.int64)
@@ -208,9 +223,11 @@ class _Staging(object):
         return base + self.o_inst, base + self.o_rot, base + self.o_ron, base + self.o_non
 
 
-def crop_to_net(net, pool, instances, S, mean, std, aug=None, void_label=-1):
+def crop_to_net(net, pool, instances, S, mean, std, aug=None, void_label=-1, quantize_f16=False):
     """dynamically_create_patches + normalize_images (isprs:1742-1745 / 1579-1583) fused on the device:
-    fills net's conv1 slab, net.labels and net.acc_mask for `instances` rows (map, x, y[, rot])."""
+    fills net's conv1 slab, net.labels and net.acc_mask for `instances` rows (map, x, y[, rot]).
+    quantize_f16: the coffee script's training patches pass through float16 (coffee:293) and are normalised in place in that
+    array (coffee:1290): value, difference and quotient are each rounded to float16."""
     import ctypes as C
     B = len(instances)
     net._check(B, S)
@@ -234,7 +251,7 @@ def crop_to_net(net, pool, instances, S, mean, std, aug=None, void_label=-1):
               p_inst, p_rot if aug is not None else None, p_ron if aug is not None else None,
               None if noise is None else noise.data_ptr(), p_non if aug is not None else None,
               aug.seed if aug is not None else 0, aug.index0 if aug is not None else 0, C.cast(m3c, C.c_void_p), C.cast(s3c, C.c_void_p), B, S, P, ld,
-              slab.data_ptr(), net.labels.data_ptr(), net.acc_mask.data_ptr(), int(void_label), net._stream())
+              slab.data_ptr(), net.labels.data_ptr(), net.acc_mask.data_ptr(), int(void_label), 1 if quantize_f16 else 0, net._stream())
     net._keep = noise                                            # alive until the stream has consumed it
     return inst[:, 1:3]
 

@@ -197,14 +197,16 @@ int drs_confusion(const unsigned char* labels, const unsigned char* pred, const 
  * out: conv1 input slab [B][S+2P][S+2P][ld] (channels C..ld-1 and the halo are zeroed);
  * out_lab / out_mask [B][S][S] (uint8); out_mask is 0 where the rotation pulled in fill or the label equals
  * void_label (contest_dilated_random.py:235-239; -1 = none).  Normalisation touches channels 0,1,2 only.
- * mean3 / std3 are HOST pointers to 3 doubles each (copied into the kernel arguments). */
+ * mean3 / std3 are HOST pointers to 3 doubles each (copied into the kernel arguments).
+ * quantize_f16: coffee_dilated_random.py:293 casts its training patches to float16 and :67-74 normalises them in that array:
+ * value, value - mean and (value - mean) / std are each rounded to float16 (float32 arithmetic, as numpy >= 2 evaluates it). */
 int drs_crop_normalize(const void* tiles, int tiles_are_f64, const unsigned char* labels, const long long* tile_off,
                        const long long* lab_off, const int* tile_h, const int* tile_w, int C, const int* inst,
                        const double* rot, const unsigned char* rot_on, const double* noise,
                        const unsigned char* noise_on, unsigned long long seed, int noise_index0, const double* mean3,
                        const double* std3,
                        int B, int S, int P, int ld, float* out, unsigned char* out_lab, unsigned char* out_mask,
-                       int void_label, void* stream);
+                       int void_label, int quantize_f16, void* stream);
 
 /* ---- overlap-add of window logits and arg-max of the average  (isprs:1261-1284, 1925-1949) ---------------
  * windows [first_window, first_window + n_windows) of the row-major window grid at `stride` (last row/col

@@ -216,3 +216,39 @@ def multiscale_argmax(mean_logit_maps):
         mean_prob[i] = m
         mean_prob[i] = softmax_lastaxis(mean_prob[i])
     return np.argmax(np.sum(mean_prob, axis=0), axis=2)
+
+
+def indexed_create_patches(data, mask_data, crop_size, class_distribution, shuffle, float16=False, void_label=None):
+    """coffee_dilated_random.py:241-293 / contest_dilated_random.py:192-254: index i of the 3N-long permutation selects window
+    i mod N and the flip ([0,N) as is, [N,2N) left-right, [2N,3N) up-down); a window clipped by the border moves back to end at
+    it; coffee returns float16 patches (:293); contest also returns the void mask (label 7 -> False, :235-239).
+    data [n,H,W,C], mask_data [n,H,W]; class_distribution rows (map, x, y)."""
+    n = len(class_distribution)
+    patches, classes, masks = [], [], []
+    for i in shuffle:
+        k, x, y = class_distribution[int(i) % n]
+        h, w = data[k].shape[0], data[k].shape[1]
+        x, y = min(x, h - crop_size), min(y, w - crop_size)
+        p = data[k][x:x + crop_size, y:y + crop_size, :]
+        c = mask_data[k][x:x + crop_size, y:y + crop_size]
+        m = (c != void_label) if void_label is not None else np.ones(c.shape, dtype=bool)
+        if n <= i < 2 * n:
+            p, c, m = np.fliplr(p), np.fliplr(c), np.fliplr(m)
+        elif i >= 2 * n:
+            p, c, m = np.flipud(p), np.flipud(c), np.flipud(m)
+        patches.append(p)
+        classes.append(c)
+        masks.append(m)
+    return (np.asarray(patches, dtype=np.float16 if float16 else None), np.asarray(classes, dtype=np.int8), np.asarray(masks, dtype=bool))
+
+
+def normalize_images_f16(patches16, mean_full, std_full):
+    """coffee:67-74 applied to the float16 patches of coffee:293, as numpy >= 2 evaluates it (the goldens were made with 2.2):
+    float16 array (op) float32 scalar runs in float32 and the assignment into the float16 array rounds -- so every value is
+    rounded to float16 three times: by the cast, after the subtraction and after the division.  (numpy 1.x cast the scalar to
+    float16 first; results can differ in the last float16 bit.)"""
+    out = patches16.copy()
+    for ch in range(3):
+        out[..., ch] = np.subtract(out[..., ch], np.float32(mean_full[ch]))
+        out[..., ch] = np.divide(out[..., ch], np.float32(std_full[ch]))
+    return out

@@ -161,7 +161,114 @@ def main():
     mean_full, std_full = ref.dynamically_calculate_mean_and_std(data, dist, 25)
     d["data0"], d["data1"], d["mean_full"], d["std_full"] = data[0], data[1], mean_full, std_full
     np.savez_compressed(os.path.join(HERE, "sampling.npz"), **d)
+    coffee_goldens()
+    contest_goldens()
     print("goldens written to", HERE)
+
+
+class _NpPy2(object):
+    """`np` as the coffee script sees it: its `np.empty([len(files) / 2, ...])` (coffee:85-86) relies on Python 2's integer `/`."""
+
+    def __getattr__(self, k):
+        return getattr(np, k)
+
+    @staticmethod
+    def empty(shape, *a, **k):
+        return np.empty([int(v) for v in shape], *a, **k)
+
+
+def coffee_goldens():
+    """coffee_dilated_random.py: the flip-by-index patch sampler with its float16 cast (:241-293), normalisation of those float16
+    patches (:67-74), the square-tile window enumeration (:296-349), class distributions (:358-372), mean / std (:352-355) and the
+    Torch-ASCII reader (:84-125)."""
+    import importlib
+    import tempfile
+    import_reference()
+    cf = importlib.import_module("coffee_dilated_random")
+    cf.np = _NpPy2()
+    sys.path.insert(0, HERE)
+    from torch_ascii_fixture import write_torch_ascii
+    rng = np.random.default_rng(101)
+    data = rng.uniform(0, 1, size=(2, 40, 40, 3)).astype(np.float32)
+    mask = np.zeros((2, 40, 40, 1), dtype=np.float32)
+    mask[0, :22, :17] = 1
+    mask[1, 10:, 25:] = 1
+    mask[1, 30:, :8] = 1
+    d = dict(data=data, mask=mask)
+    dist = cf.create_distributions_over_classes([mask[0], mask[1]], 9, 4)
+    d["dist"] = np.array([(k, i, j) for (k, (i, j)) in dist], dtype=np.int64)
+    mean, std = cf.create_mean_and_std(data, mask, 9, 4)
+    d["mean"], d["std"] = mean, std
+    # windows were enumerated at the reference crop size (9) but are cut at the step's size (13): the border ones shift back
+    n = len(dist)
+    shuffle = np.array([0, n - 1, n + 3, 2 * n - 1, 2 * n, 3 * n - 1, 7, n + 7, 2 * n + 7, n // 2, n + n // 2, 2 * n + n // 2, 1, n + 1])
+    for s in (9, 13):
+        p, c = cf.dynamically_create_patches(data, mask, s, dist, shuffle)
+        d["patches16_%d" % s], d["classes_%d" % s] = p, c                      # float16 / int8 as returned
+        pn = p.copy()
+        cf.normalize_images(pn, mean, std)                                       # in place, on the float16 array
+        d["normalized16_%d" % s] = pn
+    d["shuffle"] = shuffle
+    for tag, (s, st, idx, bs) in dict(a=(13, 6, 0, 64), b=(13, 6, 1, 10), c=(9, 4, 3, 7)).items():
+        p, c, pos = cf.create_patches_per_map(data[0], mask[0], s, st, idx, bs)
+        d["win_args_" + tag] = np.array([s, st, idx, bs])
+        d["win_pos_" + tag] = np.asarray(pos)
+        d["win_psum_" + tag] = p.reshape(len(p), -1).sum(axis=1)
+    # Torch-ASCII reader: two (image, mask) pairs of the hard-wired 500 x 500 size, written from seeds (torch_ascii_fixture.py)
+    with tempfile.TemporaryDirectory() as tmp:
+        for i, nm in enumerate(["B_img.txt", "b_mask.txt", "a_img.txt", "A_mask.txt"]):     # case-insensitive sort: a_img, A_mask, B_img, b_mask
+            write_torch_ascii(os.path.join(tmp, nm), seed=500 + i, c=1 if "mask" in nm else 3, h=500, w=500, is_mask="mask" in nm)
+        imgs, masks = cf.load_images_torch(tmp + "/")
+    d["torch_names"] = np.array(["B_img.txt", "b_mask.txt", "a_img.txt", "A_mask.txt"])
+    d["torch_seeds"] = np.array([500, 501, 502, 503])
+    d["torch_img_shape"], d["torch_mask_shape"] = np.array(imgs.shape), np.array(masks.shape)
+    d["torch_img_sample"] = imgs[:, ::37, ::41, :].copy()
+    d["torch_img_sum"] = imgs.astype(np.float64).sum(axis=(1, 2))
+    d["torch_mask_sample"] = masks[:, ::37, ::41, :].copy()
+    d["torch_mask_sum"] = masks.astype(np.float64).sum(axis=(1, 2, 3))
+    np.savez_compressed(os.path.join(HERE, "coffee.npz"), **d)
+
+
+def contest_goldens():
+    """contest_dilated_random.py: class distributions with their quirks (:172-190), mean / std over those windows (:99-113), the
+    flip-by-index sampler with the void mask (:192-254), the non-square window enumeration with masks (:257-324), the PGM label
+    reader (:119-143) and the accuracy function that never counts (:327-345: `mask[i, j, k] is True` is False for numpy bools)."""
+    import importlib
+    import_reference()
+    ct = importlib.import_module("contest_dilated_random")
+    rng = np.random.default_rng(202)
+    data = rng.uniform(0, 1, size=(60, 50, 3)).astype(np.float32)
+    lab = rng.integers(0, 7, size=(60, 50)).astype(np.int64)
+    lab[:20, :30] = 3                     # a uniform region (windows inside it are all one class)
+    lab[40:, 20:] = 7                     # a void region
+    lab[25:35, 5:15] = 6
+    d = dict(data=data, lab=lab)
+    dist = ct.create_distributions_over_classes(lab, 9, 4)
+    d["dist"] = np.array(dist, dtype=np.int64).reshape(-1, 2)
+    mean, std = ct.create_mean_and_std(data, dist, 9)
+    d["mean"], d["std"] = mean, std
+    n = len(dist)
+    shuffle = np.array([0, n - 1, n + 2, 2 * n - 1, 2 * n, 3 * n - 1, 5, n + 5, 2 * n + 5, n // 3, n + n // 3, 2 * n + n // 3])
+    for s in (9, 14):
+        p, c, m = ct.dynamically_create_patches(data, lab, s, dist, shuffle)
+        d["patches_%d" % s], d["classes_%d" % s], d["masks_%d" % s] = p, c, m
+    d["shuffle"] = shuffle
+    for tag, (s, st, idx, bs) in dict(a=(14, 7, 0, 64), b=(14, 7, 1, 9), c=(9, 4, 5, 8)).items():
+        p, c, m, pos = ct.create_patches_per_map(data, lab, s, st, idx, bs)
+        d["win_args_" + tag] = np.array([s, st, idx, bs])
+        d["win_pos_" + tag] = np.asarray(pos)
+        d["win_psum_" + tag] = p.reshape(len(p), -1).sum(axis=1)
+        d["win_mask_" + tag] = m
+    with open(os.path.join(HERE, "contest_gt.pgm")) as fh:
+        d["pgm"] = ct.read_pgm(fh)
+    t = rng.integers(0, 7, size=(2, 5, 5))
+    p = rng.integers(0, 7, size=(2, 5, 5))
+    m = np.ones((2, 5, 5), dtype=bool)
+    track = np.zeros((7, 7), dtype=np.uint32)
+    res = ct.calc_cccuracy_by_crop(t, p, m, track)
+    d["acc_quirk"] = np.array([float(res[0])])        # 0: documented quirk, deliberately not reproduced (SURVEY 2.1)
+    d["acc_quirk_track_sum"] = np.array([int(track.sum())])
+    np.savez_compressed(os.path.join(HERE, "contest.npz"), **d)
 
 
 if __name__ == "__main__":

@@ -112,3 +112,46 @@ def test_shard_slice_rejects_uneven_batches():
         assert False
     except ValueError:
         pass
+
+
+def _sync_worker(rank, world, port, tmp):
+    """loops.sync_rng / rank0_cached / TorchComm.agree with two ranks that start from DIFFERENT RNG states and of which only
+    rank 0 builds the cache (so only rank 0 consumes draws there): what the data-parallel step loops rely on."""
+    import random
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"], os.environ["WORLD_SIZE"] = str(rank), str(world)
+    from drs_amd.dist import TorchComm
+    from drs_amd import loops
+    comm = TorchComm("gloo")
+    random.seed(100 + rank)
+    np.random.seed(200 + rank)
+    loops.sync_rng(comm)
+    a = (random.random(), float(np.random.rand()))
+    path = os.path.join(tmp, "cache.npy")
+
+    def make():
+        assert comm.rank == 0                       # only rank 0 ever builds
+        return np.random.randint(0, 1000, size=(5, 3))
+    v1 = loops.rank0_cached(comm, path, make)       # built by rank 0 (draws there only), broadcast
+    loops.sync_rng(comm)                            # ... so the streams are re-aligned afterwards
+    b = (random.random(), float(np.random.rand()))
+    v2 = loops.rank0_cached(comm, path, make)       # now loaded by rank 0, broadcast
+    comm.agree((int(v1.sum()), int(v2.sum()), 7), "cache contents")
+    ok = False
+    try:
+        comm.agree((rank,), "rank (must differ)")
+    except RuntimeError:
+        ok = True
+    assert ok
+    np.save(os.path.join(tmp, "r%d.npy" % rank), np.array([a[0], a[1], b[0], b[1], float(v1.sum()), float(v2.sum())]))
+    comm.barrier()
+    dist.destroy_process_group()
+
+
+def test_rng_and_cache_synchronisation_across_ranks(tmp_path):
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_sync_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
+    np.testing.assert_array_equal(r0, r1)
+    assert os.path.isfile(tmp_path / "cache.npy") and not [f for f in os.listdir(tmp_path) if ".tmp" in f]

@@ -58,3 +58,69 @@ def test_two_rank_step_equals_single_rank(tmp_path):
     assert rel(r["params"], d.params.cpu().numpy()) < 1e-4
     assert rel(r["bn"], d.bn.cpu().numpy()) < 1e-6
     np.testing.assert_array_equal(r["conf"], res["conf"].cpu().numpy())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# data parallelism behind the reference's command line (isprs:1987-2138): two processes through cli.main, placed by the
+# launcher's environment (dist.from_env), against the single-process run.
+ARGV = ["isprs_dilated_random.py", "synthetic:70x80x5/vaihingen/", "OUT", "none", "a,b", "c", "0.01", "0.005", "4", "3", "25", "10",
+        "dilated8_grsl", "multi_fixed", "9,13", "acc", "training"]
+
+
+def _cli_worker(rank, world, port, root):
+    import random
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      DRS_DIST_REHEARSAL="1")               # both ranks on the one GPU of the test box, over gloo
+    import torch.distributed as dist
+    from drs_amd import cli
+    os.chdir(root)                                           # the reference keeps its .npy caches in the cwd
+    random.seed(40 + rank)                                   # deliberately different: loops.sync_rng must align the ranks
+    np.random.seed(50 + rank)
+    argv = list(ARGV)
+    argv[2] = os.path.join(root, "dp_")
+    net = cli.main(argv)                                     # device / communicator from the environment
+    assert net.comm.world == 2 and net.b_max == 2
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.save(os.path.join(root, "dp_params.npy"), net.params.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_through_the_command_line_equal_one_process(tmp_path):
+    import random
+    from drs_amd import cli
+    from drs_amd.net import NoComm
+
+    class _SyncOnly(NoComm):
+        """single-process stand-in that re-seeds at the loops' synchronisation points exactly like a 2-rank run's rank 0"""
+        sync_rng = True
+    root2, root1 = str(tmp_path / "two"), str(tmp_path / "one")
+    os.makedirs(root2)
+    os.makedirs(root1)
+    env0 = dict(os.environ)
+    try:
+        mp.spawn(_cli_worker, args=(2, 30100 + os.getpid() % 1000, root2), nprocs=2, join=True)
+    finally:
+        os.environ.clear()
+        os.environ.update(env0)
+    cwd = os.getcwd()
+    os.chdir(root1)
+    try:
+        random.seed(40)
+        np.random.seed(50)
+        argv = list(ARGV)
+        argv[2] = os.path.join(root1, "sp_")
+        net = cli.main(argv, device="cuda:0", comm=_SyncOnly())
+    finally:
+        os.chdir(cwd)
+    torch.cuda.synchronize()
+    # only rank 0 wrote: one checkpoint, one set of score files, one set of cwd caches, no temporary left behind
+    files = sorted(os.listdir(root2))
+    assert "dp_model-3.npz" in files and "dp_patch_occur_step_3.npy" in files and not [f for f in files if ".tmp" in f]
+    np.testing.assert_array_equal(np.load(os.path.join(root2, "dp_patch_occur_step_3.npy")), np.load(os.path.join(root1, "sp_patch_occur_step_3.npy")))
+    np.testing.assert_allclose(np.load(os.path.join(root2, "dp_patch_acc_loss_step_3.npy")),
+                               np.load(os.path.join(root1, "sp_patch_acc_loss_step_3.npy")), rtol=0, atol=0.02)
+    np.testing.assert_array_equal(np.load(os.path.join(root2, "dataset_vaihingen.npy")), np.load(os.path.join(root1, "dataset_vaihingen.npy")))
+    a, b = np.load(os.path.join(root2, "dp_params.npy")), net.params.cpu().numpy()
+    assert float(np.abs(a - b).max() / np.abs(b).max()) < 5e-4          # same patches, sizes and augmentation; sums grouped differently

@@ -12,6 +12,8 @@ pytestmark = pytest.mark.gpu
 
 from gpu_util import DEV, dev, stream   # noqa: E402
 
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
 
 def _net(ch, B, S):
     from drs_amd.net import DilatedNet
@@ -108,3 +110,55 @@ def test_stitch_matches_reference_order(h, w, S, K, bs):
     np.testing.assert_array_equal(prob.cpu().numpy().reshape(h, w, K), p_ref)      # same addition order -> bit-exact
     np.testing.assert_array_equal(occ.cpu().numpy().reshape(h, w), o_ref[:, :, 0])
     np.testing.assert_array_equal(out.cpu().numpy().reshape(h, w), am_ref)
+
+
+# ---- the coffee / contest flavours of the sampler on the device, against goldens made by the reference's own functions
+def _indexed_on_device(g, S, C, K, dist, data_tiles, lab_tiles, void_label=-1, quantize=False, mean=(0, 0, 0), std=(1, 1, 1)):
+    from drs_amd import patches as P
+    from drs_amd.net import DilatedNet
+    n = len(dist)
+    shuffle = g["shuffle"]
+    B = len(shuffle)
+    d = DilatedNet("dilated_icpr_rate6_small", C, K, 0.0, b_max=B, s_max=S, device=DEV)
+    pool = P.TilePool(data_tiles, lab_tiles, DEV, dtype=np.float32)
+    rows = np.asarray(dist, dtype=np.int64)[shuffle % n]
+    aug = P.Augmentation(B)
+    aug.flip = np.where(shuffle >= 2 * n, 1, np.where(shuffle >= n, 2, 0)).astype(np.int32)       # as loops_indexed.train
+    P.crop_to_net(d, pool, rows, S, mean, std, aug, void_label=void_label, quantize_f16=quantize)
+    torch.cuda.synchronize()
+    slab, Pd, ld = d.input_slab()
+    x = slab.view(B, S + 2 * Pd, S + 2 * Pd, ld)[:, Pd:Pd + S, Pd:Pd + S, :C].cpu().numpy()
+    M = B * S * S
+    return x, d.labels[:M].cpu().numpy().reshape(B, S, S), d.acc_mask[:M].cpu().numpy().reshape(B, S, S).astype(bool)
+
+
+@pytest.mark.parametrize("S", [9, 13])
+def test_coffee_sampler_flip_by_index_and_float16_on_device(S):
+    g = np.load(os.path.join(GOLDEN, "coffee.npz"))
+    dist = [(int(k), int(i), int(j)) for k, i, j in g["dist"]]
+    tiles = [g["data"][0], g["data"][1]]
+    labs = [g["mask"][0, :, :, 0].astype(np.uint8), g["mask"][1, :, :, 0].astype(np.uint8)]
+    x, lab, _ = _indexed_on_device(g, S, 3, 2, dist, tiles, labs)
+    np.testing.assert_array_equal(x, _ref_patches(g, S))                              # float32 path: the plain crop + flip
+    np.testing.assert_array_equal(lab, g["classes_%d" % S][..., 0])
+    xq, _, _ = _indexed_on_device(g, S, 3, 2, dist, tiles, labs, quantize=True)
+    np.testing.assert_array_equal(xq, g["patches16_%d" % S].astype(np.float32))       # coffee:293
+    xn, _, _ = _indexed_on_device(g, S, 3, 2, dist, tiles, labs, quantize=True, mean=g["mean"], std=g["std"])
+    np.testing.assert_array_equal(xn, g["normalized16_%d" % S].astype(np.float32))    # coffee:67-74 on the float16 array, bit for bit
+
+
+def _ref_patches(g, S):
+    from oracle import host_ref as H
+    dist = [(int(k), int(i), int(j)) for k, i, j in g["dist"]]
+    p, _, _ = H.indexed_create_patches(g["data"], g["mask"][..., 0], S, dist, g["shuffle"])
+    return p.astype(np.float32)
+
+
+@pytest.mark.parametrize("S", [9, 14])
+def test_contest_sampler_with_void_mask_on_device(S):
+    g = np.load(os.path.join(GOLDEN, "contest.npz"))
+    dist = [(0, int(i), int(j)) for i, j in g["dist"]]
+    x, lab, mask = _indexed_on_device(g, S, 3, 7, dist, [g["data"]], [g["lab"].astype(np.uint8)], void_label=7)
+    np.testing.assert_array_equal(x, g["patches_%d" % S])
+    np.testing.assert_array_equal(lab, g["classes_%d" % S])
+    np.testing.assert_array_equal(mask, g["masks_%d" % S])
