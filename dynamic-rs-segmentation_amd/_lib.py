@@ -52,7 +52,34 @@ SIGNATURES = {
     "drs_stitch_accumulate": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "drs_stitch_finalize": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "drs_softmax_accumulate": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "drs_scale_f64": (_i, [_p, _i, _d, _p]),
+    # ---- step level (csrc/engine.hip)
+    "drs_net_create": (_i, [C.c_char_p, _i, _i, _f, _i, _i, _i, _f, C.POINTER(_p)]),
+    "drs_net_destroy": (None, [_p]),
+    "drs_net_num_buffers": (_i, [_p]),
+    "drs_net_buffer_info": (_i, [_p, _i, C.c_char_p, _i, C.POINTER(_sz), C.POINTER(_i)]),
+    "drs_net_bind": (_i, [_p, C.c_char_p, _p, _sz]),
+    "drs_net_buffer": (_i, [_p, C.c_char_p, C.POINTER(_p), C.POINTER(_sz)]),
+    "drs_net_layout": (_i, [_p, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "drs_net_num_variables": (_i, [_p]),
+    "drs_net_variable_info": (_i, [_p, _i, C.c_char_p, _i, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_i), C.POINTER(_i)]),
+    "drs_params_get": (_i, [_p, C.c_char_p, C.c_char_p, _p, _sz, _p]),
+    "drs_params_set": (_i, [_p, C.c_char_p, C.c_char_p, _p, _sz, _p]),
+    "drs_grad_buffer": (_i, [_p, C.POINTER(_p), C.POINTER(_sz)]),
+    "drs_net_global_step": (C.c_longlong, [_p, C.c_longlong]),
+    "drs_net_learning_rate": (_f, [_p, _f]),
+    "drs_net_set_comm": (_i, [_p, _i, _i, _p, _p, _p]),
+    "drs_train_step": (_i, [_p, _i, _i, _f, _i, _d, _p]),
+    "drs_forward": (_i, [_p, _i, _i, _i, _i, _p]),
+    "drs_apply_update": (_i, [_p, _f, _p]),
+    "drs_net_timing": (_i, [_p, _i]),
+    "drs_net_num_timing_kinds": (_i, []),
+    "drs_net_timing_summary": (_i, [_p, _i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_d), C.POINTER(_d)]),
 }
+# callback types of drs_net_set_comm
+ALLREDUCE_FN = C.CFUNCTYPE(_i, _p, _p, _sz, _i, _i, _p)
+WAIT_FN = C.CFUNCTYPE(_i, _p, _i, _p)
+WANT_LOGITS, WITH_LABELS, USE_ACC_MASK, USE_LOSS_MASK, NO_UPDATE = 1, 2, 4, 8, 16
 
 
 class DrsError(RuntimeError):

@@ -829,6 +829,11 @@ __global__ void sum_f64_kernel(const double* __restrict__ in, int n, double* __r
   if (threadIdx.x == 0) out[0] = sh[0];
 }
 
+__global__ void scale_f64_kernel(double* __restrict__ x, int n, double s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= s;
+}
+
 // 0.5 * sum(w^2) over [0, n): per-workgroup partials in fp64 (tf.nn.l2_loss, isprs:648)
 __global__ void l2_partial_kernel(const float* __restrict__ w, size_t n, double* __restrict__ partial) {
   __shared__ double sh[256];
@@ -1071,6 +1076,12 @@ int drs_rows_reduce_f32(const float* in, int nrows, int ncols, float* out, doubl
 int drs_sum_f64(const double* in, int n, double* out, void* stream) {
   if (!in || !out) return DRS_ERR_ARG;
   DRS_LAUNCH(sum_f64_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, in, n, out);
+  return DRS_LAUNCH_CHECK();
+}
+
+int drs_scale_f64(double* x, int n, double s, void* stream) {
+  if (!x || n < 1) return DRS_ERR_ARG;
+  DRS_LAUNCH(scale_f64_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, x, n, s);
   return DRS_LAUNCH_CHECK();
 }
 

@@ -1,0 +1,179 @@
+"""DilatedNet on the step-level C ABI (include/drs.h, csrc/engine.hip): one library call per `sess.run`.
+
+The net table, the variable layout and the launch order of a step live in the library (`drs_net_create`, `drs_train_step`,
+`drs_forward`); this class allocates the buffers the library lists (PyTorch-ROCm tensors: device memory and the stream are all
+PyTorch supplies), binds them, and hands the library an all-reduce callback for data parallelism (torch.distributed over RCCL).
+Everything else -- feeding, variable access by TensorFlow scope name, checkpoints, the loops -- is inherited from the op-level
+mirror `net.DilatedNet`, which keeps the per-op launch sequence in Python and is held bitwise equal to this class by
+tests/test_gpu_engine.py.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .net import DilatedNet, KernelTimer
+
+_DTYPES = {0: torch.float32, 1: torch.float64, 2: torch.uint8, 3: torch.int32}
+
+
+class EngineTimer(KernelTimer):
+    """bench.py's per-kernel-family figures, measured by the library (HIP events around its launches)."""
+
+    def __init__(self, net):
+        KernelTimer.__init__(self)
+        self.net = net
+
+    def summary(self):
+        out = {}
+        name = C.create_string_buffer(64)
+        n, ms, work = C.c_int(), C.c_double(), C.c_double()
+        for k in range(_lib.query("drs_net_num_timing_kinds")):
+            _lib.call("drs_net_timing_summary", self.net.h, k, name, 64, C.byref(n), C.byref(ms), C.byref(work))
+            if n.value:
+                out[name.value.decode()] = dict(launches=n.value, ms=ms.value, work=work.value)
+        return out
+
+
+class EngineNet(DilatedNet):
+    h = None
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc_params(self):
+        """create the library-side net and every buffer it lists; the flat parameter / gradient / momentum / statistics buffers are
+        among them"""
+        if self.ns:
+            raise ValueError("the step-level library runs the exact-fp32 arithmetic; split-bf16 is the op-level path (engine=False)")
+        hp = C.c_void_p()
+        _lib.call("drs_net_create", self.plan.net_type.encode(), self.plan.channels, self.plan.K, self.wd, self.b_max, self.s_max, self.bessel,
+                  float(self.lr_decay_factor), C.byref(hp))
+        self.h = hp
+        self._bufs = {}
+        name, nb, dt = C.create_string_buffer(64), C.c_size_t(), C.c_int()
+        for i in range(_lib.query("drs_net_num_buffers", self.h)):
+            _lib.call("drs_net_buffer_info", self.h, i, name, 64, C.byref(nb), C.byref(dt))
+            dtype = _DTYPES[dt.value]
+            t = torch.zeros(nb.value // torch.empty(0, dtype=dtype).element_size(), dtype=dtype, device=self.dev)
+            self._bufs[name.value.decode()] = t
+            _lib.call("drs_net_bind", self.h, name.value, t.data_ptr(), nb.value)
+        b = self._bufs
+        self.params, self.grads, self.mom, self.bn = b["params"], b["grads"], b["momentum"], b["bn"]
+        # the library's layout must be the one nets.Plan describes (names, offsets): both are derived from the same tables
+        np_, nd, nbn, nl, c0, p0 = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_int(), C.c_int(), C.c_int()
+        _lib.call("drs_net_layout", self.h, C.byref(np_), C.byref(nd), C.byref(nbn), C.byref(nl), C.byref(c0), C.byref(p0))
+        p = self.plan
+        assert (np_.value, nd.value, nbn.value, nl.value) == (p.n_params, p.n_decay, p.n_bn, len(p.layers)), "library / nets.Plan layout mismatch"
+        assert (c0.value, p0.value) == p.buffers["x0"]
+        self._gs_pending = getattr(self, "_gs_pending", 0)
+        _lib.query("drs_net_global_step", self.h, int(self._gs_pending))
+        if self.comm.world > 1:
+            self._install_comm()
+
+    def _alloc(self):
+        """aliases of the library's buffers under the op-level attribute names (tests, feeding and the loops read them)"""
+        b, p = self._bufs, self.plan
+        self.abuf = {n: b["act:" + n] for n in p.buffers}
+        self.gbuf = {n: b["gact:" + n] for n in p.buffers if n != "x0"}
+        self.x0 = self.abuf["x0"]
+        nl = len(p.layers)
+        self.z = [b["z%d" % i] for i in range(nl)]
+        self.idx = [b.get("idx%d" % i) for i in range(nl)]
+        self.mean_rstd = [b["mean_rstd%d" % i] for i in range(nl)]
+        for n in ("sums", "partial", "gxh", "gz", "slab", "w0pad", "dw_partial", "db_partial", "loss_partial", "scalars", "logits", "pred", "conf",
+                  "labels", "acc_mask", "loss_mask"):
+            setattr(self, n, b[n])
+        self.acc_mask.fill_(1)
+        self.loss_mask.fill_(1)
+
+    def workspace_bytes(self):
+        return sum(t.numel() * t.element_size() for t in self._bufs.values())
+
+    def __del__(self):
+        try:
+            if self.h is not None and _lib._lib is not None:
+                _lib.load().drs_net_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ data parallelism: the library's all-reduce callback
+    def _install_comm(self):
+        spans = sorted((t.data_ptr(), t.data_ptr() + t.numel() * t.element_size(), t) for t in self._bufs.values())
+        self._works = {}
+        self._next_handle = 0
+
+        def view(ptr, count):
+            for lo, hi, t in spans:
+                if lo <= ptr < hi:
+                    off = (ptr - lo) // t.element_size()
+                    return t[off:off + count]
+            raise ValueError("all-reduce of memory outside the bound buffers")
+
+        def allreduce(user, ptr, count, dtype, is_async, stream):
+            try:
+                v = view(ptr, count)
+                if is_async:
+                    hnd = self._next_handle
+                    self._next_handle = (hnd + 1) % (1 << 30)
+                    self._works[hnd] = self.comm.all_reduce_sum_async(v)
+                    return hnd
+                self.comm.all_reduce_sum(v)
+                return 0
+            except Exception as e:      # nothing may propagate into the library
+                print("drs all-reduce callback failed:", repr(e))
+                return -1
+
+        def wait(user, hnd, stream):
+            try:
+                self.comm.wait([self._works.pop(hnd, None)])
+                return 0
+            except Exception as e:
+                print("drs wait callback failed:", repr(e))
+                return -1
+        self._cb = (_lib.ALLREDUCE_FN(allreduce), _lib.WAIT_FN(wait))       # kept alive with the net
+        _lib.call("drs_net_set_comm", self.h, self.comm.world, self.comm.rank, C.cast(self._cb[0], C.c_void_p), C.cast(self._cb[1], C.c_void_p), None)
+
+    # ------------------------------------------------------------------ state the library owns
+    @property
+    def global_step(self):
+        return int(_lib.query("drs_net_global_step", self.h, -1)) if self.h is not None else self._gs_pending
+
+    @global_step.setter
+    def global_step(self, v):
+        if self.h is None:
+            self._gs_pending = int(v)
+        else:
+            _lib.query("drs_net_global_step", self.h, int(v))
+
+    @property
+    def timer(self):
+        return self.__dict__.get("_timer")
+
+    @timer.setter
+    def timer(self, v):
+        if self.h is not None:
+            _lib.call("drs_net_timing", self.h, 0 if v is None else 1)
+        self.__dict__["_timer"] = None if v is None else EngineTimer(self)
+
+    def learning_rate(self, lr0):
+        return float(_lib.query("drs_net_learning_rate", self.h, float(lr0)))
+
+    # ------------------------------------------------------------------ the three sess.run shapes
+    def forward(self, B, S, want_logits=True, labels=False, acc_mask=False, ignore_label=-1):
+        self._check(B, S)
+        flags = (_lib.WANT_LOGITS if want_logits else 0) | (_lib.WITH_LABELS if labels else 0) | (_lib.USE_ACC_MASK if acc_mask else 0)
+        _lib.call("drs_forward", self.h, B, S, flags, int(ignore_label), self._stream())
+        M, K = B * S * S, self.plan.K
+        return self.pred[:M].view(B, S, S), (self.logits[:M * K].view(B, S, S, K) if want_logits else None)
+
+    def train_step(self, B, S, lr0, use_loss_mask=False, use_acc_mask=True, global_pixels=None, apply_update=True, want_logits=False):
+        self._check(B, S)
+        flags = ((_lib.USE_LOSS_MASK if use_loss_mask else 0) | (_lib.USE_ACC_MASK if use_acc_mask else 0) | (0 if apply_update else _lib.NO_UPDATE)
+                 | (_lib.WANT_LOGITS if want_logits else 0))
+        _lib.call("drs_train_step", self.h, B, S, float(lr0), flags, float(global_pixels) if global_pixels is not None else 0.0, self._stream())
+        M, K = B * S * S, self.plan.K
+        return dict(loss_parts=self.scalars[:2], pred=self.pred[:M].view(B, S, S), conf=self.conf.view(K, K))
+
+    def apply_update(self, lr0):
+        _lib.call("drs_apply_update", self.h, float(lr0), self._stream())

@@ -14,6 +14,7 @@ PyTorch supplies device memory, the stream and (through `comm`) the collectives;
 libdrs_hip.so (include/drs.h).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -86,8 +87,22 @@ class NoComm(object):
 
 
 class DilatedNet(object):
+    def __new__(cls, *args, **kw):
+        """`DilatedNet(...)` is the step-level net (engine.EngineNet: one library call per sess.run, csrc/engine.hip) for the
+        exact-fp32 arithmetic, and this op-level class -- the same launch sequence spelled out in Python -- with engine=False, with
+        DRS_OP_LEVEL=1 in the environment, or for the split-bf16 arithmetics."""
+        if cls is DilatedNet:
+            arith = kw.get("arith", args[11] if len(args) > 11 else "f32")
+            eng = kw.get("engine")
+            if eng is None:
+                eng = arith == "f32" and os.environ.get("DRS_OP_LEVEL") != "1"
+            if eng:
+                from .engine import EngineNet
+                return object.__new__(EngineNet)
+        return object.__new__(cls)
+
     def __init__(self, net_type, channels, num_classes, weight_decay, b_max, s_max, device="cuda:0", seed=42,
-                 comm=None, bessel_moving_var=True, lr_decay_factor=0.5, arith="f32"):
+                 comm=None, bessel_moving_var=True, lr_decay_factor=0.5, arith="f32", engine=None):
         _lib.load()                       # fail loudly here if the HIP library is absent
         if arith not in ARITH_TERMS:
             raise ValueError("arith must be one of %s" % sorted(ARITH_TERMS))
@@ -104,14 +119,17 @@ class DilatedNet(object):
         self.timer = None
         if self.b_max * self.s_max * self.s_max >= (1 << 24):
             raise ValueError("B*S*S must stay below 2^24")
+        self._alloc_params()
+        self._init_params(seed)
+        self._alloc()
+
+    def _alloc_params(self):
         p = self.plan
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.params = torch.zeros(p.n_params, **f32)
         self.grads = torch.zeros(p.n_params, **f32)
         self.mom = torch.zeros(p.n_params, **f32)
         self.bn = torch.zeros(p.n_bn, **f32)
-        self._init_params(seed)
-        self._alloc()
 
     # ------------------------------------------------------------------ parameters
     def _init_params(self, seed):

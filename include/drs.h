@@ -176,6 +176,7 @@ int drs_classifier_loss(const float* feat, int B, int S, int P, int ld, int coff
 /* fixed-order column sums (scratch: drs_colsum_scratch_doubles(ncols) doubles) / scalar sums used on the slabs above */
 int drs_rows_reduce_f32(const float* in, int nrows, int ncols, float* out, double* scratch, void* stream);
 int drs_sum_f64(const double* in, int n, double* out, void* stream);
+int drs_scale_f64(double* x, int n, double s, void* stream);      /* x[i] *= s (the 1/N of the mean cross-entropy) */
 /* tf.nn.l2_loss over the kernels (isprs:646-651): out[0] = 0.5 * sum w^2; scratch = 256 doubles */
 int drs_l2_loss(const float* w, size_t n, double* scratch, double* out, void* stream);
 
@@ -218,6 +219,66 @@ int drs_stitch_finalize(const float* prob, const unsigned int* occur, int h, int
 /* multi-scale evaluation (isprs:1347-1474, softmax isprs:38-43): acc[h][w][K] += softmax_k(prob / max(occur, 1));
  * the label map of the summed scales is drs_stitch_finalize(acc, ones, ...). */
 int drs_softmax_accumulate(const float* prob, const unsigned int* occur, int h, int w, int K, float* acc, void* stream);
+
+/* ==================================================================================================================
+ * Step level: the reference's three `sess.run` call shapes (isprs:1750-1752 train, :1274-1275 infer, :1588 validate) as entry
+ * points, for hosts that do not want to sequence the op-level calls above themselves (csrc/engine.hip).  A drs_net_t holds the
+ * net table selected by `net_type` (the reference's if-chain isprs:1660-1680, both spellings of Dilated8Pooling), the variable
+ * layout under TensorFlow's scope names and the launch order of a forward pass / a training step.  It owns no device memory:
+ *
+ *   drs_net_create(...)                                      -> handle
+ *   for i < drs_net_num_buffers(h): drs_net_buffer_info(h, i, name, cap, &bytes, &dtype); allocate; drs_net_bind(h, name, ptr, bytes)
+ *       (zero-fill "momentum"; fill "params" / "bn" through drs_params_set or directly: layout from drs_net_variable_info)
+ *   per step:  drs_crop_normalize(... out = buffer "act:x0" with P, ld from drs_net_layout, out_lab = "labels", out_mask = "acc_mask")
+ *              drs_train_step(h, B, S, lr0, flags, global_pixels, stream)     or     drs_forward(h, B, S, flags, ignore_label, stream)
+ *   results in the bound buffers: "scalars" (double[4]: [0] mean CE over all ranks, [1] 0.5*sum w^2; total loss = [0] + wd*[1]),
+ *       "pred" (u8 [B*S*S]), "logits" (f32 [B*S*S][K], with DRS_WANT_LOGITS), "conf" (i32 [K][K])
+ *
+ * One stream per handle, not re-entrant per handle, one handle per rank.  Status codes as above; nothing throws.
+ * Data parallelism: the sums that must run over all ranks (sync-BN statistics forward and backward, the gradient buffer in
+ * buckets, the CE sum, the confusion matrix) go through the callback given to drs_net_set_comm -- the driver owns the
+ * communicator (RCCL through torch.distributed in the Python mirror).
+ *   allreduce(user, dev_ptr, count, dtype (0 f32, 1 f64, 3 i32), async, stream) -> handle >= 0, or < 0 on failure; in-place sum;
+ *       async = 1: may return before the sum is done, the library then calls wait(user, handle, stream) before it reads the data;
+ *       async = 0: the sum must be ordered before later work on `stream`.
+ */
+typedef struct drs_net drs_net_t;
+typedef int (*drs_allreduce_fn)(void* user, void* dev_ptr, size_t count, int dtype, int async, void* stream);
+typedef int (*drs_wait_fn)(void* user, int handle, void* stream);
+#define DRS_WANT_LOGITS 1     /* also write the [B*S*S][K] logits */
+#define DRS_WITH_LABELS 2     /* drs_forward: add the confusion matrix of (labels, pred) into "conf" */
+#define DRS_USE_ACC_MASK 4    /* gate the confusion matrix by "acc_mask" (augmentation validity / void pixels) */
+#define DRS_USE_LOSS_MASK 8   /* drs_train_step: only pixels with loss_mask != 0 enter the loss (contest:881-901) */
+#define DRS_NO_UPDATE 16      /* drs_train_step: leave the gradients in "grads", do not apply the momentum update */
+
+int drs_net_create(const char* net_type, int channels, int num_classes, float weight_decay, int b_max, int s_max, int bessel_moving_var,
+                   float lr_decay_factor, drs_net_t** out);
+void drs_net_destroy(drs_net_t* net);
+int drs_net_num_buffers(const drs_net_t* net);
+int drs_net_buffer_info(const drs_net_t* net, int index, char* name, int name_cap, size_t* bytes, int* dtype);   /* dtype: 0 f32, 1 f64, 2 u8, 3 i32 */
+int drs_net_bind(drs_net_t* net, const char* name, void* dev_ptr, size_t bytes);
+int drs_net_buffer(drs_net_t* net, const char* name, void** dev_ptr, size_t* bytes);
+int drs_net_layout(const drs_net_t* net, size_t* n_params, size_t* n_decay, size_t* n_bn, int* n_layers, int* x0_channels, int* x0_halo);
+/* variables under their TensorFlow scope names (`conv1/weights`, `conv1/biases`, `conv1/moving_mean`, `conv1/moving_variance`,
+ * `conv_classifier/weights`, ...: what tf.train.Saver stores, isprs:1693-1695): offset / count in floats inside "params" (and
+ * "grads", "momentum") or, with *in_bn = 1, inside "bn"; shape4 = HWIO for kernels */
+int drs_net_num_variables(const drs_net_t* net);
+int drs_net_variable_info(const drs_net_t* net, int index, char* name, int name_cap, size_t* offset, size_t* count, int* shape4, int* in_bn);
+/* copy one variable (slot NULL) or its optimizer accumulator (slot "Momentum") to / from HOST memory; waits for the copy */
+int drs_params_get(drs_net_t* net, const char* name, const char* slot, float* host_dst, size_t count, void* stream);
+int drs_params_set(drs_net_t* net, const char* name, const char* slot, const float* host_src, size_t count, void* stream);
+/* the flat fp32 gradient buffer the RCCL all-reduce runs on (= buffer "grads") */
+int drs_grad_buffer(drs_net_t* net, float** dev_ptr, size_t* count);
+long long drs_net_global_step(drs_net_t* net, long long set_to);      /* set_to < 0: read only (`main_global_step`, isprs:1685) */
+float drs_net_learning_rate(const drs_net_t* net, float lr0);         /* exponential_decay(lr0, global_step, 50000, factor, staircase) */
+int drs_net_set_comm(drs_net_t* net, int world, int rank, drs_allreduce_fn allreduce, drs_wait_fn wait, void* user);
+int drs_train_step(drs_net_t* net, int B, int S, float lr0, int flags, double global_pixels, void* stream);
+int drs_forward(drs_net_t* net, int B, int S, int flags, int ignore_label, void* stream);
+int drs_apply_update(drs_net_t* net, float lr0, void* stream);        /* the update alone (after DRS_NO_UPDATE) */
+/* per-kernel-family HIP-event timing of the launches of a step (bench.py's roofline figures); off by default */
+int drs_net_timing(drs_net_t* net, int enable);
+int drs_net_num_timing_kinds(void);
+int drs_net_timing_summary(drs_net_t* net, int kind, char* name, int name_cap, int* launches, double* ms, double* work);
 
 #ifdef __cplusplus
 }
