@@ -62,53 +62,46 @@ def pmc_traffic(arith):
         return None
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The reference step restated with PyTorch-CPU fp32 ops (oracle/torch_ref.py) + the reference's host pipeline
-    (numpy crop, normalise of bands 0..2, vectorised confusion matrix), on this host's cores."""
+def cpu_baseline(batch=64, warmup=2, timed=5):
+    """The reference step restated with PyTorch-CPU fp32 ops (oracle/torch_ref.py) + the reference's host pipeline (numpy crop /
+    rotate / noise / flip, normalise of bands 0..2, confusion matrix), on this host's cores, as SURVEY.md 8(d) specifies it: the
+    bench's own workload (same net, 64x64x5 patches of the same 2048 x 2048 synthetic tile, same instances), `warmup` + `timed`
+    steps, every core the process is allowed (affinity), median step; plus a 1-thread figure.  The batch is 64 rather than the
+    GPU line's 128 to keep the default run within minutes (a CPU step is seconds long and scales linearly in the batch); the
+    1-thread figure uses one step of 8 patches for the same reason.  Both are stated in `sample`."""
     from oracle.torch_ref import TorchNet
     from oracle import host_ref as H
+    from oracle.tf_ops import OracleNet
     from drs_amd.synthetic import make_tile, grid_instances
     try:
-        avail = len(os.sched_getaffinity(0))
+        ncores = len(os.sched_getaffinity(0))
     except AttributeError:
-        avail = os.cpu_count() or 1
-    ncores = max(1, min(avail, 16))       # the GPU box gives one GPU a 16-core share of the host
+        ncores = os.cpu_count() or 1
     torch.set_num_threads(ncores)
-    B = 8
-    tile, lab = make_tile(512, 512, CHANNELS, CLASSES, seed=1234)
-    inst = grid_instances(512, 512, PATCH, 25, B * 8, seed=0)
-    mean, std = [0.5, 0.5, 0.5, 0, 0], [0.1, 0.1, 0.1, 1, 1]
-    from oracle.tf_ops import OracleNet
+    tile, lab = make_tile(TILE, TILE, CHANNELS, CLASSES, seed=1234)
+    inst = grid_instances(TILE, TILE, PATCH, 25, GLOBAL_BATCH * 100, seed=0)
+    mean = tile[:, :, :3].mean(axis=(0, 1)).tolist() + [0, 0]
+    std = tile[:, :, :3].std(axis=(0, 1)).tolist() + [1, 1]
     o = OracleNet(NET, CHANNELS, CLASSES, dtype=np.float32, seed=42)
     net = TorchNet(NET, CHANNELS, CLASSES, params=o.p, dtype=torch.float32)
     track = np.zeros((CLASSES, CLASSES), dtype=np.uint32)
-    times = []
     np.random.seed(0)
-    t_start = time.time()
-    step = 0
-    while True:
-        rows = inst[(step * B) % len(inst):(step * B) % len(inst) + B]
+
+    def step(i, B):
+        rows = inst[(i * B) % (len(inst) - B):(i * B) % (len(inst) - B) + B]
         t0 = time.time()
         x, y, m = H.dynamically_create_patches([tile], [lab], rows, PATCH, is_train=True)
         H.normalize_images(x, mean, std)
         _, pred = net.train_step(x.astype(np.float32), y, LR, WD)
         H.calc_accuracy_by_crop(y, pred, track, m, CLASSES)
-        dt = time.time() - t0
-        if step > 0:
-            times.append(dt)
-        step += 1
-        if step >= 2 and (time.time() - t_start > seconds_budget or len(times) >= 5):
-            break
+        return time.time() - t0
+    for i in range(warmup):
+        step(i, batch)
+    times = [step(warmup + i, batch) for i in range(timed)]
     med = float(np.median(times))
-    # one-thread figure (SURVEY 8d): one more step of the same batch with a single intra-op thread
     torch.set_num_threads(1)
-    rows = inst[:B]
-    t0 = time.time()
-    x, y, m = H.dynamically_create_patches([tile], [lab], rows, PATCH, is_train=True)
-    H.normalize_images(x, mean, std)
-    _, pred = net.train_step(x.astype(np.float32), y, LR, WD)
-    H.calc_accuracy_by_crop(y, pred, track, m, CLASSES)
-    one = time.time() - t0
+    b1 = 8
+    one = step(0, b1)
     torch.set_num_threads(ncores)
     model = "unknown"
     try:
@@ -118,9 +111,44 @@ def cpu_baseline(seconds_budget=25.0):
                 break
     except OSError:
         pass
-    return dict(value=B / med, unit="patches/s", cores=ncores, kind="port", cpu_model=model, value_1_thread=round(B / one, 3),
-                sample="%d timed steps (1 warm-up) of batch %d, same net / 64x64x5 patches / host crop+augment+normalise+"
-                       "confusion; median step %.2f s; one further step with 1 thread %.2f s" % (len(times), B, med, one))
+    return dict(value=round(batch / med, 3), unit="patches/s", cores=ncores, kind="port", cpu_model=model, value_1_thread=round(b1 / one, 3),
+                sample="%d timed steps after %d warm-up, batch %d (GPU line: 128), dilated_grsl_rate8 / 64x64x5 patches of the 2048x2048 "
+                       "tile, host crop+augment+normalise+confusion included; median step %.2f s (min %.2f, max %.2f); 1-thread figure: one "
+                       "step of %d patches, %.2f s" % (timed, warmup, batch, med, min(times), max(times), b1, one))
+
+
+def executed_fraction(plan, B, S):
+    """Share of the algorithmic multiply-adds of the forward / input-gradient launches that the kernels really issue: filter-tap
+    rows that meet only the zero halo for a whole M tile are skipped (drs_common.hpp live_tap_rows; taken from 4096 workgroups).
+    Mirrors that rule on the host: M tiles of 128 pixels, whole tap rows, a tile that crosses an image boundary keeps every row."""
+    M = B * S * S
+    tot = live = 0.0
+    for i, L in enumerate(plan.layers):
+        for pad, cout, on in ((L.pad_b, L.cout, True), (L.pad_a, L.cin, i > 0)):          # forward; input gradient (none for conv1), N = Cin
+            if not on:
+                continue
+            work = float(L.k * L.k * L.cin * L.cout)
+            skip = L.cin_k >= 32 and ((M + 127) // 128) * ((cout + 127) // 128) >= 4096
+            frac = 1.0
+            if skip:
+                rows = 0
+                ntile = (M + 127) // 128
+                for t in range(ntile):
+                    p0, p1 = t * 128, min(t * 128 + 127, M - 1)
+                    b0, b1 = p0 // (S * S), p1 // (S * S)
+                    y0, y1 = (p0 % (S * S)) // S, (p1 % (S * S)) // S
+                    if b0 != b1:
+                        y0, y1 = 0, S - 1
+                    a = pad - y1
+                    lo = (a + L.rate - 1) // L.rate if a > 0 else 0
+                    hi = min((S - 1 - y0 + pad) // L.rate + 1, L.k)
+                    if lo >= hi:
+                        lo, hi = 0, L.k
+                    rows += hi - lo
+                frac = rows / float(ntile * L.k)
+            tot += work
+            live += work * frac
+    return live / tot
 
 
 def main():
@@ -175,7 +203,6 @@ def main():
     np.random.seed(7)
     shuffle = np.asarray(random.sample(range(len(inst)), len(inst)))
     it = 0
-    epoch_cm = torch.zeros(CLASSES, CLASSES, dtype=torch.int64, device=dev)
 
     def one_step():
         nonlocal shuffle, it      # `net` is read from the enclosing scope at call time (the opt-in pass rebinds it)
@@ -185,9 +212,7 @@ def main():
         mine = P.Augmentation(B_local)
         mine.rot_on, mine.rot, mine.noise_on, mine.flip, mine.seed, mine.index0 = aug.rot_on[sl], aug.rot[sl], aug.noise_on[sl], aug.flip[sl], aug.seed, sl.start
         P.crop_to_net(net, pool, rows[sl], PATCH, mean, std, mine)
-        out = net.train_step(B_local, PATCH, LR)
-        epoch_cm.add_(out["conf"])
-        return out
+        return net.train_step(B_local, PATCH, LR)      # loss parts, predictions and the confusion matrix stay on the device
 
     if args.warmup == 0:
         one_step()          # with W = 0 still load the code objects / create the communicators outside the timed region
@@ -232,9 +257,15 @@ def main():
         ms = sum(summ[k]["ms"] for k in ("conv_fwd", "conv_dgrad") if k in summ)
         nl = sum(summ[k]["launches"] for k in ("conv_fwd", "conv_dgrad") if k in summ)
         ach = w / (ms * 1e-3) / 1e12
+        ex = executed_fraction(net.plan, B_local, PATCH)
         roofline = dict(kernel=ar["kernel"], bound="mfma", achieved=round(ach, 2), peak=ar["peak"],
                         unit="TFLOP/s", frac=round(ach / ar["peak"], 4), traffic=pmc_traffic(args.arith),
-                        launches=nl, avg_launch_ms=round(ms / nl, 4), algorithmic_gflop_per_launch=round(w / nl / 1e9, 2))
+                        launches=nl, avg_launch_ms=round(ms / nl, 4), algorithmic_gflop_per_launch=round(w / nl / 1e9, 2),
+                        # `frac` prices the ALGORITHMIC flops (every filter tap); taps that meet only the zero halo for a whole tile
+                        # are not multiplied, so the MFMA pipe issues `executed_share` of them: executed_frac = frac * executed_share
+                        executed_share=round(ex, 4), executed_frac=round(ach * ex / ar["peak"], 4),
+                        traffic_source="separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed under "
+                                       "profiles/ (tools/pmc_summary.py); not measurable inside this process")
         if ar["products"] > 1:      # the MFMA pipe executes `products` partial products per algorithmic multiply
             roofline["mfma_products_per_multiply"] = ar["products"]
             roofline["mfma_issued_tflops"] = round(ach * ar["products"], 1)

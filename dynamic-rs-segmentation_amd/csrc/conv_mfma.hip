@@ -459,6 +459,218 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
       }
 }
 
+// The same tile with its operands brought in by LDS-DMA (global_load_lds_dwordx4: global memory -> LDS without passing through
+// vector registers and without a ds_write pass) into a DOUBLE-BUFFERED image of two 16-pixel half-chunks (the bytes of one
+// 32-pixel stage): while half h is multiplied the DMA of half h+1 lands in the other stage; one barrier per half.  Measured on
+// wgrad_kernel (profiles/r02/wgrad_ablation.txt): with the address arithmetic gone, the register-staged loads still cost 6-13 %
+// and the LDS stores 3-4 % of the MFMA rate -- both disappear here.  A DMA wave-instruction writes 64 lanes x 16 B to consecutive
+// LDS bytes, so image rows are unpadded (TR / TO floats); the ds_read_b32 fragment reads of this kernel (32 consecutive floats
+// per lane group) are conflict-free on such rows.  Chunk walk, tile geometry, slab layout and the order of every sum are those
+// of wgrad_kernel: results are bitwise the same.
+template <int TR, int TO>
+__global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) void wgrad_dma_kernel(const WgradArgs a) {
+  constexpr int WR = TR >= 64 ? 2 : 1, WC = TO >= 64 ? 2 : 1;
+  constexpr int NW = WR * WC, NT = 64 * NW;
+  constexpr int WTR = TR / WR, WTO = TO / WC;
+  constexpr int TMr = WTR / 32, TNo = WTO / 32;
+  constexpr int BP = 32, HP = 16;             // pixels per chunk (walk / table unit) and per pipeline stage
+  constexpr int XPI = 256 / TR, GPI = 256 / TO;      // pixels one DMA wave-instruction covers (1 KiB / row bytes)
+  constexpr int IX = (HP / XPI) / NW, IG = (HP / GPI) / NW;   // DMA instructions per wave and half
+  static_assert(IX >= 1 && IG >= 1 && IX * NW * XPI == HP && IG * NW * GPI == HP, "tile / wave layout");
+  constexpr int XSTAGE = HP * TR, STAGE = HP * (TR + TO);     // floats
+
+  __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+  __shared__ uint32_t tabx[2][BP], tabg[2][BP];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int wr = wave / WC, wc = wave % WC;
+
+  const int ntile = a.ntr * a.nto;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = __builtin_amdgcn_readfirstlane(id / ntile);
+  const int tile = __builtin_amdgcn_readfirstlane(id % ntile);
+  const int R0 = (tile / a.nto) * TR;
+  const int o0 = (tile % a.nto) * TO;
+  const int rows_all = a.k * a.k * a.Cin;
+  // DMA lane roles: lane -> (pixel inside the instruction, 16-byte piece of the row)
+  const int xq = lane % (TR / 4), xp = lane / (TR / 4);
+  const int gq = lane % (TO / 4), gp = lane / (TO / 4);
+  const int myR = R0 + xq * 4;
+  const int myRc = myR < rows_all ? myR : 0;
+  const int tap = myRc / a.Cin, c0 = myRc % a.Cin;
+  const int u = tap / a.k, v = tap % a.k;
+  const int Sxp = a.S + 2 * a.Px, Sgp = a.S + 2 * a.Pg;
+  const uint32_t xconst = (uint32_t)((u * a.rate * Sxp + v * a.rate) * a.ld_x + a.coff_x + c0) * 4u;
+  const uint32_t gconst = (uint32_t)(a.coff_g + o0 + gq * 4) * 4u;
+  const bool affine = (a.S & 31) == 0;
+  // instruction i of this wave covers pixels (wave + NW * i) * XPI + xp of the half
+  uint32_t xoff[IX], goff[IG];
+  int xpix[IX], gpix[IG];
+#pragma unroll
+  for (int i = 0; i < IX; ++i) { xpix[i] = (wave + NW * i) * XPI + xp; xoff[i] = xconst + (affine ? (uint32_t)(xpix[i] * a.ld_x) * 4u : 0u); }
+#pragma unroll
+  for (int i = 0; i < IG; ++i) { gpix[i] = (wave + NW * i) * GPI + gp; goff[i] = gconst + (affine ? (uint32_t)(gpix[i] * a.ld_g) * 4u : 0u); }
+
+  f32x16 acc[TMr][TNo];
+#pragma unroll
+  for (int mi = 0; mi < TMr; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TNo; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int nchunks_total = (a.M + BP - 1) / BP;
+  const int cbeg = split * a.chunks_per_split;
+  int cend = cbeg + a.chunks_per_split;
+  cend = cend < nchunks_total ? cend : nchunks_total;
+  const int clast = (a.M & 31) ? nchunks_total - 1 : -1;
+  int live_lo, live_hi;
+  {
+    const int rlast = (R0 + TR < rows_all ? R0 + TR : rows_all) - 1;
+    live_pixel_range(R0, rlast, a.Cin, a.k, a.rate, a.pad, a.S, a.skip_halo, live_lo, live_hi);
+  }
+  ChunkWalk w;
+  w.init(cbeg, a.S, a.rcpS, a.rcpSS, live_lo, live_hi);
+
+  int pb = 0, py = 0, px = 0;
+  auto pixel_from_index = [&](int p) {
+    int rem;
+    divmod24(p < a.M ? p : a.M - 1, w.S2, a.rcpSS, pb, rem);
+    divmod24(rem, a.S, a.rcpS, py, px);
+  };
+  if (!affine && t < BP) pixel_from_index(w.c * BP + t);
+  auto fill_tables = [&](int slot, int stepped) {
+    if (affine || t >= BP || w.c >= cend) return;
+    const int p = w.c * BP + t;
+    if (stepped == 1 && p < a.M && a.S >= 11) {
+      px += 32;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) if (px >= a.S) { px -= a.S; ++py; }
+      if (py >= a.S) { py -= a.S; ++pb; }
+    } else if (stepped != 0) {
+      pixel_from_index(p);
+    }
+    tabx[slot][t] = (uint32_t)(((pb * Sxp + py + a.Px - a.pad) * Sxp + px + a.Px - a.pad) * a.ld_x) * 4u;
+    tabg[slot][t] = (uint32_t)(((pb * Sgp + py + a.Pg) * Sgp + px + a.Pg) * a.ld_g) * 4u;
+  };
+
+  const char* xbase = reinterpret_cast<const char*>(a.x);
+  const char* gbase = reinterpret_cast<const char*>(a.g);
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  // scalar bases of the chunk the walk stands on (S % 32 == 0), taken when the walk is there
+  auto chunk_bases = [&](const char*& xb, const char*& gb) {
+    xb = xbase + (size_t)(uint32_t)(((w.b * Sxp + w.y + a.Px - a.pad) * Sxp + w.x0 + a.Px - a.pad) * a.ld_x) * 4u;
+    gb = gbase + (size_t)(uint32_t)(((w.b * Sgp + w.y + a.Pg) * Sgp + w.x0 + a.Pg) * a.ld_g) * 4u;
+  };
+  // DMA of half `half` of a chunk (bases xb / gb, or table slot) into LDS stage `stage`
+  auto issue = [&](const char* xb, const char* gb, int slot, int half, int stage) {
+    float* sx = lds + stage * STAGE;
+    float* sg = sx + XSTAGE;
+    if (affine) {
+      const char* xh = xb + (size_t)(uint32_t)(half * HP * a.ld_x) * 4u;
+      const char* gh = gb + (size_t)(uint32_t)(half * HP * a.ld_g) * 4u;
+#pragma unroll
+      for (int i = 0; i < IX; ++i) {
+        uint32_t o = xoff[i]; asm volatile("" : "+v"(o));
+        __builtin_amdgcn_global_load_lds(xh + o, (lds_ptr)(sx + (wave + NW * i) * 256), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < IG; ++i) {
+        uint32_t o = goff[i]; asm volatile("" : "+v"(o));
+        __builtin_amdgcn_global_load_lds(gh + o, (lds_ptr)(sg + (wave + NW * i) * 256), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < IX; ++i)
+        __builtin_amdgcn_global_load_lds(xbase + (tabx[slot][half * HP + xpix[i]] + xoff[i]), (lds_ptr)(sx + (wave + NW * i) * 256), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < IG; ++i)
+        __builtin_amdgcn_global_load_lds(gbase + (tabg[slot][half * HP + gpix[i]] + goff[i]), (lds_ptr)(sg + (wave + NW * i) * 256), 16, 0, 0);
+    }
+  };
+  // pixels past the end (only in the last chunk) were fetched from a clamped address: their G rows must read as zero
+  auto zero_tail = [&](int chunk, int half, int stage) {
+    if (chunk != clast) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float* sg = lds + stage * STAGE + XSTAGE;
+    for (int e = t; e < HP * TO; e += NT)
+      if (chunk * BP + half * HP + e / TO >= a.M) sg[e] = 0.f;
+  };
+  const int xr = wr * WTR + li, gc = wc * WTO + li;
+  auto compute = [&](int stage) {
+    const float* Xs = lds + stage * STAGE;
+    const float* Gs = Xs + XSTAGE;
+    float af[2][TMr], bf[2][TNo];
+#pragma unroll
+    for (int mi = 0; mi < TMr; ++mi) af[0][mi] = Xs[h * TR + xr + mi * 32];
+#pragma unroll
+    for (int ni = 0; ni < TNo; ++ni) bf[0][ni] = Gs[h * TO + gc + ni * 32];
+#pragma unroll
+    for (int s = 0; s < HP / 2; ++s) {
+      if (s + 1 < HP / 2) {
+#pragma unroll
+        for (int mi = 0; mi < TMr; ++mi) af[(s + 1) & 1][mi] = Xs[(2 * s + 2 + h) * TR + xr + mi * 32];
+#pragma unroll
+        for (int ni = 0; ni < TNo; ++ni) bf[(s + 1) & 1][ni] = Gs[(2 * s + 2 + h) * TO + gc + ni * 32];
+        __builtin_amdgcn_sched_group_barrier(0x100, TMr + TNo, 0);
+      }
+#pragma unroll
+      for (int mi = 0; mi < TMr; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TNo; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][mi], bf[s & 1][ni], acc[mi][ni], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x8, TMr * TNo, 0);
+    }
+  };
+
+  int cA = w.c;
+  if (cA < cend) {
+    const char *xbA, *gbA, *xbB = xbase, *gbB = gbase;
+    chunk_bases(xbA, gbA);
+    fill_tables(0, 0);
+    if (!affine) __syncthreads();
+    issue(xbA, gbA, 0, 0, 0);                    // chunk A, first half -> stage 0
+    int stepped = w.advance();                   // the walk now stands on B
+    int cB = w.c;
+    chunk_bases(xbB, gbB);
+    fill_tables(1, stepped);
+    zero_tail(cA, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA has landed; the barrier then publishes everybody's
+    __syncthreads();
+    for (int it = 0; cA < cend; ++it) {
+      issue(xbA, gbA, it & 1, 1, 1);             // second half of A -> stage 1, lands while stage 0 is multiplied
+      compute(0);
+      zero_tail(cA, 1, 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (cB < cend) issue(xbB, gbB, (it + 1) & 1, 0, 0);      // first half of B -> stage 0 (every wave is done with it)
+      stepped = w.advance();                     // ... and on C, whose table goes into the slot A's table was in
+      compute(1);
+      fill_tables(it & 1, stepped);
+      if (cB < cend) zero_tail(cB, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cA = cB; xbA = xbB; gbA = gbB;
+      cB = w.c;
+      chunk_bases(xbB, gbB);
+    }
+  }
+  const size_t rows_total = (size_t)a.k * a.k * a.Cin;
+  float* dst = a.slab + ((size_t)split * rows_total + R0) * a.Cout + o0;
+#pragma unroll
+  for (int mi = 0; mi < TMr; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TNo; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wr * WTR + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int col = wc * WTO + ni * 32 + li;
+        if (R0 + row < rows_all) dst[(size_t)row * a.Cout + col] = acc[mi][ni][r];
+      }
+}
+
 // grad[tap][c][o] = sum over splits (fixed order) of slab[split][tap][c (of cin_pad)][o], c < cin_real
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, int nsplit, int taps,
                                     int cin_pad, int cin_real, int cout) {
@@ -516,10 +728,13 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
   return DRS_LAUNCH_CHECK();
 }
 
+int g_wgrad_variant = 1;     // development switch (drs_debug_wgrad_variant): 0 = register-staged tiles, 1 = LDS-DMA double-buffered halves
+
 template <int TR, int TO>
 int launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t st) {
   constexpr int NT = 64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1);
-  DRS_LAUNCH((wgrad_kernel<TR, TO>), dim3(nsplit * a.ntr * a.nto), dim3(NT), 0, st, a);
+  if (g_wgrad_variant == 0) DRS_LAUNCH((wgrad_kernel<TR, TO>), dim3(nsplit * a.ntr * a.nto), dim3(NT), 0, st, a);
+  else DRS_LAUNCH((wgrad_dma_kernel<TR, TO>), dim3(nsplit * a.ntr * a.nto), dim3(NT), 0, st, a);
   return DRS_LAUNCH_CHECK();
 }
 
@@ -550,6 +765,8 @@ extern "C" {
 int drs_debug_skip_taps(int v) { const int old = drs_g_skip_halo_taps; if (v >= 0) drs_g_skip_halo_taps = v; return old; }
 
 int drs_debug_wgrad_target(int v) { const int old = g_wgrad_target; if (v > 0) g_wgrad_target = v; return old; }
+
+int drs_debug_wgrad_variant(int v) { const int old = g_wgrad_variant; if (v >= 0) g_wgrad_variant = v; return old; }
 
 // M-tile height the forward/dgrad kernel uses for this Cout (= rows per BN-statistics slab row)
 int drs_conv_mtile(int cout) { return pick_tile(cout) >= 64 ? 128 : 256; }

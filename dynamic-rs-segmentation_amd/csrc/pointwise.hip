@@ -735,7 +735,7 @@ __global__ __launch_bounds__(256) void classifier_loss_kernel(const ClsArgs a) {
     if (!a.labels) return;
     const int y = a.labels[p];
     if (lane == 0 && a.conf && (!a.acc_mask || a.acc_mask[p]) && y < K) atomicAdd(&confs[y * KM + am], 1u);
-    const bool in_loss = !a.loss_mask || a.loss_mask[p];
+    const bool in_loss = (!a.loss_mask || a.loss_mask[p]) && y < K;      // a label outside [0, K) (TF would raise) never trains the net
     float ex[KM], se = 0.f;
 #pragma unroll
     for (int k = 0; k < KM; ++k) { ex[k] = k < K ? __expf(lg[k] - mx) : 0.f; se += ex[k]; }

@@ -125,6 +125,16 @@ def validation(net, test_pool, selected_testing_instances, mean_full, std_full, 
     return cm, n * crop_size * crop_size
 
 
+def check_training_labels(pool, num_classes, void_label=None):
+    """tf.nn.sparse_softmax_cross_entropy_with_logits raises on a label outside [0, K) (isprs:1093); a label map that holds one
+    (an unknown colour from datasets.convert_to_class becomes 255 in the uint8 pool) must not silently enter the loss."""
+    bad = pool.labels >= num_classes
+    if void_label is not None:
+        bad &= pool.labels != void_label
+    if bool(bad.any()):
+        raise ValueError("training labels hold class ids outside [0, %d): %s" % (num_classes, torch.unique(pool.labels[bad]).tolist()[:8]))
+
+
 # ------------------------------------------------------------------------------------------------- data parallelism
 def sync_rng(comm):
     """Data parallelism runs the same host code on every rank and relies on identical `random` / `numpy.random` streams (size
@@ -205,6 +215,7 @@ def train(training_data, training_labels, training_class_distribution, training_
                      lr_decay_factor=lr_decay_factor)
     train_pool = P.TilePool(training_data, training_labels, device, dtype=tile_dtype)
     test_pool = P.TilePool(testing_data, testing_labels, device, dtype=tile_dtype)
+    check_training_labels(train_pool, num_classes)
 
     shuffle = np.asarray(random.sample(range(total_length), total_length))
     epoch_counter = 1
@@ -325,6 +336,8 @@ def predict_tile(net, pool, map_index, crop_size, batch_size, mean_full, std_ful
     stride = int(math.floor(crop_size / 2.0))
     n_h, n_w = P.window_counts(h, w, crop_size, stride)
     total = n_h * n_w
+    if comm.world > 1 and not return_sums and flavour == "isprs" and n_h >= comm.world:
+        return _predict_tile_bands(net, pool, map_index, crop_size, batch_size, mean_full, std_full, comm), total
     prob = torch.zeros(h * w * K, dtype=torch.float32, device=net.dev)
     occur = torch.zeros(h * w, dtype=torch.int32, device=net.dev)
     bs = min(batch_size, net.b_max)
@@ -341,7 +354,7 @@ def predict_tile(net, pool, map_index, crop_size, batch_size, mean_full, std_ful
         _, logits = net.forward(len(pos), crop_size, want_logits=True)
         _lib.call("drs_stitch_accumulate", prob.data_ptr(), occur.data_ptr(), logits.data_ptr(), h, w, K, crop_size, stride,
                   P.window_start(h, w, crop_size, stride, i, bs, flavour), len(pos), st)
-    if comm.world > 1:
+    if comm.world > 1:          # (the multi-scale caller needs the whole sums; the plain path below exchanges bands instead)
         comm.all_reduce_sum(prob)
         comm.all_reduce_sum(occur)
     if return_sums:
@@ -349,6 +362,73 @@ def predict_tile(net, pool, map_index, crop_size, batch_size, mean_full, std_ful
     out = torch.zeros(h * w, dtype=torch.uint8, device=net.dev)
     _lib.call("drs_stitch_finalize", prob.data_ptr(), occur.data_ptr(), h, w, K, out.data_ptr(), st)
     return out.view(h, w), total
+
+
+def band_plan(h, crop_size, stride, n_h, world):
+    """Window rows per rank and the image rows they touch: rank r takes window rows [a[r], a[r+1]) (contiguous, as even as
+    possible); its band is image rows [top[r], bot[r]) (the last window row is shifted back to end at the border, isprs:366-375);
+    it OWNS rows [own[r], own[r+1]) of the final map, own[r] = top[r] (own[0] = 0, own[world] = h): what lies below its owned rows
+    inside its band is handed to the ranks that own those rows."""
+    a = [r * n_h // world for r in range(world + 1)]
+    x = lambda i: min(i * stride, h - crop_size)
+    top = [x(a[r]) for r in range(world)]
+    bot = [x(a[r + 1] - 1) + crop_size for r in range(world)]
+    own = [0] + top[1:] + [h]
+    return a, top, bot, own
+
+
+def _predict_tile_bands(net, pool, map_index, crop_size, batch_size, mean_full, std_full, comm):
+    """Sliding-window inference of one tile on several ranks: the window rows are cut into one contiguous band per
+    rank, every rank overlap-adds its windows into a band-sized accumulator ([rows of the band][w][K] instead of the whole
+    [h][w][K]), only the rows a band shares with the next ranks' territory are exchanged (one sum all-reduce of a buffer in which
+    every rank fills its own segment: (world-1) x (S - stride) rows instead of the whole map), each rank divides and arg-maxes the
+    rows it owns, and the uint8 label bands are gathered.  Sums are formed as (own windows in window order) + (lower ranks'
+    contributions in rank order): deterministic, and equal to the single-rank result up to the association of those float sums."""
+    from . import _lib
+    h, w = pool.h[map_index], pool.w[map_index]
+    K = net.plan.K
+    S = crop_size
+    stride = int(math.floor(S / 2.0))
+    n_h, n_w = P.window_counts(h, w, S, stride)
+    W, r = comm.world, comm.rank
+    a, top, bot, own = band_plan(h, S, stride, n_h, W)
+    rows = bot[r] - top[r]
+    prob = torch.zeros(rows * w * K, dtype=torch.float32, device=net.dev)
+    occur = torch.zeros(rows * w, dtype=torch.int32, device=net.dev)
+    st = net._stream()
+    bs = min(batch_size, net.b_max)
+    f_end = a[r + 1] * n_w
+    # the stitch kernel addresses absolute image rows: hand it the address row 0 would have
+    vprob, voccur = prob.data_ptr() - top[r] * w * K * 4, occur.data_ptr() - top[r] * w * 4
+    for f0 in range(a[r] * n_w, f_end, bs):
+        f = np.arange(f0, min(f0 + bs, f_end))
+        pos = np.stack([np.minimum((f // n_w) * stride, h - S), np.minimum((f % n_w) * stride, w - S)], axis=1).astype(np.int64)
+        inst = np.concatenate([np.full((len(pos), 1), map_index), pos], axis=1)
+        P.crop_to_net(net, pool, inst, S, mean_full, std_full)
+        _, logits = net.forward(len(pos), S, want_logits=True)
+        _lib.call("drs_stitch_accumulate", vprob, voccur, logits.data_ptr(), h, w, K, S, stride, int(f0), len(pos), st)
+    # exchange: segment q of the buffer = rank q's band rows below its owned rows, [own[q+1], bot[q])
+    seg = [max(0, bot[q] - own[q + 1]) for q in range(W)]
+    off = np.concatenate([[0], np.cumsum(seg)]).astype(np.int64)
+    xp = torch.zeros(int(off[-1]) * w * K, dtype=torch.float32, device=net.dev)
+    xo = torch.zeros(int(off[-1]) * w, dtype=torch.int32, device=net.dev)
+    if seg[r]:
+        lo = own[r + 1] - top[r]
+        xp[off[r] * w * K:off[r + 1] * w * K].copy_(prob[lo * w * K:(lo + seg[r]) * w * K])
+        xo[off[r] * w:off[r + 1] * w].copy_(occur[lo * w:(lo + seg[r]) * w])
+    comm.all_reduce_sum(xp)
+    comm.all_reduce_sum(xo)
+    for q in range(r):          # lower ranks' contributions to the rows this rank owns, in rank order
+        lo, hi = max(own[q + 1], own[r]), min(bot[q], own[r + 1])
+        if hi > lo:
+            src, dst = off[q] + (lo - own[q + 1]), lo - top[r]
+            prob[dst * w * K:(dst + hi - lo) * w * K] += xp[src * w * K:(src + hi - lo) * w * K]
+            occur[dst * w:(dst + hi - lo) * w] += xo[src * w:(src + hi - lo) * w]
+    out = torch.zeros(h * w, dtype=torch.uint8, device=net.dev)
+    n_own, d0 = own[r + 1] - own[r], own[r] - top[r]
+    _lib.call("drs_stitch_finalize", prob.data_ptr() + d0 * w * K * 4, occur.data_ptr() + d0 * w * 4, n_own, w, K, out.data_ptr() + own[r] * w, st)
+    comm.all_reduce_sum(out)    # every rank wrote only the rows it owns: the sum is the gather of the uint8 label bands
+    return out.view(h, w)
 
 
 def predict_tile_multiscale(net, pool, map_index, crop_sizes, batch_size, mean_full, std_full, comm=None):

@@ -103,6 +103,7 @@ def train(training_data, training_labels, test_data, test_labels, class_distribu
                      lr_decay_factor=0.1)                                            # coffee:1228, contest:1021
     train_pool = P.TilePool(training_data, [np.squeeze(l) for l in training_labels], device)
     test_pool = P.TilePool(test_data, [np.squeeze(l) for l in test_labels], device)
+    loops.check_training_labels(train_pool, num_classes, void_label if void_label >= 0 else None)
     shuffle = np.asarray(random.sample(range(total), total))
     current_iter = 1
     if current_model is not None and "model" in current_model:

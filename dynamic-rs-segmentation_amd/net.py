@@ -221,8 +221,9 @@ class DilatedNet(object):
         self.colsum_scratch = torch.zeros(_lib.query("drs_colsum_scratch_doubles", max(2 * cmax, p.c_last * p.K)), **f64)
         rows_fwd = max((M + self._mtile(i) - 1) // self._mtile(i) for i in range(len(p.layers)))
         # the slab's row count depends on the patch size through the kernel's tiling: size it for every S up to s_max
-        part = max(max(_lib.query("drs_bn_backward_rows", B, s, L.cout, 1 if self._is_max(i) else 0) * L.cout * 2
-                       for i, L in enumerate(p.layers)) for s in range(1, S + 1))
+        # (not monotonic in the batch either: every (b, s) a step may be called with)
+        part = max(_lib.query("drs_bn_backward_rows", b, s, L.cout, 1 if self._is_max(i) else 0) * L.cout * 2
+                   for i, L in enumerate(p.layers) for b in range(1, B + 1) for s in range(1, S + 1))
         self.partial = torch.zeros(max(rows_fwd * cmax * 2, part), **f32)
         if p.se:        # per SE block: the activated input, its spatial mean and the two excitation vectors (kept for backward)
             self.se_state = {}

@@ -155,3 +155,19 @@ def test_rng_and_cache_synchronisation_across_ranks(tmp_path):
     r0, r1 = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
     np.testing.assert_array_equal(r0, r1)
     assert os.path.isfile(tmp_path / "cache.npy") and not [f for f in os.listdir(tmp_path) if ".tmp" in f]
+
+
+def test_band_plan_covers_every_row_once():
+    """loops.band_plan: bands of consecutive ranks overlap (windows overlap by S - stride), owned row ranges partition [0, h)."""
+    from drs_amd import patches as P
+    from drs_amd.loops import band_plan
+    for h, S, W in [(6000, 64, 8), (200, 25, 3), (130, 64, 2), (70, 25, 4), (97, 25, 2), (1000, 85, 8)]:
+        st = S // 2
+        n_h, _ = P.window_counts(h, h, S, st)
+        a, top, bot, own = band_plan(h, S, st, n_h, W)
+        assert a[0] == 0 and a[-1] == n_h and all(a[i] < a[i + 1] for i in range(W))
+        assert own[0] == 0 and own[-1] == h and all(own[i] < own[i + 1] for i in range(W))
+        for r in range(W):
+            assert top[r] <= own[r] and bot[r] >= own[r + 1] and bot[r] <= h          # a rank's band holds every row it owns
+            rows = {min(i * st, h - S) for i in range(a[r], a[r + 1])}
+            assert min(rows) == top[r] and max(rows) + S == bot[r]

@@ -1,11 +1,14 @@
-"""-m gpu: BASELINE.json's closing requirement -- "pixel-accuracy parity on a held-out synthetic tile".
+"""-m gpu: BASELINE.json's closing requirement -- "pixel-accuracy parity on a held-out synthetic tile" -- on the net it names,
+dilated_grsl_rate8 (Dilated8Pooling, 5 bands, 6 classes).
+
 The same short training run (same initial weights, same patches, same schedule) on the HIP path and on the CPU oracle
-(oracle/torch_ref.py, fp32), then both models label a held-out tile by sliding window.  The two trajectories are not
-bit-identical (ReLU / pool decisions flip on near-ties), so the comparison is on what the north star
-names: the loss curve and the held-out pixel accuracy.  300 SGD steps are chaotic: implementations that differ only in the
-ORDER of an fp32 sum end up as measurably different models (observed held-out accuracies over the revisions of the classifier
-kernel and the three convolution arithmetics: 0.848 ... 0.903, CPU oracle 0.885), so the accuracy band is 0.05 while the loss
-curves are held to 5 %."""
+(oracle/torch_ref.py, fp32 PyTorch-CPU), then both models label a held-out tile by sliding window (isprs:1241-1284).
+SGD through eight batch-normalised layers is chaotic: two correct fp32 implementations that differ only in the ORDER of a sum
+drift apart after a few dozen steps, so one pair of runs says little.  The test therefore
+  * holds the START of the trajectory tightly (the first steps, before rounding differences are amplified), and
+  * repeats the run over several seeds (weights, batch order) on both sides and compares the two populations: the difference of
+    the mean held-out accuracies (and of the mean late losses) must lie inside a band set by the measured seed-to-seed spread.
+"""
 import numpy as np
 import pytest
 import torch
@@ -18,66 +21,73 @@ pytestmark = pytest.mark.gpu
 
 from gpu_util import DEV   # noqa: E402
 
+NET, CH, K, B, S, STEPS, LR, WD = "dilated_grsl_rate8", 5, 6, 6, 20, 120, 0.01, 0.0005
+SEEDS = (0, 1, 2)
 
-def test_heldout_pixel_accuracy_matches_cpu_oracle():
+
+def _run(seed, tile, lab, held, held_lab, mean, std):
     from drs_amd import loops, patches as P
     from drs_amd.net import DilatedNet
-    from drs_amd.synthetic import make_tile, grid_instances
-    net_type, ch, K, B, S, steps, lr, wd = "dilated_icpr_rate6_small", 5, 6, 8, 24, 300, 0.01, 0.0005
-    tile, lab = make_tile(160, 160, ch, K, seed=3, n_seeds=24, class_signal=0.35)
-    held, held_lab = make_tile(96, 96, ch, K, seed=4, n_seeds=12, class_signal=0.35)
-    mean, std = tile[:, :, :3].mean(axis=(0, 1)), tile[:, :, :3].std(axis=(0, 1))
-    inst = grid_instances(160, 160, S, 8, B * steps, seed=1)
-    # the exact-fp32 arithmetic and the two split-bf16 arithmetics of the convolutions, all from the same initial weights
-    ariths = ["f32", "bf16x3", "bf16x6"]
-    nets = [DilatedNet(net_type, ch, K, wd, b_max=B, s_max=S, device=DEV, seed=21, arith=a) for a in ariths]
-    d = nets[0]
-    o = T.OracleNet(net_type, ch, K, dtype=np.float32, seed=0)
+    from drs_amd.synthetic import grid_instances
+    inst = grid_instances(tile.shape[0], tile.shape[1], S, 8, B * STEPS, seed=100 + seed)
+    d = DilatedNet(NET, CH, K, WD, b_max=B, s_max=S, device=DEV, seed=21 + seed)
+    o = T.OracleNet(NET, CH, K, dtype=np.float32, seed=0)
     o.p = {n: d.get_variable(n) for n in d.variable_names()}
-    t = TorchNet(net_type, ch, K, params=o.p, dtype=torch.float32)
+    t = TorchNet(NET, CH, K, params=o.p, dtype=torch.float32)
     pool = P.TilePool([tile], [lab], DEV)
     loss_d, loss_t = [], []
-    loss_x = {a: [] for a in ariths[1:]}
-    for i in range(steps):
+    m5, s5 = list(mean) + [0, 0], list(std) + [1, 1]
+    for i in range(STEPS):
         rows = inst[i * B:(i + 1) * B]
         P.crop_to_net(d, pool, rows, S, mean, std)
-        out = d.train_step(B, S, lr)
-        loss_d.append(d.loss_value(out["loss_parts"]))
-        for a, dn in zip(ariths[1:], nets[1:]):
-            P.crop_to_net(dn, pool, rows, S, mean, std)
-            loss_x[a].append(dn.loss_value(dn.train_step(B, S, lr)["loss_parts"]))
+        loss_d.append(d.loss_value(d.train_step(B, S, LR)["loss_parts"]))
         x, y, _ = H.dynamically_create_patches([tile], [lab], rows, S, is_train=False)
         x = x.copy()
-        H.normalize_images(x, list(mean) + [0, 0], list(std) + [1, 1])
-        lt, _ = t.train_step(x.astype(np.float32), y, lr, wd)
-        loss_t.append(lt)
-    print("loss HIP  ", np.round(loss_d[::30], 4))
-    print("loss torch", np.round(loss_t[::30], 4))
-    for a in loss_x:
-        print("loss %-6s" % a, np.round(loss_x[a][::30], 4))
-        assert abs(loss_x[a][0] - loss_t[0]) < 1e-4 * loss_t[0]
-        assert abs(np.mean(loss_x[a][-5:]) - np.mean(loss_t[-5:])) < 0.05 * np.mean(loss_t[-5:])
-    assert np.mean(loss_d[-5:]) < 0.7 * loss_d[0]                          # it learns
-    assert abs(loss_d[0] - loss_t[0]) < 1e-4 * loss_t[0]                   # identical start
-    assert abs(np.mean(loss_d[-5:]) - np.mean(loss_t[-5:])) < 0.05 * np.mean(loss_t[-5:])
-    # held-out tile, sliding window at stride S/2 (isprs:1241-1284) on both
+        H.normalize_images(x, m5, s5)
+        loss_t.append(t.train_step(x.astype(np.float32), y, LR, WD)[0])
     hpool = P.TilePool([held], [held_lab], DEV)
     pred_d, _ = loops.predict_tile(d, hpool, 0, S, B, mean, std)
     st = H.stride_for(S)
-    nh, nw = H.window_counts(96, 96, S, st)
+    hh, hw = held_lab.shape
+    nh, nw = H.window_counts(hh, hw, S, st)
     batches = []
     for i in range(-(-nh * nw // B)):
         p, _, pos = H.create_patches_per_map(held, held_lab, S, st, i, B)
         p = p.copy()
-        H.normalize_images(p, list(mean) + [0, 0], list(std) + [1, 1])
+        H.normalize_images(p, m5, s5)
         batches.append((t.forward(p.astype(np.float32), False).detach().numpy(), pos))
-    _, _, pred_t = H.stitch_tile(96, 96, K, S, batches)
-    acc_d = float((pred_d.cpu().numpy() == held_lab).mean())
-    acc_t = float((pred_t == held_lab).mean())
-    print("held-out pixel accuracy: HIP %.4f  CPU oracle %.4f  (chance %.3f)" % (acc_d, acc_t, 1.0 / K))
-    assert acc_t > 2.0 / K and abs(acc_d - acc_t) < 0.05
-    for a, dn in zip(ariths[1:], nets[1:]):
-        pred_x, _ = loops.predict_tile(dn, hpool, 0, S, B, mean, std)
-        acc_x = float((pred_x.cpu().numpy() == held_lab).mean())
-        print("held-out pixel accuracy: HIP %s %.4f" % (a, acc_x))
-        assert abs(acc_x - acc_t) < 0.05
+    _, _, pred_t = H.stitch_tile(hh, hw, K, S, batches)
+    return (np.asarray(loss_d), np.asarray(loss_t), float((pred_d.cpu().numpy() == held_lab).mean()), float((pred_t == held_lab).mean()))
+
+
+def test_heldout_pixel_accuracy_matches_cpu_oracle_over_seeds():
+    from drs_amd.synthetic import make_tile
+    tile, lab = make_tile(160, 160, CH, K, seed=3, n_seeds=24, class_signal=0.6)
+    held, held_lab = make_tile(96, 96, CH, K, seed=4, n_seeds=12, class_signal=0.6)
+    mean, std = tile[:, :, :3].mean(axis=(0, 1)), tile[:, :, :3].std(axis=(0, 1))
+    acc_d, acc_t, late_d, late_t = [], [], [], []
+    for seed in SEEDS:
+        ld, lt, ad, at = _run(seed, tile, lab, held, held_lab, mean, std)
+        print("seed %d  loss HIP   %s" % (seed, np.round(ld[::10], 4)))
+        print("seed %d  loss torch %s" % (seed, np.round(lt[::10], 4)))
+        print("seed %d  held-out pixel accuracy: HIP %.4f  CPU oracle %.4f" % (seed, ad, at))
+        # the start of the trajectory, before the chaos: identical first loss, the next steps close
+        dev = np.abs(ld[:8] / lt[:8] - 1.0)
+        print("seed %d  |loss HIP / loss torch - 1| over the first steps: %s" % (seed, np.array2string(dev, precision=5)))
+        assert dev[0] < 1e-4 and dev[1:4].max() < 1e-2, dev
+        assert np.mean(ld[-20:]) < 0.6 * ld[0] and np.mean(lt[-20:]) < 0.6 * lt[0]          # both learn
+        acc_d.append(ad); acc_t.append(at)
+        late_d.append(np.mean(ld[-20:])); late_t.append(np.mean(lt[-20:]))
+    n = len(SEEDS)
+    acc_d, acc_t, late_d, late_t = map(np.asarray, (acc_d, acc_t, late_d, late_t))
+    se_acc = np.sqrt((acc_d.var(ddof=1) + acc_t.var(ddof=1)) / n)
+    se_loss = np.sqrt((late_d.var(ddof=1) + late_t.var(ddof=1)) / n)
+    print("held-out accuracy  HIP %.4f +- %.4f   CPU oracle %.4f +- %.4f   (chance %.3f; difference %.4f, standard error %.4f)"
+          % (acc_d.mean(), acc_d.std(ddof=1), acc_t.mean(), acc_t.std(ddof=1), 1.0 / K, acc_d.mean() - acc_t.mean(), se_acc))
+    print("late loss          HIP %.4f +- %.4f   CPU oracle %.4f +- %.4f   (difference %.4f, standard error %.4f)"
+          % (late_d.mean(), late_d.std(ddof=1), late_t.mean(), late_t.std(ddof=1), late_d.mean() - late_t.mean(), se_loss))
+    assert acc_t.mean() > 2.0 / K and acc_d.mean() > 2.0 / K
+    # the two populations agree: difference of means within 3 standard errors of the seed-to-seed spread (+ a 1 % floor so that
+    # an accidentally tiny spread cannot fail a correct implementation)
+    assert abs(acc_d.mean() - acc_t.mean()) <= 3.0 * se_acc + 0.01
+    assert abs(late_d.mean() - late_t.mean()) <= 3.0 * se_loss + 0.01 * late_t.mean()

@@ -124,3 +124,52 @@ def test_two_ranks_through_the_command_line_equal_one_process(tmp_path):
     np.testing.assert_array_equal(np.load(os.path.join(root2, "dataset_vaihingen.npy")), np.load(os.path.join(root1, "dataset_vaihingen.npy")))
     a, b = np.load(os.path.join(root2, "dp_params.npy")), net.params.cpu().numpy()
     assert float(np.abs(a - b).max() / np.abs(b).max()) < 5e-4          # same patches, sizes and augmentation; sums grouped differently
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# band-partitioned sliding-window inference: window rows cut into one band per rank, boundary rows exchanged,
+# uint8 label bands gathered -- against the single-process map.
+def _tile_for_bands():
+    from drs_amd.synthetic import make_tile
+    return make_tile(150, 97, 5, 6, seed=12, n_seeds=30)
+
+
+def _band_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from drs_amd import loops, patches as P
+    from drs_amd.dist import TorchComm
+    from drs_amd.net import DilatedNet
+    torch.cuda.set_device(0)
+    comm = TorchComm("gloo")
+    tile, lab = _tile_for_bands()
+    d = DilatedNet("dilated_grsl", 5, 6, 0.005, b_max=5, s_max=25, device="cuda:0", seed=4, comm=comm)
+    pool = P.TilePool([tile], [lab], "cuda:0")
+    pred, total = loops.predict_tile(d, pool, 0, 25, 5, [0.5] * 3, [0.2] * 3, comm)
+    torch.cuda.synchronize()
+    if rank == 1:                      # any rank holds the whole map
+        np.save(out, pred.cpu().numpy())
+    comm.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_band_partitioned_inference_equals_single_process(tmp_path, world):
+    from drs_amd import loops, patches as P
+    from drs_amd.net import DilatedNet
+    out = str(tmp_path / "bands.npy")
+    mp.spawn(_band_worker, args=(world, 30600 + os.getpid() % 1000 + world, out), nprocs=world, join=True)
+    tile, lab = _tile_for_bands()
+    d = DilatedNet("dilated_grsl", 5, 6, 0.005, b_max=5, s_max=25, device="cuda:0", seed=4)
+    pool = P.TilePool([tile], [lab], "cuda:0")
+    prob, occ, total = loops.predict_tile(d, pool, 0, 25, 5, [0.5] * 3, [0.2] * 3, return_sums=True)
+    pred, _ = loops.predict_tile(d, pool, 0, 25, 5, [0.5] * 3, [0.2] * 3)
+    torch.cuda.synchronize()
+    got = np.load(out)
+    want = pred.cpu().numpy()
+    avg = (prob.view(150, 97, 6) / occ.view(150, 97, 1).float()).cpu().numpy()
+    srt = np.sort(avg, axis=2)
+    clear = (srt[..., -1] - srt[..., -2]) > 1e-5 * np.abs(avg).max()
+    assert clear.mean() > 0.99 and got.shape == want.shape
+    np.testing.assert_array_equal(got[clear], want[clear])        # the float sums associate differently at band boundaries only
+    assert (got != want).mean() < 1e-3

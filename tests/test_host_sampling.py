@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hdr = open(os.path.join(root, "include", "drs.h")).read()
-    declared = set(re.findall(r"\bint\s+(drs_[a-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"^(?:int|void|float|long long)\s+(drs_[a-z0-9_]+)\s*\(", hdr, flags=re.M))      # every function of the header
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)

@@ -29,6 +29,7 @@ def main(B=128, S=64, targets="1536", variants="0,1", rounds=4, staggers="0", la
             slabs[(v, tg, sg)] = (ns, torch.zeros(ns * L.k * L.k * L.cin_k * L.cout, device=DEV))
         for r in range(rounds):
             for (v, tg, sg) in arms:
+                lib.drs_debug_wgrad_variant(v)
                 lib.drs_debug_wgrad_target(tg)
                 ns, slab = slabs[(v, tg, sg)]
                 for rep in range(3):
