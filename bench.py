@@ -62,21 +62,44 @@ def pmc_traffic(arith):
         return None
 
 
+def allowed_cores():
+    """CPU cores this process may really use: its affinity mask, cut to the cgroup's CPU-time quota where one is set (a GPU box
+    shows every core of the host in the mask but grants one GPU's share of CPU time: more threads than that only thrash)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    note = "affinity mask: %d" % n
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1") and float(quota) > 0:
+                q = max(1, int(float(quota) / period + 0.5))
+                if q < n:
+                    note += ", cgroup CPU quota: %d" % q
+                    n = q
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n, note
+
+
 def cpu_baseline(batch=64, warmup=2, timed=5):
     """The reference step restated with PyTorch-CPU fp32 ops (oracle/torch_ref.py) + the reference's host pipeline (numpy crop /
     rotate / noise / flip, normalise of bands 0..2, confusion matrix), on this host's cores, as SURVEY.md 8(d) specifies it: the
     bench's own workload (same net, 64x64x5 patches of the same 2048 x 2048 synthetic tile, same instances), `warmup` + `timed`
-    steps, every core the process is allowed (affinity), median step; plus a 1-thread figure.  The batch is 64 rather than the
+    steps, every core the process is allowed (allowed_cores: affinity mask cut to the cgroup's CPU quota), median step; plus a 1-thread figure.  The batch is 64 rather than the
     GPU line's 128 to keep the default run within minutes (a CPU step is seconds long and scales linearly in the batch); the
     1-thread figure uses one step of 8 patches for the same reason.  Both are stated in `sample`."""
     from oracle.torch_ref import TorchNet
     from oracle import host_ref as H
     from oracle.tf_ops import OracleNet
     from drs_amd.synthetic import make_tile, grid_instances
-    try:
-        ncores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncores = os.cpu_count() or 1
+    ncores, core_note = allowed_cores()
     torch.set_num_threads(ncores)
     tile, lab = make_tile(TILE, TILE, CHANNELS, CLASSES, seed=1234)
     inst = grid_instances(TILE, TILE, PATCH, 25, GLOBAL_BATCH * 100, seed=0)
@@ -111,7 +134,8 @@ def cpu_baseline(batch=64, warmup=2, timed=5):
                 break
     except OSError:
         pass
-    return dict(value=round(batch / med, 3), unit="patches/s", cores=ncores, kind="port", cpu_model=model, value_1_thread=round(b1 / one, 3),
+    return dict(value=round(batch / med, 3), unit="patches/s", cores=ncores, cores_note=core_note, kind="port", cpu_model=model,
+                value_1_thread=round(b1 / one, 3),
                 sample="%d timed steps after %d warm-up, batch %d (GPU line: 128), dilated_grsl_rate8 / 64x64x5 patches of the 2048x2048 "
                        "tile, host crop+augment+normalise+confusion included; median step %.2f s (min %.2f, max %.2f); 1-thread figure: one "
                        "step of %d patches, %.2f s" % (timed, warmup, batch, med, min(times), max(times), b1, one))

@@ -469,6 +469,7 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
 // of wgrad_kernel: results are bitwise the same.
 template <int TR, int TO>
 __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) void wgrad_dma_kernel(const WgradArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass has no LDS-DMA builtin; it only needs the launch stub
   constexpr int WR = TR >= 64 ? 2 : 1, WC = TO >= 64 ? 2 : 1;
   constexpr int NW = WR * WC, NT = 64 * NW;
   constexpr int WTR = TR / WR, WTO = TO / WC;
@@ -669,6 +670,7 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
         const int col = wc * WTO + ni * 32 + li;
         if (R0 + row < rows_all) dst[(size_t)row * a.Cout + col] = acc[mi][ni][r];
       }
+#endif
 }
 
 // grad[tap][c][o] = sum over splits (fixed order) of slab[split][tap][c (of cin_pad)][o], c < cin_real
@@ -728,12 +730,15 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
   return DRS_LAUNCH_CHECK();
 }
 
-int g_wgrad_variant = 1;     // development switch (drs_debug_wgrad_variant): 0 = register-staged tiles, 1 = LDS-DMA double-buffered halves
+int g_wgrad_variant = -1;    // development switch (drs_debug_wgrad_variant): 0 = register-staged tiles, 1 = LDS-DMA double-buffered halves, -1 = per tile
 
 template <int TR, int TO>
 int launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t st) {
   constexpr int NT = 64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1);
-  if (g_wgrad_variant == 0) DRS_LAUNCH((wgrad_kernel<TR, TO>), dim3(nsplit * a.ntr * a.nto), dim3(NT), 0, st, a);
+  // in-process A/B at B = 128 (profiles/r02/wgrad_ablation.txt): the LDS-DMA form wins 3-6 % on the 128-wide tiles and loses 7-10 % on the
+  // 64-wide ones (Cout = 64, 192), so each layer takes the form that is faster for its tile
+  const bool dma = g_wgrad_variant < 0 ? TO == 128 : g_wgrad_variant == 1;
+  if (!dma) DRS_LAUNCH((wgrad_kernel<TR, TO>), dim3(nsplit * a.ntr * a.nto), dim3(NT), 0, st, a);
   else DRS_LAUNCH((wgrad_dma_kernel<TR, TO>), dim3(nsplit * a.ntr * a.nto), dim3(NT), 0, st, a);
   return DRS_LAUNCH_CHECK();
 }
@@ -766,7 +771,7 @@ int drs_debug_skip_taps(int v) { const int old = drs_g_skip_halo_taps; if (v >= 
 
 int drs_debug_wgrad_target(int v) { const int old = g_wgrad_target; if (v > 0) g_wgrad_target = v; return old; }
 
-int drs_debug_wgrad_variant(int v) { const int old = g_wgrad_variant; if (v >= 0) g_wgrad_variant = v; return old; }
+int drs_debug_wgrad_variant(int v) { const int old = g_wgrad_variant; if (v >= -1) g_wgrad_variant = v; return old; }
 
 // M-tile height the forward/dgrad kernel uses for this Cout (= rows per BN-statistics slab row)
 int drs_conv_mtile(int cout) { return pick_tile(cout) >= 64 ? 128 : 256; }
