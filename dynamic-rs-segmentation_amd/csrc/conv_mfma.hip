@@ -36,6 +36,53 @@ struct ConvArgs {
   float rcpS, rcpSS;
 };
 
+// Epilogue shared by the forward / input-gradient kernels: bias, optional accumulate, store, and the tile's batch-norm statistics.
+// C/D map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  `scratch`: LDS no wave reads any more.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* scratch, int m0, int n0) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  float bv[TN];
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni) {
+    const int col = n0 + wn * WTN + ni * 32 + li;
+    bv[ni] = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row < a.M) {
+          float v = acc[mi][ni][r] + bv[ni];
+          float* dst = a.out + (size_t)row * a.ld_out + a.coff_out + col;
+          if (a.accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+  }
+  if (a.stats) {
+    // batch-norm statistics of the tile (never together with accumulate): fixed-order reduction over the lane halves, then
+    // over the WM waves that share a column; one slab row per M tile
+    const int rem = a.M - m0;
+    tile_column_stats<TN, WM, BN>(
+        scratch, t, wm, h == 0, (float)(rem < BM ? rem : BM), [&](int ni) { return wn * WTN + ni * 32 + li; },
+        [](float s) { return s + __shfl_xor(s, 32); },
+        [&](int ni, auto f) {
+#pragma unroll
+          for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < a.M) f(acc[mi][ni][r] + bv[ni]);
+        },
+        a.stats + ((size_t)(m0 / BM) * a.Cout + n0) * 2);
+  }
+}
+
 // PACK: the input has fewer than 32 channels (conv1: 3..5 bands in an 8-channel slab).  A K-step is then 32 / Cin consecutive
 // filter taps x Cin channels instead of one tap x 32 channels, so the contraction is k*k*Cin long rather than k*k*32 (conv1: 224
 // instead of 800); every thread adds the offset of ITS tap.  The filter is [round_up(k*k*Cin, 32)][Cout] with zero tail rows.
@@ -174,42 +221,148 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 128) ? 3 : 1) void conv_ig
     if (ks + 1 < nks) { lstore(); __syncthreads(); }
   }
 
-  // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  float bv[TN];
+  conv_epilogue<BM, BN, WM, WN>(a, acc, lds, m0, n0);
+}
+
+// The forward / input-gradient tile with its operands brought in by LDS-DMA (as wgrad_dma_kernel): a K-step (32 channels of one
+// tap) is multiplied as two 16-channel halves out of a double-buffered LDS image -- A half [BM pixels][16 ch] (64-B rows), B half
+// [16 k][BN] -- the DMA of half h+1 landing while half h is multiplied; one barrier per half; no staging registers, no ds_write
+// pass.  A DMA wave-instruction writes 64 lanes x 16 B to consecutive LDS bytes, so the A image cannot be padded; its
+// ds_read_b128 fragment reads stay conflict-free through a swizzle realised on the SOURCE address: the 16-byte piece c of pixel
+// row r sits in slot c ^ ((r >> 2) & 3) (the 16 lanes of every ds_read_b128 group then cover the 16 slots of the 256-byte bank
+// row once).  K order, accumulation order and epilogue are those of conv_igemm_kernel: results are bitwise the same.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass has no LDS-DMA builtin; it only needs the launch stub
+  static_assert(WM * WN == 4 && BM == 128, "4 waves, 128-pixel tiles");
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int HK = 16;                         // channels per pipeline stage (half a K-step)
+  constexpr int ASTAGE = BM * HK, STAGE = ASTAGE + HK * BN;   // floats
+  constexpr int IA = (BM / 16) / 4;              // A DMA instructions per wave and half (16 pixel rows each)
+  constexpr int BRPI = 256 / BN;                 // B k-rows per DMA instruction (1 KiB / row bytes)
+  constexpr int IB = (HK / BRPI) / 4;            // B DMA instructions per wave and half
+  static_assert(IA >= 1 && IB >= 1, "tile / wave layout");
+
+  __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int ntn = a.Cout / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / ntn) * BM;
+  const int n0 = (tile % ntn) * BN;
+  const int Sp = a.S + 2 * a.P;
+
+  // DMA lane roles.  A: instruction j covers pixel rows 16 j + (lane >> 2); this lane fills slot (lane & 3) of its row with
+  // the source piece (lane & 3) ^ ((row >> 2) & 3) = (lane & 3) ^ ((lane >> 4) & 3)
+  uint32_t offA[IA], offB[IB];
 #pragma unroll
-  for (int ni = 0; ni < TN; ++ni) {
-    const int col = n0 + wn * WTN + ni * 32 + li;
-    bv[ni] = a.bias ? a.bias[col] : 0.f;
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < a.M) {
-          float v = acc[mi][ni][r] + bv[ni];
-          float* dst = a.out + (size_t)row * a.ld_out + a.coff_out + col;
-          if (a.accumulate) v += *dst;
-          *dst = v;
-        }
-      }
-    }
+  for (int i = 0; i < IA; ++i) {
+    int p = m0 + (wave + 4 * i) * 16 + (lane >> 2);
+    p = p < a.M ? p : a.M - 1;
+    offA[i] = (padded_pixel_off(p, a.S, a.P, a.ld_in, a.rcpS, a.rcpSS, -a.pad, -a.pad) + (uint32_t)a.coff_in) * 4u +
+              (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) * 16);
   }
-  if (a.stats) {
-    // batch-norm statistics of the tile (never together with accumulate): fixed-order reduction over the lane halves, then
-    // over the WM waves that share a column; one slab row per M tile; lds aliases the (finished) A tile
-    const int rem = a.M - m0;
-    tile_column_stats<TN, WM, BN>(
-        lds, t, wm, h == 0, (float)(rem < BM ? rem : BM), [&](int ni) { return wn * WTN + ni * 32 + li; },
-        [](float s) { return s + __shfl_xor(s, 32); },
-        [&](int ni, auto f) {
+  // B: instruction j covers k-rows BRPI j + lane / (BN / 4), this lane the 16-byte piece lane % (BN / 4) of its row
+#pragma unroll
+  for (int i = 0; i < IB; ++i)
+    offB[i] = (uint32_t)((((wave + 4 * i) * BRPI + lane / (BN / 4)) * a.Cout + n0 + (lane % (BN / 4)) * 4)) * 4u;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int cpt = a.Cin / BK;
+  int u_lo, u_hi;
+  live_tap_rows(m0, BM, a.M, a.S, a.k, a.rate, a.pad, a.rcpS, a.rcpSS, u_lo, u_hi);
+  if (!a.skip_halo) { u_lo = 0; u_hi = a.k; }
+  u_lo = __builtin_amdgcn_readfirstlane(u_lo);
+  u_hi = __builtin_amdgcn_readfirstlane(u_hi);
+  const int nks = (u_hi - u_lo) * a.k * cpt;
+  const char* wlive = reinterpret_cast<const char*>(a.w + (size_t)u_lo * a.k * a.Cin * a.Cout);
+  const char* inb = reinterpret_cast<const char*>(a.in);
+  int lu = u_lo, lv = 0, lc = 0;                // (tap row, tap col, channel chunk) of the K-step being fetched
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+
+  auto issue = [&](int ks, int half, int stage) {
+    float* sa = lds + stage * STAGE;
+    float* sb = sa + ASTAGE;
+    const char* ab = inb + (size_t)(uint32_t)((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK + half * HK) * 4u;
+    const char* wb = wlive + (size_t)(uint32_t)(ks * BK + half * HK) * (uint32_t)a.Cout * 4u;
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      uint32_t o = offA[i]; asm volatile("" : "+v"(o));
+      __builtin_amdgcn_global_load_lds(ab + o, (lds_ptr)(sa + (wave + 4 * i) * 256), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      uint32_t o = offB[i]; asm volatile("" : "+v"(o));
+      __builtin_amdgcn_global_load_lds(wb + o, (lds_ptr)(sb + (wave + 4 * i) * 256), 16, 0, 0);
+    }
+  };
+  auto next_kstep = [&]() { if (++lc == cpt) { lc = 0; if (++lv == a.k) { lv = 0; ++lu; } } };
+
+  // fragment addresses (floats): A row r = arow + 32 mi, piece c = 2 q + h in slot c ^ ((r >> 2) & 3); B row k, column
+  const int arow = wm * WTM + li, bcolw = wn * WTN + li;
+  const int sw = (li >> 2) & 3;                 // (arow + 32 mi) >> 2 & 3 == (li >> 2) & 3: WTM and 32 are multiples of 16
+  auto compute = [&](int stage) {
+    const float* As = lds + stage * STAGE;
+    const float* Bs = As + ASTAGE;
+    constexpr int NST = HK / 2;                 // MFMA k-steps per half
+    f32x4 af[2][TM];
+    float bf[2][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) af[0][mi] = *reinterpret_cast<const f32x4*>(&As[(arow + mi * 32) * HK + ((h ^ sw) * 4)]);
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) bf[0][ni] = Bs[(h * 4) * BN + bcolw + ni * 32];
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      const int e = st & 3;
+      if (st + 1 < NST) {
+        const int q1 = (st + 1) >> 2, e1 = (st + 1) & 3;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) bf[(st + 1) & 1][ni] = Bs[(q1 * 8 + h * 4 + e1) * BN + bcolw + ni * 32];
+        if (e1 == 0) {
 #pragma unroll
           for (int mi = 0; mi < TM; ++mi)
+            af[q1 & 1][mi] = *reinterpret_cast<const f32x4*>(&As[(arow + mi * 32) * HK + (((2 * q1 + h) ^ sw) * 4)]);
+          __builtin_amdgcn_sched_group_barrier(0x100, TN + TM, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x100, TN, 0);
+        }
+      }
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              if (m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < a.M) f(acc[mi][ni][r] + bv[ni]);
-        },
-        a.stats + ((size_t)(m0 / BM) * a.Cout + n0) * 2);
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(st >> 2) & 1][mi][e], bf[st & 1][ni], acc[mi][ni], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x8, TM * TN, 0);
+    }
+  };
+
+  issue(0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int ks = 0; ks < nks; ++ks) {
+    issue(ks, 1, 1);                              // second half of this K-step lands while the first is multiplied
+    compute(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    next_kstep();
+    if (ks + 1 < nks) issue(ks + 1, 0, 0);        // first half of the next K-step (every wave is done with stage 0)
+    compute(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   }
+  conv_epilogue<BM, BN, WM, WN>(a, acc, lds, m0, n0);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ wgrad
@@ -722,11 +875,17 @@ __global__ void pad_cin_kernel(const float* __restrict__ w, float* __restrict__ 
   }
 }
 
+int g_conv_variant = -1;     // development switch (drs_debug_conv_variant): 0 = register-staged tiles, 1 = LDS-DMA double-buffered halves, -1 = per tile
+
 template <int BM, int BN, int WM, int WN>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
   const int mt = (a.M + BM - 1) / BM, nt = a.Cout / BN;
   if (a.Cin < BK) DRS_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, true>), dim3(mt * nt), dim3(256), 0, st, a);
-  else DRS_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN>), dim3(mt * nt), dim3(256), 0, st, a);
+  else if constexpr (BM == 128) {
+    const bool dma = g_conv_variant != 0;       // in-process A/B (tools/ab_conv.py): the DMA form is 1-6 % faster on every Dilated8Pooling shape at B = 128 and 4 % at B = 16
+    if (dma) DRS_LAUNCH((conv_dma_kernel<BM, BN, WM, WN>), dim3(mt * nt), dim3(256), 0, st, a);
+    else DRS_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN>), dim3(mt * nt), dim3(256), 0, st, a);
+  } else DRS_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN>), dim3(mt * nt), dim3(256), 0, st, a);
   return DRS_LAUNCH_CHECK();
 }
 
@@ -770,6 +929,8 @@ extern "C" {
 int drs_debug_skip_taps(int v) { const int old = drs_g_skip_halo_taps; if (v >= 0) drs_g_skip_halo_taps = v; return old; }
 
 int drs_debug_wgrad_target(int v) { const int old = g_wgrad_target; if (v > 0) g_wgrad_target = v; return old; }
+
+int drs_debug_conv_variant(int v) { const int old = g_conv_variant; if (v >= -1) g_conv_variant = v; return old; }
 
 int drs_debug_wgrad_variant(int v) { const int old = g_wgrad_variant; if (v >= -1) g_wgrad_variant = v; return old; }
 
