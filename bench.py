@@ -178,8 +178,8 @@ def executed_fraction(plan, B, S):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)     # 100 x 53 ms: long enough for a driver that samples GPU activity every few seconds
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-opt-in", action="store_true", help="skip the short bf16x3 measurement reported beside the fp32 headline")
@@ -315,27 +315,32 @@ def main():
         tv = comm.max_float(tv, dev)
     val_pixels_per_s = vb * GLOBAL_BATCH * PATCH * PATCH / tv
 
-    # ---- the opt-in arithmetic beside the headline (N = 1 only; never `value`): the same step on the split-bf16 kernels
+    # ---- the opt-in arithmetics beside the headline (N = 1 only; never `value`): the same step on the split-bf16 kernels (op-level path).
+    # bf16x6 is the fp32-EQUIVALENT one (tests/test_gpu_split.py: its errors against the fp64 oracle are no larger than the fp32 MFMA
+    # kernels' on every BASELINE shape); bf16x3 trades 2^-16 product error for speed.
     opt_in = None
     if world == 1 and args.arith == "f32" and not args.no_opt_in:
-        net2 = DilatedNet(NET, CHANNELS, CLASSES, WD, b_max=B_local, s_max=PATCH, device=dev, seed=42, arith="bf16x3")
-        main_net, net = net, net2
-        try:
-            for _ in range(3):
-                one_step()
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            for _ in range(10):
-                one_step()
-            torch.cuda.synchronize()
-            dt2 = (time.perf_counter() - t2) / 10
-        finally:
-            net = main_net
-        opt_in = {"arith": "bf16x3", "dtype": ARITH["bf16x3"]["dtype"], "value": round(GLOBAL_BATCH / dt2, 2), "unit": "patches/s",
-                  "ms_per_step": round(1e3 * dt2, 3), "steps": 10, "warmup": 3,
-                  "note": "not the headline: opt-in arithmetic (DESIGN.md 3a), held to the fp32 path's parity bounds in tests/"}
-        del net2
-        torch.cuda.empty_cache()
+        opt_in = {}
+        main_net = net
+        for arith in ("bf16x6", "bf16x3"):
+            net = DilatedNet(NET, CHANNELS, CLASSES, WD, b_max=B_local, s_max=PATCH, device=dev, seed=42, arith=arith)
+            try:
+                for _ in range(3):
+                    one_step()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                for _ in range(10):
+                    one_step()
+                torch.cuda.synchronize()
+                dt2 = (time.perf_counter() - t2) / 10
+            finally:
+                del net
+                net = main_net
+                torch.cuda.empty_cache()
+            opt_in[arith] = {"dtype": ARITH[arith]["dtype"], "value": round(GLOBAL_BATCH / dt2, 2), "unit": "patches/s",
+                             "ms_per_step": round(1e3 * dt2, 3), "steps": 10, "warmup": 3}
+        opt_in["note"] = ("not the headline: opt-in arithmetics of the convolutions (DESIGN.md 3a), held to the fp32 path's parity bounds in "
+                          "tests/; bf16x6 is as exact as the fp32 MFMA kernels (tests/test_gpu_split.py), bf16x3 is not")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -628,9 +628,10 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   constexpr int WTR = TR / WR, WTO = TO / WC;
   constexpr int TMr = WTR / 32, TNo = WTO / 32;
   constexpr int BP = 32, HP = 16;             // pixels per chunk (walk / table unit) and per pipeline stage
-  constexpr int XPI = 256 / TR, GPI = 256 / TO;      // pixels one DMA wave-instruction covers (1 KiB / row bytes)
-  constexpr int IX = (HP / XPI) / NW, IG = (HP / GPI) / NW;   // DMA instructions per wave and half
-  static_assert(IX >= 1 && IG >= 1 && IX * NW * XPI == HP && IG * NW * GPI == HP, "tile / wave layout");
+  constexpr int XQ = TR / 4, GQ = TO / 4;     // 16-byte pieces per pixel row
+  // a DMA wave-instruction moves 64 pieces = 1 KiB of the half-stage image [HP][TR] (resp. [HP][TO]) taken as one linear run
+  constexpr int IX = HP * XQ / 64 / NW, IG = HP * GQ / 64 / NW;   // DMA instructions per wave and half
+  static_assert(IX >= 1 && IG >= 1 && IX * NW * 64 == HP * XQ && IG * NW * 64 == HP * GQ, "tile / wave layout");
   constexpr int XSTAGE = HP * TR, STAGE = HP * (TR + TO);     // floats
 
   __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
@@ -648,24 +649,30 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   const int R0 = (tile / a.nto) * TR;
   const int o0 = (tile % a.nto) * TO;
   const int rows_all = a.k * a.k * a.Cin;
-  // DMA lane roles: lane -> (pixel inside the instruction, 16-byte piece of the row)
-  const int xq = lane % (TR / 4), xp = lane / (TR / 4);
-  const int gq = lane % (TO / 4), gp = lane / (TO / 4);
+  const int Sxp = a.S + 2 * a.Px, Sgp = a.S + 2 * a.Pg;
+  const bool affine = (a.S & 31) == 0;
+  // DMA lane roles: instruction i of this wave moves pieces 64 (wave + NW i) + lane of the linear image: piece f belongs to pixel
+  // f / XQ, 16-byte column f % XQ.  (TR is a power of two, so the X column -- and with it the filter tap of the rows this lane
+  // stages -- is the same for all of a lane's instructions; TO = 192 gives every instruction its own (pixel, column) pair.)
+  const int xq = lane % XQ;
   const int myR = R0 + xq * 4;
   const int myRc = myR < rows_all ? myR : 0;
   const int tap = myRc / a.Cin, c0 = myRc % a.Cin;
   const int u = tap / a.k, v = tap % a.k;
-  const int Sxp = a.S + 2 * a.Px, Sgp = a.S + 2 * a.Pg;
   const uint32_t xconst = (uint32_t)((u * a.rate * Sxp + v * a.rate) * a.ld_x + a.coff_x + c0) * 4u;
-  const uint32_t gconst = (uint32_t)(a.coff_g + o0 + gq * 4) * 4u;
-  const bool affine = (a.S & 31) == 0;
-  // instruction i of this wave covers pixels (wave + NW * i) * XPI + xp of the half
   uint32_t xoff[IX], goff[IG];
   int xpix[IX], gpix[IG];
 #pragma unroll
-  for (int i = 0; i < IX; ++i) { xpix[i] = (wave + NW * i) * XPI + xp; xoff[i] = xconst + (affine ? (uint32_t)(xpix[i] * a.ld_x) * 4u : 0u); }
+  for (int i = 0; i < IX; ++i) {
+    xpix[i] = (64 * (wave + NW * i) + lane) / XQ;
+    xoff[i] = xconst + (affine ? (uint32_t)(xpix[i] * a.ld_x) * 4u : 0u);
+  }
 #pragma unroll
-  for (int i = 0; i < IG; ++i) { gpix[i] = (wave + NW * i) * GPI + gp; goff[i] = gconst + (affine ? (uint32_t)(gpix[i] * a.ld_g) * 4u : 0u); }
+  for (int i = 0; i < IG; ++i) {
+    const int f = 64 * (wave + NW * i) + lane;
+    gpix[i] = f / GQ;
+    goff[i] = (uint32_t)(a.coff_g + o0 + (f % GQ) * 4) * 4u + (affine ? (uint32_t)(gpix[i] * a.ld_g) * 4u : 0u);
+  }
 
   f32x16 acc[TMr][TNo];
 #pragma unroll
@@ -902,13 +909,19 @@ int launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t st) {
   return DRS_LAUNCH_CHECK();
 }
 
+template <int TR, int TO>
+int launch_wgrad_dma_only(const WgradArgs& a, int nsplit, hipStream_t st) {
+  DRS_LAUNCH((wgrad_dma_kernel<TR, TO>), dim3(nsplit * a.ntr * a.nto), dim3(256), 0, st, a);
+  return DRS_LAUNCH_CHECK();
+}
+
 }  // namespace
 
 int drs_g_skip_halo_taps = 1;
 
 namespace {
 
-int g_wgrad_target = 1536;   // workgroups the pixel split of the filter gradient aims at (development switch drs_debug_wgrad_target)
+int g_wgrad_target = 2048;   // workgroups the pixel split of the filter gradient aims at: two rounds of the 4 x 256 resident 128x128 DMA workgroups (sweep in profiles/r02/wgrad_ablation.txt; development switch drs_debug_wgrad_target)
 
 int pick_tile(int c) { return c % 128 == 0 ? 128 : (c % 64 == 0 ? 64 : 32); }
 
@@ -920,6 +933,10 @@ int pick_wgrad_rows(int rows) {
   if (rows % 64 == 0) return 64;
   return rows % 32 == 0 && rows < 128 ? 32 : 128;
 }
+
+// wgrad column tile: Cout = 192 (conv5 / conv6 of Dilated8Pooling) takes ONE 192-wide tile with the 128-row LDS-DMA form (wave
+// tile 64 x 96: 6 MFMAs per 5 fragment reads, 320 operand floats per pixel for 24576 products) instead of three 64-wide ones
+int pick_wgrad_cols(int tr, int cout) { return (tr == 128 && cout % 192 == 0 && cout % 128 != 0 && g_wgrad_variant != 0) ? 192 : pick_tile(cout); }
 
 }  // namespace
 
@@ -965,14 +982,18 @@ int drs_conv_forward(const float* in, int B, int S, int P, int ld_in, int coff_i
 // number of pixel splits (= slab count) drs_conv_wgrad will use; workspace = nsplit * k*k*cin * cout floats
 int drs_conv_wgrad_splits(int B, int S, int k, int cin, int cout) {
   const long long M = (long long)B * S * S;
-  const int tr = pick_wgrad_rows(k * k * cin), to = pick_tile(cout);
+  const int tr = pick_wgrad_rows(k * k * cin), to = pick_wgrad_cols(tr, cout);
   const int ntile = ((k * k * cin + tr - 1) / tr) * (cout / to);
   const int nchunks = (int)((M + 31) / 32);
   // fill the 256 CUs evenly.  6 workgroups per CU (2 rounds at 3 resident) where a launch has few tiles or few pixels; twice that
   // where it has many tiles and pixels: with the all-halo chunks skipped its workgroups differ in length by up to a quarter and 2
   // rounds quantise the gain away (measured at B = 128: conv6 3.48 -> 3.01 ms, conv8 5.19 -> 4.85; conv3, 8 tiles, loses 6 %).
   // Never less than 32 chunks (1024 pixels) per split.
-  const int target = (ntile >= 24 && nchunks >= 8192) ? 2 * g_wgrad_target : g_wgrad_target;
+  // ... and small launches (the per-rank batches of data parallelism) want long workgroups more than many: >= 96 chunks each, down
+  // to one round of 512 (sweeps at B = 16 / 32 in profiles/r02/wgrad_ablation.txt)
+  long long fit = (long long)nchunks * ntile / 96;
+  fit = fit < 512 ? 512 : (fit > g_wgrad_target ? g_wgrad_target : fit);
+  const int target = (ntile >= 24 && nchunks >= 8192) ? 2 * g_wgrad_target : (int)fit;
   int want = target / ntile;
   int maxs = (nchunks + 31) / 32;
   if (maxs < 1) maxs = 1;
@@ -994,7 +1015,7 @@ int drs_conv_wgrad(const float* x, int B, int S, int Px, int ld_x, int coff_x, c
   a.x = x; a.S = S; a.Px = Px; a.ld_x = ld_x; a.coff_x = coff_x;
   a.g = g; a.Pg = Pg; a.ld_g = ld_g; a.coff_g = coff_g; a.M = (int)M;
   a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout; a.slab = slab;
-  const int tr = pick_wgrad_rows(k * k * cin), to = pick_tile(cout);
+  const int tr = pick_wgrad_rows(k * k * cin), to = pick_wgrad_cols(tr, cout);
   a.ntr = (k * k * cin + tr - 1) / tr; a.nto = cout / to;
   const int nsplit = drs_conv_wgrad_splits(B, S, k, cin, cout);
   const int nchunks = (int)((M + 31) / 32);
@@ -1003,7 +1024,8 @@ int drs_conv_wgrad(const float* x, int B, int S, int Px, int ld_x, int coff_x, c
   a.skip_halo = drs_skip_halo_taps_wgrad(M);
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (tr == 128 && to == 128) rc = launch_wgrad<128, 128>(a, nsplit, st);
+  if (tr == 128 && to == 192) rc = launch_wgrad_dma_only<128, 192>(a, nsplit, st);
+  else if (tr == 128 && to == 128) rc = launch_wgrad<128, 128>(a, nsplit, st);
   else if (tr == 128 && to == 64) rc = launch_wgrad<128, 64>(a, nsplit, st);
   else if (tr == 128 && to == 32) rc = launch_wgrad<128, 32>(a, nsplit, st);
   else if (tr == 64 && to == 128) rc = launch_wgrad<64, 128>(a, nsplit, st);

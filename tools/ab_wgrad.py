@@ -48,7 +48,7 @@ def main(B=128, S=64, targets="1536", variants="0,1", rounds=4, staggers="0", la
             tot[a] += best[a]
         del slabs
     print("total  " + "".join("  v%d t%d s%d %7.3f ms |" % (v, tg, sg, tot[(v, tg, sg)]) for (v, tg, sg) in arms))
-    lib.drs_debug_wgrad_target(1536)
+    lib.drs_debug_wgrad_target(2048)
 
 if __name__ == "__main__":
     kw = dict(a.split("=") for a in sys.argv[1:])
