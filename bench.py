@@ -37,8 +37,8 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 # arithmetic of the convolution kernels (net.ARITH_TERMS): MFMA peak it is priced against, MFMA products issued per
 # algorithmic multiply, the dtype string of the JSON line and the dominant kernel's name
 ARITH = {
-    "f32": dict(peak=PEAK_FP32_MFMA_TFLOPS, products=1, dtype="f32", kernel="conv_igemm_kernel (fwd + dgrad launches)",
-                pmc_key="conv_igemm_kernel (all)"),
+    "f32": dict(peak=PEAK_FP32_MFMA_TFLOPS, products=1, dtype="f32", kernel="conv_dma_kernel (fwd + dgrad launches; conv1: conv_igemm_kernel)",
+                pmc_key="conv fwd+dgrad (all)"),
     "bf16x3": dict(peak=PEAK_BF16_MFMA_TFLOPS, products=3, kernel="conv_split_dma_kernel (fwd + dgrad launches)",
                    dtype="bf16x3 (fp32 operands as 2 bf16 terms, 3 bf16 MFMA products per multiply, fp32 accumulate)",
                    pmc_key="conv_split_dma_kernel (all)"),
@@ -56,10 +56,12 @@ def pmc_traffic(arith):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)))
     if not files:
         return None
-    try:
-        return json.load(open(files[-1]))[ARITH[arith]["pmc_key"]]["traffic_bytes_per_launch"]
-    except (KeyError, ValueError):
-        return None
+    for f in reversed(files):           # newest round that has the key (older rounds named the kernel family differently)
+        try:
+            return json.load(open(f))[ARITH[arith]["pmc_key"]]["traffic_bytes_per_launch"]
+        except (KeyError, ValueError):
+            continue
+    return None
 
 
 def allowed_cores():

@@ -428,3 +428,47 @@ def test_bn_statistics_survive_a_large_mean(lib, cout, B, S, ratio):
     two_launch = sv[:, 1] / M - (sv[:, 0] / M) ** 2
     assert np.abs(two_launch / var - 1.0).max() < 2e-5
     assert rel_err(mv.cpu().numpy(), T.moving_update(np.ones(cout), var * M / (M - 1.0))) < 1e-5
+
+
+@pytest.mark.parametrize("k,rate,cin,cout,B,S", [(3, 8, 64, 128, 2, 21), (4, 3, 64, 64, 3, 32), (5, 2, 32, 64, 2, 9), (3, 5, 128, 256, 1, 40),
+                                                  (3, 2, 96, 128, 2, 13)])
+def test_register_staged_and_lds_dma_kernel_forms_are_bitwise_equal(lib, k, rate, cin, cout, B, S):
+    """The forward / input-gradient and filter-gradient tiles exist in a register-staged and an LDS-DMA form (conv_mfma.hip); the
+    library picks per tile by measured speed.  K order, chunk walk and summation order are the same, so the two forms must agree
+    bit for bit -- also on patch sides that are not multiples of 32 (table walk), ragged M tiles and a last chunk with pixels past
+    the end (the DMA form zeroes those rows in LDS)."""
+    rng = np.random.default_rng(S * 13 + cout + k)
+    x = rng.normal(size=(B, S, S, cin)).astype(np.float32)
+    w = (rng.normal(size=(k, k, cin, cout)) * 0.05).astype(np.float32)
+    g = rng.normal(size=(B, S, S, cout)).astype(np.float32)
+    bias = rng.normal(size=(cout,)).astype(np.float32)
+    pb, pa = onets.same_pad(k, rate)
+    P = max(pb, pa)
+    M = B * S * S
+    xd, gd, wd, bd = padded(x, P), padded(g, P), dev(w), dev(bias)
+    mt = lib.query("drs_conv_mtile", cout)
+    raw = lib.load()
+    res = {}
+    try:
+        for v in (0, 1):
+            raw.drs_debug_conv_variant(v)
+            raw.drs_debug_wgrad_variant(v)
+            out = torch.zeros(M * cout, dtype=torch.float32, device=DEV)
+            stats = torch.zeros(((M + mt - 1) // mt) * cout * 2, dtype=torch.float32, device=DEV)
+            lib.call("drs_conv_forward", xd.data_ptr(), B, S, P, cin, 0, wd.data_ptr(), bd.data_ptr(), k, rate, pb, cin, cout, out.data_ptr(), cout, 0, 0,
+                     stats.data_ptr(), stream())
+            nsp = lib.query("drs_conv_wgrad_splits", B, S, k, cin, cout)
+            slab = torch.zeros(nsp * w.size, dtype=torch.float32, device=DEV)
+            gw = torch.zeros(w.size, dtype=torch.float32, device=DEV)
+            lib.call("drs_conv_wgrad", xd.data_ptr(), B, S, P, cin, 0, gd.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout, slab.data_ptr(),
+                     gw.data_ptr(), stream())
+            torch.cuda.synchronize()
+            res[v] = (out, stats, gw, nsp)
+    finally:
+        raw.drs_debug_conv_variant(-1)
+        raw.drs_debug_wgrad_variant(-1)
+    assert res[0][3] == res[1][3]
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert torch.equal(a, b)
+    ref = T.conv2d_same(x.astype(np.float64), w.astype(np.float64), rate) + bias.astype(np.float64)
+    assert rel_err(res[1][0].cpu().numpy().reshape(ref.shape), ref) < 1e-5

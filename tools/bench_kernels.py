@@ -67,7 +67,7 @@ def main(B=128, S=64, net="dilated_grsl_rate8", which="fwd,dgrad,wgrad", pad0=32
                                               L.cin_k, L.cin_k, L.cout, slab2.data_ptr(), gw.data_ptr(), st), reps=5)
                 row += " | %d: %d splits %6.3f ms" % (target, ns2, ms)
                 del slab2
-            _lib.load().drs_debug_wgrad_target(1536)
+            _lib.load().drs_debug_wgrad_target(2048)
         if "wab" in which:      # A/B of skipping the all-halo pixel chunks in the filter gradient, inside one process
             f = lambda: _lib.call("drs_conv_wgrad", x.data_ptr(), B, S, P, L.cin_k, 0, g.data_ptr(), P, L.cout, 0, L.k, L.rate, L.pad_b,
                                   L.cin_k, L.cin_k, L.cout, slab.data_ptr(), gw.data_ptr(), st)

@@ -34,12 +34,12 @@ def main(fetch_csv, write_csv, out):
         res[k] = dict(launches=f[k][0], fetch_bytes_per_launch=round(fb), write_bytes_per_launch=round(wb),
                       traffic_bytes_per_launch=round(fb + wb))
     # the dominant kernel of bench.py's roofline: all launches of the forward / input-gradient conv kernel together
-    for fam in ("conv_igemm_kernel", "conv_split_dma"):
-        conv = [k for k in res if k.startswith(fam)]
+    # (exact fp32: the LDS-DMA form conv_dma_kernel and, for conv1's packed K-steps, conv_igemm_kernel; split-bf16: conv_split_dma_kernel)
+    for name, fams in (("conv fwd+dgrad (all)", ("conv_dma_kernel", "conv_igemm_kernel")), ("conv_split_dma_kernel (all)", ("conv_split_dma",))):
+        conv = [k for k in res if k.startswith(fams)]
         n = sum(res[k]["launches"] for k in conv)
         if n:
-            res[("conv_split_dma_kernel" if fam == "conv_split_dma" else fam) + " (all)"] = dict(launches=n, traffic_bytes_per_launch=round(
-                sum(res[k]["traffic_bytes_per_launch"] * res[k]["launches"] for k in conv) / n))
+            res[name] = dict(launches=n, traffic_bytes_per_launch=round(sum(res[k]["traffic_bytes_per_launch"] * res[k]["launches"] for k in conv) / n))
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     for k in sorted(res, key=lambda k: -res[k]["traffic_bytes_per_launch"]):
         print("%-48s %4d launches  %8.1f MB/launch" % (k, res[k]["launches"], res[k]["traffic_bytes_per_launch"] / 1e6))

@@ -3,7 +3,7 @@
 held (GRBM_GUI_ACTIVE is summed over the 8 XCDs), MFMA-pipe busy share (SQ_VALU_MFMA_BUSY_CYCLES over 1024 SIMDs) and the split
 of wave time into parked / issue-stalled / issuing (quad-cycle counters; MI355X_MICROARCH.md, rocprofv3 PMC slots).
 
-    python tools/sq_summary.py <counter_collection.csv> [name filter, default 'wgrad_kernel|conv_igemm'] > profiles/rNN/sq_*.txt
+    python tools/sq_summary.py <counter_collection.csv> [name filter, default 'wgrad|conv_igemm|conv_dma'] > profiles/rNN/sq_*.txt
 """
 import collections
 import csv
@@ -16,7 +16,7 @@ def short(name):
     return name.split("(")[0]
 
 
-def main(path, pat="wgrad_kernel|conv_igemm"):
+def main(path, pat="wgrad|conv_igemm|conv_dma"):
     rx = re.compile(pat)
     disp = {}
     for r in csv.DictReader(open(path)):
