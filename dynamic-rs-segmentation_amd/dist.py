@@ -29,11 +29,13 @@ class TorchComm(object):
                 dist.init_process_group(backend=backend)
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
-        # Two communicators.  The collectives of one communicator run in order on ITS stream: a 2 KB sync-BN sum issued behind a
-        # 4 MB gradient bucket would wait for the bucket and stall the compute stream that needs it next.  The latency-bound sums
-        # (batch-norm statistics, CE sum, confusion matrix: <= SMALL elements) therefore get a communicator of their own and
-        # overtake the buckets; every rank issues both sequences in the same program order.
-        self.small = dist.new_group(ranks=list(range(self.world))) if self.world > 1 else None
+        # The collectives of one communicator run in order on ITS stream: a 2 KB sync-BN sum issued behind a 4 MB gradient bucket
+        # waits for the bucket.  In the step's schedule a bucket (~0.15 ms on 8 GPUs) is followed by >= 0.35 ms of kernels before the
+        # next batch-norm sum is issued, so the queue is normally empty by then and ONE communicator is the default.  DRS_BN_COMM=1
+        # gives the latency-bound sums (<= SMALL elements) a communicator of their own (they then overtake the buckets); it is opt-in
+        # because no multi-GPU node was available to this build to measure either choice.
+        two = self.world > 1 and os.environ.get("DRS_BN_COMM") == "1"
+        self.small = dist.new_group(ranks=list(range(self.world))) if two else None
 
     SMALL = 4096
 
