@@ -80,7 +80,7 @@ def test_heldout_pixel_accuracy_matches_cpu_oracle_over_seeds():
         late_d.append(np.mean(ld[-20:])); late_t.append(np.mean(lt[-20:]))
     n = len(SEEDS)
     acc_d, acc_t, late_d, late_t = map(np.asarray, (acc_d, acc_t, late_d, late_t))
-    se_acc = np.sqrt((acc_d.var(ddof=1) + acc_t.var(ddof=1)) / n)
+    se_acc = np.sqrt((acc_d.var(ddof=1) + acc_t.var(ddof=1)) / n)        # standard error of the difference of the two means
     se_loss = np.sqrt((late_d.var(ddof=1) + late_t.var(ddof=1)) / n)
     print("held-out accuracy  HIP %.4f +- %.4f   CPU oracle %.4f +- %.4f   (chance %.3f; difference %.4f, standard error %.4f)"
           % (acc_d.mean(), acc_d.std(ddof=1), acc_t.mean(), acc_t.std(ddof=1), 1.0 / K, acc_d.mean() - acc_t.mean(), se_acc))
@@ -89,5 +89,56 @@ def test_heldout_pixel_accuracy_matches_cpu_oracle_over_seeds():
     assert acc_t.mean() > 2.0 / K and acc_d.mean() > 2.0 / K
     # the two populations agree: difference of means within 3 standard errors of the seed-to-seed spread (+ a 1 % floor so that
     # an accidentally tiny spread cannot fail a correct implementation)
-    assert abs(acc_d.mean() - acc_t.mean()) <= 3.0 * se_acc + 0.01
-    assert abs(late_d.mean() - late_t.mean()) <= 3.0 * se_loss + 0.01 * late_t.mean()
+    # (three seeds estimate the spread itself only to +-40 %, and the CPU side is not run-to-run deterministic -- threaded sums --
+    # so the floor is what keeps a correct build from failing once in a hundred runs)
+    assert abs(acc_d.mean() - acc_t.mean()) <= 3.0 * se_acc + 0.03
+    assert abs(late_d.mean() - late_t.mean()) <= 3.0 * se_loss + 0.03 * late_t.mean()
+
+
+def test_trained_weights_label_the_heldout_tile_alike():
+    """The tight half of the accuracy parity: train on the HIP path until the net has learnt the synthetic classes, then label the
+    held-out tile by sliding window (isprs:1241-1284) with the HIP path and with the CPU oracle FROM THE SAME trained variables
+    (moving statistics included).  No chaos between the two here, so the label maps and the pixel accuracies must agree closely."""
+    from drs_amd import loops, patches as P
+    from drs_amd.net import DilatedNet
+    from drs_amd.synthetic import grid_instances, make_tile
+    B2, S2, steps = 8, 32, 260
+    tile, lab = make_tile(192, 192, CH, K, seed=3, n_seeds=24, class_signal=0.6)
+    held, held_lab = make_tile(96, 96, CH, K, seed=4, n_seeds=12, class_signal=0.6)
+    mean, std = tile[:, :, :3].mean(axis=(0, 1)), tile[:, :, :3].std(axis=(0, 1))
+    inst = grid_instances(192, 192, S2, 8, B2 * steps, seed=7)
+    d = DilatedNet(NET, CH, K, WD, b_max=B2, s_max=S2, device=DEV, seed=33)
+    pool = P.TilePool([tile], [lab], DEV)
+    losses = []
+    for i in range(steps):
+        P.crop_to_net(d, pool, inst[i * B2:(i + 1) * B2], S2, mean, std)
+        out = d.train_step(B2, S2, LR)
+        if i % 20 == 0 or i == steps - 1:
+            losses.append(d.loss_value(out["loss_parts"]))
+    print("HIP training loss every 20 steps:", np.round(losses, 3))
+    assert losses[-1] < 0.5 * losses[0]
+    t = TorchNet(NET, CH, K, params={n: d.get_variable(n) for n in d.variable_names()}, dtype=torch.float32)
+    hpool = P.TilePool([held], [held_lab], DEV)
+    pred_d, _ = loops.predict_tile(d, hpool, 0, S2, B2, mean, std)
+    prob_d, occ_d, _ = loops.predict_tile(d, hpool, 0, S2, B2, mean, std, return_sums=True)
+    st = H.stride_for(S2)
+    nh, nw = H.window_counts(96, 96, S2, st)
+    m5, s5 = list(mean) + [0, 0], list(std) + [1, 1]
+    batches = []
+    for i in range(-(-nh * nw // B2)):
+        p, _, pos = H.create_patches_per_map(held, held_lab, S2, st, i, B2)
+        p = p.copy()
+        H.normalize_images(p, m5, s5)
+        batches.append((t.forward(p.astype(np.float32), False).detach().numpy(), pos))
+    prob_t, occ_t, pred_t = H.stitch_tile(96, 96, K, S2, batches)
+    got = pred_d.cpu().numpy()
+    acc_d, acc_t = float((got == held_lab).mean()), float((pred_t == held_lab).mean())
+    agree = float((got == pred_t).mean())
+    avg_d = (prob_d.view(96, 96, K) / occ_d.view(96, 96, 1).float()).cpu().numpy()
+    avg_t = prob_t / occ_t
+    err = float(np.abs(avg_d - avg_t).max() / np.abs(avg_t).max())
+    print("held-out tile, same trained variables: pixel accuracy HIP %.4f  CPU oracle %.4f  (chance %.3f); label maps agree on %.4f of the "
+          "pixels; averaged logits differ by %.2e of their range" % (acc_d, acc_t, 1.0 / K, agree, err))
+    assert acc_t > 3.0 / K                                  # the net has learnt the task
+    assert err < 1e-3                                       # north star: logits within 1e-3 relative
+    assert agree > 0.998 and abs(acc_d - acc_t) < 0.002
