@@ -472,3 +472,40 @@ def test_register_staged_and_lds_dma_kernel_forms_are_bitwise_equal(lib, k, rate
         assert torch.equal(a, b)
     ref = T.conv2d_same(x.astype(np.float64), w.astype(np.float64), rate) + bias.astype(np.float64)
     assert rel_err(res[1][0].cpu().numpy().reshape(ref.shape), ref) < 1e-5
+
+
+@pytest.mark.parametrize("S,B", [(5, 3), (8, 5), (10, 2), (11, 3), (12, 2), (16, 3), (31, 1), (32, 2), (33, 1), (48, 1), (63, 1), (96, 1)])
+def test_filter_gradient_chunk_walk_over_patch_sides(lib, S, B):
+    """The filter-gradient kernels walk 32-pixel chunks with a scalar state machine (ChunkWalk) and, when the patch side is not a
+    multiple of 32, per-pixel offset tables that each thread advances incrementally (below 11 pixels a side: by division).  Every
+    regime -- sides below 11, not / exactly a multiple of 32, chunks spanning several rows or images, a ragged last chunk -- against
+    the fp64 oracle, in both kernel forms and with the all-halo chunks skipped or not, which must also agree bit for bit."""
+    k, rate, cin, cout = 3, 2, 64, 128
+    rng = np.random.default_rng(S * 31 + B)
+    x = rng.normal(size=(B, S, S, cin)).astype(np.float32)
+    g = rng.normal(size=(B, S, S, cout)).astype(np.float32)
+    w = rng.normal(size=(k, k, cin, cout)).astype(np.float32)
+    pb, pa = onets.same_pad(k, rate)
+    P = max(pb, pa)
+    xd, gd = padded(x, P), padded(g, P)
+    _, gw_ref = T.conv2d_same_bwd(x.astype(np.float64), w.astype(np.float64), rate, g.astype(np.float64))
+    raw = lib.load()
+    outs = []
+    try:
+        for variant in (0, 1):
+            for skip in (0, 2):
+                raw.drs_debug_wgrad_variant(variant)
+                raw.drs_debug_skip_taps(skip)
+                nsp = lib.query("drs_conv_wgrad_splits", B, S, k, cin, cout)
+                slab = torch.zeros(nsp * w.size, dtype=torch.float32, device=DEV)
+                gw = torch.full((w.size,), 7.0, dtype=torch.float32, device=DEV)
+                lib.call("drs_conv_wgrad", xd.data_ptr(), B, S, P, cin, 0, gd.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout, slab.data_ptr(),
+                         gw.data_ptr(), stream())
+                torch.cuda.synchronize()
+                outs.append(gw)
+    finally:
+        raw.drs_debug_wgrad_variant(-1)
+        raw.drs_debug_skip_taps(1)
+    assert rel_err(outs[0].cpu().numpy().reshape(gw_ref.shape), gw_ref) < 1e-5
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
