@@ -519,8 +519,8 @@ def validate_test(net, testing_data, testing_labels, testing_instances, batch_si
 
 def generate_final_maps(net, testing_data, testing_instances, batch_size, mean_full, std_full, update_type,
                         distribution_type, values, dataset, output_path, patch_acc_loss=None, patch_occur=None, comm=None):
-    """isprs:1854-1957: best (or fixed) patch size, sliding-window label map per tile, saved as
-    `<prefix><instance>_class.npy` (the reference writes colour TIFFs through PIL, out of the hot path)."""
+    """isprs:1854-1957: best (or fixed) patch size, sliding-window label map per tile, written as the reference's colour TIFF
+    (`top_mosaic_09cm_area<i>_class.tif` / `top_potsdam_<i>_label.tif`) and as class ids (`.npy`)."""
     comm = comm or NoComm()
     sized = distribution_type in ("multi_fixed", "uniform", "multinomial")
     crop_size = (select_best_patch_size(distribution_type, values, patch_acc_loss, patch_occur, update_type, debug=comm.rank == 0)
@@ -531,6 +531,10 @@ def generate_final_maps(net, testing_data, testing_instances, batch_size, mean_f
         pred, _ = predict_tile(net, pool, k, crop_size, batch_size, mean_full, std_full, comm)
         maps.append(pred.cpu().numpy())
         if comm.rank == 0 and output_path:
-            prefix = "top_mosaic_09cm_area" if dataset == "vaihingen" else "top_potsdam_"
-            np.save(output_path + prefix + str(testing_instances[k]) + "_class.npy", maps[-1])
+            # isprs:1950-1955: the colour map under the reference's file names (ISPRS palette, isprs:118-139), plus the class ids as .npy
+            from . import datasets
+            stem = ("top_mosaic_09cm_area" + str(testing_instances[k]) + "_class" if dataset == "vaihingen"
+                    else "top_potsdam_" + str(testing_instances[k]) + "_label")
+            datasets.create_prediction_map(output_path + stem + ".tif", maps[-1])
+            np.save(output_path + stem + ".npy", maps[-1])
     return maps

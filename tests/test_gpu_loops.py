@@ -220,6 +220,10 @@ def test_cli_training_then_validate_test_then_final_maps(tmp_path, monkeypatch, 
     maps2 = cli.main(common + [out + "model-3"] + tail + ["generate_final_maps"], device=DEV)
     np.testing.assert_array_equal(maps2[0], maps[0])
     assert os.path.isfile(out + "top_mosaic_09cm_areac_class.npy")
+    from PIL import Image
+    from drs_amd.datasets import ISPRS_PALETTE
+    rgb = np.asarray(Image.open(out + "top_mosaic_09cm_areac_class.tif"))          # the reference's file name and palette (isprs:1950, 118-139)
+    np.testing.assert_array_equal(rgb, ISPRS_PALETTE[maps2[0]])
     text = capsys.readouterr().out
     assert "Test ALL MAPS" in text and "net_type" in text
     with pytest.raises(SystemExit):
