@@ -209,7 +209,13 @@ def main():
     from drs_amd.dist import TorchComm, shard_slice
 
     comm = None
-    if world > 1:
+    # DRS_FORCE_COLLECTIVES=1 at N = 1: every collective of the step is issued through RCCL anyway (identities on the data): what the
+    # collectives' launches and stream hand-overs cost a rank, measurable on a one-GPU box; the JSON line says so
+    forced = world == 1 and os.environ.get("DRS_FORCE_COLLECTIVES") == "1"
+    if forced:
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(k, v)
+    if world > 1 or forced:
         comm = TorchComm("gloo" if rehearsal else "nccl")
     rank = comm.rank if comm else 0
     B_local = GLOBAL_BATCH // world
@@ -357,7 +363,8 @@ def main():
             "config": {"workload": "dilated_grsl_rate8 (Dilated8Pooling) training step, single_fixed 64x64, 5-band synthetic "
                                    "2048x2048 tile, global batch 128 (crop+augment+normalise, fwd, loss, bwd, momentum, confusion)",
                        "global_batch": GLOBAL_BATCH, "patch": PATCH, "bands": CHANNELS, "classes": CLASSES,
-                       "parallelism": "dp%d" % world + (" (REHEARSAL: all ranks on one GPU over gloo)" if rehearsal else ""),
+                       "parallelism": "dp%d" % world + (" (REHEARSAL: all ranks on one GPU over gloo)" if rehearsal else "")
+                                      + (" (collectives forced through RCCL at world 1)" if forced else ""),
                        "sync_bn": True},
             "val_pixels_per_sec": round(val_pixels_per_s, 1), "final_loss": round(loss, 5),
             "workspace_gb_per_gpu": round(net.workspace_bytes() / 1e9, 2),

@@ -366,17 +366,99 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ wgrad
+// How the pixel dimension of the filter gradient is cut into workgroups.  A tile of filter rows meets image data only in the
+// live rows of every image (live_pixel_range); with the dead chunks skipped, equal chunk ranges make unequal workgroups, and a
+// launch that fits the chip in one or two rounds then ends with its longest ones (measured: skipping LOST time below 2^19
+// pixels).  So the cut is by LIVE pixels: row tiles fall into classes by their live pixels per image (<= WG_MAXC distinct values:
+// tap rows entirely inside / reaching over the top / the bottom edge), class c is cut into n[c] splits of equal live-pixel
+// count, n[c] proportional to the class's live pixels, and every workgroup of the launch then has the same length.
+// Workgroup order stays split-major (the tiles of one split read the same pixels at the same time, which is what keeps X and G
+// in L2): classes are sorted by n ascending, levels [n[j-1], n[j]) hold the row tiles of classes >= j.
+constexpr int WG_MAXT = 64, WG_MAXC = 8;
+struct WgradPlan {
+  int nclass;                           // 0: every row tile has `nsplit` equal chunk ranges (chunks_per_split)
+  int n[WG_MAXC];                       // splits of class c, ascending
+  int seg_start[WG_MAXC + 1];           // first workgroup of segment j = levels n[j-1] .. n[j] - 1
+  int seg_width[WG_MAXC];               // workgroups per level in segment j
+  unsigned char cls[WG_MAXT];           // class of row tile r
+};
+
 struct WgradArgs {
   const float* x; int S, Px, ld_x, coff_x;
   const float* g; int Pg, ld_g, coff_g;
   int M;
   int k, rate, pad, Cin, Cout;
-  float* slab;               // [nsplit][k*k*Cin][Cout]
-  int chunks_per_split;      // 32-pixel chunks per split
+  float* slab;               // [split][k*k*Cin][Cout]
+  int chunks_per_split;      // 32-pixel chunks per split (uniform cut)
   int ntr, nto;
-  int skip_halo;
+  int skip_halo;             // the walk jumps over the dead chunks (0: it multiplies their zeros -- same sums, bitwise)
+  int live_cut;              // the live ranges shape the cut (plan) whether or not the walk skips
   float rcpS, rcpSS;
+  WgradPlan plan;
 };
+
+// workgroup id -> (tile, split), the split's chunk range [cbeg, cend) and the tile's live pixel range
+__host__ __device__ __forceinline__ int wave_uniform(int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_readfirstlane(v);
+#else
+  return v;
+#endif
+}
+
+__host__ __device__ __forceinline__ void wgrad_assign(const WgradArgs& a, int TR, int id, int& tile, int& split, int& cbeg, int& cend,
+                                                      int& live_lo, int& live_hi) {
+  const int nchunks_total = (a.M + 31) / 32;
+  const int rows_all = a.k * a.k * a.Cin;
+  int nr = 0;
+  if (a.plan.nclass == 0) {
+    const int ntile = a.ntr * a.nto;
+    split = id / ntile;
+    tile = id % ntile;
+  } else {
+    int j = 0;
+    while (j + 1 < a.plan.nclass && id >= a.plan.seg_start[j + 1]) ++j;
+    const int rel = id - a.plan.seg_start[j];
+    split = (j ? a.plan.n[j - 1] : 0) + rel / a.plan.seg_width[j];
+    const int pos = rel % a.plan.seg_width[j];
+    const int want = pos / a.nto;
+    int r = 0, seen = 0;
+    for (; r < a.ntr; ++r)
+      if (a.plan.cls[r] >= j) { if (seen == want) break; ++seen; }
+    tile = r * a.nto + pos % a.nto;
+    nr = a.plan.n[a.plan.cls[r]];
+  }
+  tile = wave_uniform(tile);
+  split = wave_uniform(split);
+  const int R0 = (tile / a.nto) * TR;
+  const int rlast = (R0 + TR < rows_all ? R0 + TR : rows_all) - 1;
+  int lo, hi;
+  live_pixel_range(R0, rlast, a.Cin, a.k, a.rate, a.pad, a.S, a.live_cut, lo, hi);
+  if (a.plan.nclass == 0) {
+    cbeg = split * a.chunks_per_split;
+    cend = cbeg + a.chunks_per_split;
+    cend = cend < nchunks_total ? cend : nchunks_total;
+  } else {
+    // split s of nr owns the live pixels [s q, (s+1) q) of the tile, counted through the images in order; the chunk that holds a
+    // boundary pixel starts the later split (every chunk then belongs to exactly one split, dead ones included)
+    const int S2 = a.S * a.S, lp = hi - lo;
+    const int live_total = (a.M / S2) * lp;
+    const int q = (live_total + nr - 1) / nr;
+    auto bound = [&](int s) -> int {
+      if (s <= 0) return 0;
+      const long long jp = (long long)s * q;
+      if (s >= nr || jp >= live_total) return nchunks_total;
+      const int img = (int)jp / lp, rem = (int)jp - img * lp;
+      return (img * S2 + lo + rem) >> 5;
+    };
+    cbeg = bound(split);
+    cend = bound(split + 1);
+  }
+  cbeg = wave_uniform(cbeg);
+  cend = wave_uniform(cend);
+  if (!a.skip_halo) { lo = 0; hi = a.S * a.S; }
+  live_lo = lo; live_hi = hi;
+}
 
 // Walk over the 32-pixel chunks of a pixel range that meet the live rows [lo, hi) of some image (drs_common.hpp), kept entirely in
 // wave-uniform integers: no division after init(), so the walk costs scalar-ALU instructions only.  c = chunk index; (b, r) =
@@ -446,10 +528,8 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   const int li = lane & 31, h = lane >> 5;
   const int wr = wave / WC, wc = wave % WC;
 
-  const int ntile = a.ntr * a.nto;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int split = __builtin_amdgcn_readfirstlane(id / ntile);
-  const int tile = __builtin_amdgcn_readfirstlane(id % ntile);
+  int tile, split, cbeg, cend, live_lo, live_hi;
+  wgrad_assign(a, TR, xcd_remap(blockIdx.x, gridDim.x), tile, split, cbeg, cend, live_lo, live_hi);
   const int R0 = (tile / a.nto) * TR;         // first row of the [k*k*Cin] dimension; a tile may span several taps
   const int o0 = (tile % a.nto) * TO;         // and the last one may be ragged (rows beyond k*k*Cin are not stored)
   const int rows_all = a.k * a.k * a.Cin;
@@ -478,15 +558,7 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   const int nchunks_total = (a.M + BP - 1) / BP;
-  const int cbeg = split * a.chunks_per_split;
-  int cend = cbeg + a.chunks_per_split;
-  cend = cend < nchunks_total ? cend : nchunks_total;
   const int clast = (a.M & 31) ? nchunks_total - 1 : -1;     // the one chunk that holds pixels past the end, if any
-  int live_lo, live_hi;
-  {
-    const int rlast = (R0 + TR < rows_all ? R0 + TR : rows_all) - 1;
-    live_pixel_range(R0, rlast, a.Cin, a.k, a.rate, a.pad, a.S, a.skip_halo, live_lo, live_hi);
-  }
   ChunkWalk w;
   w.init(cbeg, a.S, a.rcpS, a.rcpSS, live_lo, live_hi);
 
@@ -642,10 +714,8 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   const int li = lane & 31, h = lane >> 5;
   const int wr = wave / WC, wc = wave % WC;
 
-  const int ntile = a.ntr * a.nto;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int split = __builtin_amdgcn_readfirstlane(id / ntile);
-  const int tile = __builtin_amdgcn_readfirstlane(id % ntile);
+  int tile, split, cbeg, cend, live_lo, live_hi;
+  wgrad_assign(a, TR, xcd_remap(blockIdx.x, gridDim.x), tile, split, cbeg, cend, live_lo, live_hi);
   const int R0 = (tile / a.nto) * TR;
   const int o0 = (tile % a.nto) * TO;
   const int rows_all = a.k * a.k * a.Cin;
@@ -683,15 +753,7 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   const int nchunks_total = (a.M + BP - 1) / BP;
-  const int cbeg = split * a.chunks_per_split;
-  int cend = cbeg + a.chunks_per_split;
-  cend = cend < nchunks_total ? cend : nchunks_total;
   const int clast = (a.M & 31) ? nchunks_total - 1 : -1;
-  int live_lo, live_hi;
-  {
-    const int rlast = (R0 + TR < rows_all ? R0 + TR : rows_all) - 1;
-    live_pixel_range(R0, rlast, a.Cin, a.k, a.rate, a.pad, a.S, a.skip_halo, live_lo, live_hi);
-  }
   ChunkWalk w;
   w.init(cbeg, a.S, a.rcpS, a.rcpSS, live_lo, live_hi);
 
@@ -834,14 +896,15 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
 }
 
 // grad[tap][c][o] = sum over splits (fixed order) of slab[split][tap][c (of cin_pad)][o], c < cin_real
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, int nsplit, int taps,
-                                    int cin_pad, int cin_real, int cout) {
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, int nsplit_all, int taps,
+                                    int cin_pad, int cin_real, int cout, int tr, const WgradPlan plan) {
   const int n = taps * cin_real * cout;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int o = i % cout;
     const int rc = i / cout;
     const int c = rc % cin_real, tap = rc / cin_real;
     const size_t src = ((size_t)tap * cin_pad + c) * cout + o;
+    const int nsplit = plan.nclass ? plan.n[plan.cls[(tap * cin_pad + c) / tr]] : nsplit_all;     // the splits this row's tile wrote
     const size_t stride = (size_t)taps * cin_pad * cout;
     // the sum runs in split order (fixed, so a step is reproducible); the loads of 8 splits are in flight together
     float s = 0.f;
@@ -899,19 +962,19 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
 int g_wgrad_variant = -1;    // development switch (drs_debug_wgrad_variant): 0 = register-staged tiles, 1 = LDS-DMA double-buffered halves, -1 = per tile
 
 template <int TR, int TO>
-int launch_wgrad(const WgradArgs& a, int nsplit, hipStream_t st) {
+int launch_wgrad(const WgradArgs& a, int nwg, hipStream_t st) {
   constexpr int NT = 64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1);
   // in-process A/B at B = 128 (profiles/r02/wgrad_ablation.txt): the LDS-DMA form wins 3-6 % on the 128-wide tiles and loses 7-10 % on the
   // 64-wide ones (Cout = 64, 192), so each layer takes the form that is faster for its tile
   const bool dma = g_wgrad_variant < 0 ? TO == 128 : g_wgrad_variant == 1;
-  if (!dma) DRS_LAUNCH((wgrad_kernel<TR, TO>), dim3(nsplit * a.ntr * a.nto), dim3(NT), 0, st, a);
-  else DRS_LAUNCH((wgrad_dma_kernel<TR, TO>), dim3(nsplit * a.ntr * a.nto), dim3(NT), 0, st, a);
+  if (!dma) DRS_LAUNCH((wgrad_kernel<TR, TO>), dim3(nwg), dim3(NT), 0, st, a);
+  else DRS_LAUNCH((wgrad_dma_kernel<TR, TO>), dim3(nwg), dim3(NT), 0, st, a);
   return DRS_LAUNCH_CHECK();
 }
 
 template <int TR, int TO>
-int launch_wgrad_dma_only(const WgradArgs& a, int nsplit, hipStream_t st) {
-  DRS_LAUNCH((wgrad_dma_kernel<TR, TO>), dim3(nsplit * a.ntr * a.nto), dim3(256), 0, st, a);
+int launch_wgrad_dma_only(const WgradArgs& a, int nwg, hipStream_t st) {
+  DRS_LAUNCH((wgrad_dma_kernel<TR, TO>), dim3(nwg), dim3(256), 0, st, a);
   return DRS_LAUNCH_CHECK();
 }
 
@@ -938,6 +1001,152 @@ int pick_wgrad_rows(int rows) {
 // tile 64 x 96: 6 MFMAs per 5 fragment reads, 320 operand floats per pixel for 24576 products) instead of three 64-wide ones
 int pick_wgrad_cols(int tr, int cout) { return (tr == 128 && cout % 192 == 0 && cout % 128 != 0 && g_wgrad_variant != 0) ? 192 : pick_tile(cout); }
 
+int g_wgrad_balance = 1;     // development switch (drs_debug_wgrad_balance): 0 = equal chunk ranges (and the old rule for skipping), 1 = cut by live pixels
+int g_wgrad_target_big = 0;  // development switch: workgroups aimed at on launches with many tiles and pixels under the live cut (0 = default)
+
+// workgroups a filter-gradient launch of `work` chunk-tiles (32-pixel chunks x tiles) aims at
+int wgrad_target(long long work, int ntile, int nchunks, bool balanced) {
+  // fill the 256 CUs evenly.  Small launches (the per-rank batches of data parallelism) want long workgroups more than many:
+  // >= 96 chunks each, down to one round of 512 (sweeps at B = 16 / 32 in profiles/r02/wgrad_ablation.txt).  Launches with many
+  // tiles and pixels: with equal chunk ranges and the dead chunks skipped the workgroups differ in length by up to a quarter and
+  // two rounds quantise the gain away, so twice as many (measured at B = 128: conv6 3.48 -> 3.01 ms, conv8 5.19 -> 4.85).
+  long long fit = work / 96;
+  fit = fit < 512 ? 512 : (fit > g_wgrad_target ? g_wgrad_target : fit);
+  const bool big = ntile >= 24 && nchunks >= 8192;
+  if (!balanced) return big ? 2 * g_wgrad_target : (int)fit;
+  // equal-length workgroups: the chip holds 4 x 256 of them, and one workgroup over a whole number of rounds costs a round
+  // (measured: 513 workgroups instead of 507 +27 %, 2049 instead of 2030 +7 %), so aim AT a whole number of workgroups per CU
+  // (one round) or of rounds, and never above it (wgrad_live_plan rounds the splits down)
+  if (big) return g_wgrad_target_big ? g_wgrad_target_big : 3 * 1024;
+  static const int steps[] = {512, 768, 1024, 2048, 3072, 4096};
+  int best = steps[0];
+  for (int s : steps)
+    if (s <= g_wgrad_target && (double)(s > fit ? s : fit) / (s > fit ? fit : s) < (double)(best > fit ? best : fit) / (best > fit ? fit : best)) best = s;
+  return best;
+}
+
+// equal chunk ranges: the number of splits.  Never less than 32 chunks (1024 pixels) per split.
+int wgrad_uniform_splits(int B, int S, int k, int cin, int cout) {
+  const long long M = (long long)B * S * S;
+  const int tr = pick_wgrad_rows(k * k * cin), to = pick_wgrad_cols(tr, cout);
+  const int ntile = ((k * k * cin + tr - 1) / tr) * (cout / to);
+  const int nchunks = (int)((M + 31) / 32);
+  int want = wgrad_target((long long)nchunks * ntile, ntile, nchunks, false) / ntile;
+  int maxs = (nchunks + 31) / 32;
+  if (maxs < 1) maxs = 1;
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  const int cps = (nchunks + want - 1) / want;
+  return (nchunks + cps - 1) / cps;
+}
+
+// the cut by live pixels (WgradPlan); false = not applicable (too many row tiles / classes, or nothing to skip): use the equal cut
+bool wgrad_live_plan(int B, int S, int k, int rate, int pad, int cin, int cout, int tr, int to, int cap, WgradPlan& p, int& nwg) {
+  const int rows = k * k * cin, ntr = (rows + tr - 1) / tr, nto = cout / to;
+  p.nclass = 0;
+  if (ntr > WG_MAXT) return false;
+  int lp[WG_MAXT], vals[WG_MAXC], nv = 0;
+  for (int r = 0; r < ntr; ++r) {
+    int lo, hi;
+    const int rlast = ((r + 1) * tr < rows ? (r + 1) * tr : rows) - 1;
+    live_pixel_range(r * tr, rlast, cin, k, rate, pad, S, 1, lo, hi);
+    lp[r] = hi - lo;
+    int c = 0;
+    while (c < nv && vals[c] != lp[r]) ++c;
+    if (c == nv) { if (nv == WG_MAXC) return false; vals[nv++] = lp[r]; }
+  }
+  if (nv == 1 && vals[0] == S * S) return false;            // every tile meets every pixel: the equal cut is the live cut
+  for (int i = 1; i < nv; ++i)                              // classes ascending by live pixels (so by splits)
+    for (int j = i; j > 0 && vals[j] < vals[j - 1]; --j) { const int t = vals[j]; vals[j] = vals[j - 1]; vals[j - 1] = t; }
+  int cnt[WG_MAXC] = {0};
+  for (int r = 0; r < ntr; ++r) {
+    int c = 0;
+    while (vals[c] != lp[r]) ++c;
+    p.cls[r] = (unsigned char)c;
+    ++cnt[c];
+  }
+  const long long M = (long long)B * S * S;
+  const int nchunks = (int)((M + 31) / 32);
+  double work = 0;                                          // live chunk-tiles of the launch
+  for (int c = 0; c < nv; ++c) work += (double)cnt[c] * nto * B * vals[c] / 32.0;
+  const int target = wgrad_target((long long)work, ntr * nto, nchunks, true);
+  const double len = work / target;                          // chunks per workgroup
+  int maxs = (nchunks + 31) / 32;
+  if (maxs > cap) maxs = cap;
+  if (maxs < 1) maxs = 1;
+  double frac[WG_MAXC];
+  int total = 0;
+  for (int c = 0; c < nv; ++c) {                             // rounded down: never more workgroups than aimed at ...
+    const double x = (double)B * vals[c] / 32.0 / len;
+    int n = (int)x;
+    frac[c] = x - n;
+    if (n > maxs) { n = maxs; frac[c] = 0; }
+    if (n < 1) { n = 1; frac[c] = 0; }
+    p.n[c] = n;
+    total += n * cnt[c] * nto;
+  }
+  for (;;) {                                                 // ... then the classes nearest their next split take one more while it fits
+    int pick = -1;
+    for (int c = 0; c < nv; ++c)
+      if (frac[c] > 0 && p.n[c] < maxs && total + cnt[c] * nto <= target && (c + 1 == nv || p.n[c] < p.n[c + 1]) && (pick < 0 || frac[c] > frac[pick])) pick = c;
+    if (pick < 0) break;
+    ++p.n[pick];
+    total += cnt[pick] * nto;
+    frac[pick] = 0;
+  }
+  for (int c = 1; c < nv; ++c)
+    if (p.n[c] < p.n[c - 1]) p.n[c] = p.n[c - 1];             // (ascending by construction; stay safe)
+  int above = ntr, start = 0;                               // row tiles of classes >= j
+  for (int j = 0; j < nv; ++j) {
+    p.seg_start[j] = start;
+    p.seg_width[j] = above * nto;
+    start += (p.n[j] - (j ? p.n[j - 1] : 0)) * above * nto;
+    above -= cnt[j];
+  }
+  p.seg_start[nv] = start;
+  p.nclass = nv;
+  nwg = start;
+  return true;
+}
+
+int wgrad_bound_splits(int B, int S, int k, int cin, int cout) {
+  const int u = wgrad_uniform_splits(B, S, k, cin, cout);
+  int maxs = (int)(((long long)B * S * S + 1023) / 1024);
+  if (maxs < 1) maxs = 1;
+  const int bound = u + u / 2 + 1;
+  return bound < maxs ? bound : (maxs > u ? maxs : u);
+}
+
+// everything of a filter-gradient launch that follows from the shape: tile sizes, the cut, the workgroup count
+int wgrad_setup(int B, int S, int k, int rate, int pad_before, int cin, int cout, WgradArgs& a, int& nwg, int& tr, int& to, int& nsplit) {
+  if ((cin % 32 && cin != 8 && cin != 16) || cout % 32 || B < 1 || S < 1 || k < 1 || rate < 1) return DRS_ERR_ARG;
+  const long long M = (long long)B * S * S;
+  if (M <= 0 || M >= (1 << 24)) return DRS_ERR_ARG;
+  a.x = nullptr; a.g = nullptr; a.slab = nullptr; a.Px = a.Pg = a.ld_x = a.ld_g = a.coff_x = a.coff_g = 0;
+  a.S = S; a.M = (int)M;
+  a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout;
+  tr = pick_wgrad_rows(k * k * cin); to = pick_wgrad_cols(tr, cout);
+  a.ntr = (k * k * cin + tr - 1) / tr; a.nto = cout / to;
+  nsplit = wgrad_uniform_splits(B, S, k, cin, cout);
+  const int nchunks = (int)((M + 31) / 32);
+  a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
+  a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
+  // the cut: by live pixels (every workgroup of the launch the same length, the dead chunks skipped at any size), or equal chunk
+  // ranges where that does not apply; development switches: drs_debug_wgrad_balance(0) = the equal cut with the dead chunks
+  // skipped from 2^19 pixels only, drs_debug_skip_taps(0) = same cut, the dead chunks multiplied (same sums: bitwise)
+  nwg = nsplit * a.ntr * a.nto;
+  a.plan.nclass = 0;
+  a.live_cut = 0;
+  if (g_wgrad_balance && wgrad_live_plan(B, S, k, rate, pad_before, cin, cout, tr, to, wgrad_bound_splits(B, S, k, cin, cout), a.plan, nwg)) {
+    a.live_cut = 1;
+    a.skip_halo = drs_g_skip_halo_taps != 0;
+  } else {
+    a.skip_halo = drs_skip_halo_taps_wgrad(M);
+    a.live_cut = a.skip_halo;
+  }
+  return DRS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -946,6 +1155,10 @@ extern "C" {
 int drs_debug_skip_taps(int v) { const int old = drs_g_skip_halo_taps; if (v >= 0) drs_g_skip_halo_taps = v; return old; }
 
 int drs_debug_wgrad_target(int v) { const int old = g_wgrad_target; if (v > 0) g_wgrad_target = v; return old; }
+
+int drs_debug_wgrad_balance(int v) { const int old = g_wgrad_balance; if (v >= 0) g_wgrad_balance = v; return old; }
+
+int drs_debug_wgrad_target_big(int v) { const int old = g_wgrad_target_big; if (v >= 0) g_wgrad_target_big = v; return old; }
 
 int drs_debug_conv_variant(int v) { const int old = g_conv_variant; if (v >= -1) g_conv_variant = v; return old; }
 
@@ -979,65 +1192,56 @@ int drs_conv_forward(const float* in, int B, int S, int P, int ld_in, int coff_i
   }
 }
 
-// number of pixel splits (= slab count) drs_conv_wgrad will use; workspace = nsplit * k*k*cin * cout floats
-int drs_conv_wgrad_splits(int B, int S, int k, int cin, int cout) {
-  const long long M = (long long)B * S * S;
-  const int tr = pick_wgrad_rows(k * k * cin), to = pick_wgrad_cols(tr, cout);
-  const int ntile = ((k * k * cin + tr - 1) / tr) * (cout / to);
-  const int nchunks = (int)((M + 31) / 32);
-  // fill the 256 CUs evenly.  6 workgroups per CU (2 rounds at 3 resident) where a launch has few tiles or few pixels; twice that
-  // where it has many tiles and pixels: with the all-halo chunks skipped its workgroups differ in length by up to a quarter and 2
-  // rounds quantise the gain away (measured at B = 128: conv6 3.48 -> 3.01 ms, conv8 5.19 -> 4.85; conv3, 8 tiles, loses 6 %).
-  // Never less than 32 chunks (1024 pixels) per split.
-  // ... and small launches (the per-rank batches of data parallelism) want long workgroups more than many: >= 96 chunks each, down
-  // to one round of 512 (sweeps at B = 16 / 32 in profiles/r02/wgrad_ablation.txt)
-  long long fit = (long long)nchunks * ntile / 96;
-  fit = fit < 512 ? 512 : (fit > g_wgrad_target ? g_wgrad_target : fit);
-  const int target = (ntile >= 24 && nchunks >= 8192) ? 2 * g_wgrad_target : (int)fit;
-  int want = target / ntile;
-  int maxs = (nchunks + 31) / 32;
-  if (maxs < 1) maxs = 1;
-  if (want > maxs) want = maxs;
-  if (want < 1) want = 1;
-  const int cps = (nchunks + want - 1) / want;
-  return (nchunks + cps - 1) / cps;
+// upper bound of the splits any row tile of this layer is cut into, whatever its rate / padding (the cut by live pixels may give
+// the full tiles more splits than the equal cut has: up to half as many again): workspace = that many * k*k*cin * cout floats
+int drs_conv_wgrad_splits(int B, int S, int k, int cin, int cout) { return wgrad_bound_splits(B, S, k, cin, cout); }
+
+/* development aid (not part of the documented ABI): the workgroups drs_conv_wgrad would launch for this shape, worked out on the
+   host by the kernels' own assignment code: out[5 i ..] = (row tile, column tile, split, first chunk, end chunk) of workgroup i,
+   out_tile_splits[r] = splits of row tile r.  Returns the number of workgroups (also when it exceeds cap; nothing is then written
+   past cap), negative on a rejected shape. */
+int drs_debug_wgrad_cut(int B, int S, int k, int rate, int pad_before, int cin, int cout, int* out, int cap, int* out_tile_splits,
+                        int* out_tile_rows) {
+  WgradArgs a;
+  int nwg, tr, to, nsplit;
+  if (wgrad_setup(B, S, k, rate, pad_before, cin, cout, a, nwg, tr, to, nsplit)) return -1;
+  if (out_tile_rows) *out_tile_rows = tr;
+  for (int r = 0; r < a.ntr && out_tile_splits; ++r) out_tile_splits[r] = a.plan.nclass ? a.plan.n[a.plan.cls[r]] : nsplit;
+  for (int i = 0; i < nwg && i < cap && out; ++i) {
+    int tile, split, cbeg, cend, lo, hi;
+    wgrad_assign(a, tr, i, tile, split, cbeg, cend, lo, hi);
+    out[5 * i] = tile / a.nto; out[5 * i + 1] = tile % a.nto; out[5 * i + 2] = split; out[5 * i + 3] = cbeg; out[5 * i + 4] = cend;
+  }
+  return nwg;
 }
 
 int drs_conv_wgrad(const float* x, int B, int S, int Px, int ld_x, int coff_x, const float* g, int Pg, int ld_g,
                    int coff_g, int k, int rate, int pad_before, int cin, int cin_real, int cout, float* slab,
                    float* grad, void* stream) {
-  if (!x || !g || !slab || !grad || (cin % 32 && cin != 8 && cin != 16) || cout % 32 || cin_real > cin) return DRS_ERR_ARG;
-  const long long M = (long long)B * S * S;
-  if (M <= 0 || M >= (1 << 24)) return DRS_ERR_ARG;
+  if (!x || !g || !slab || !grad || cin_real > cin) return DRS_ERR_ARG;
   if ((long long)B * (S + 2 * Px) * (S + 2 * Px) * ld_x >= (1LL << 30)) return DRS_ERR_ARG;     // 32-bit BYTE offsets (slabs < 4 GiB)
   if ((long long)B * (S + 2 * Pg) * (S + 2 * Pg) * ld_g >= (1LL << 30)) return DRS_ERR_ARG;
   WgradArgs a;
-  a.x = x; a.S = S; a.Px = Px; a.ld_x = ld_x; a.coff_x = coff_x;
-  a.g = g; a.Pg = Pg; a.ld_g = ld_g; a.coff_g = coff_g; a.M = (int)M;
-  a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout; a.slab = slab;
-  const int tr = pick_wgrad_rows(k * k * cin), to = pick_wgrad_cols(tr, cout);
-  a.ntr = (k * k * cin + tr - 1) / tr; a.nto = cout / to;
-  const int nsplit = drs_conv_wgrad_splits(B, S, k, cin, cout);
-  const int nchunks = (int)((M + 31) / 32);
-  a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
-  a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
-  a.skip_halo = drs_skip_halo_taps_wgrad(M);
+  int nwg, tr, to, nsplit;
+  if (wgrad_setup(B, S, k, rate, pad_before, cin, cout, a, nwg, tr, to, nsplit)) return DRS_ERR_ARG;
+  a.x = x; a.Px = Px; a.ld_x = ld_x; a.coff_x = coff_x;
+  a.g = g; a.Pg = Pg; a.ld_g = ld_g; a.coff_g = coff_g; a.slab = slab;
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (tr == 128 && to == 192) rc = launch_wgrad_dma_only<128, 192>(a, nsplit, st);
-  else if (tr == 128 && to == 128) rc = launch_wgrad<128, 128>(a, nsplit, st);
-  else if (tr == 128 && to == 64) rc = launch_wgrad<128, 64>(a, nsplit, st);
-  else if (tr == 128 && to == 32) rc = launch_wgrad<128, 32>(a, nsplit, st);
-  else if (tr == 64 && to == 128) rc = launch_wgrad<64, 128>(a, nsplit, st);
-  else if (tr == 64 && to == 64) rc = launch_wgrad<64, 64>(a, nsplit, st);
-  else if (tr == 64 && to == 32) rc = launch_wgrad<64, 32>(a, nsplit, st);
-  else if (tr == 32 && to == 128) rc = launch_wgrad<32, 128>(a, nsplit, st);
-  else if (tr == 32 && to == 64) rc = launch_wgrad<32, 64>(a, nsplit, st);
-  else rc = launch_wgrad<32, 32>(a, nsplit, st);
+  if (tr == 128 && to == 192) rc = launch_wgrad_dma_only<128, 192>(a, nwg, st);
+  else if (tr == 128 && to == 128) rc = launch_wgrad<128, 128>(a, nwg, st);
+  else if (tr == 128 && to == 64) rc = launch_wgrad<128, 64>(a, nwg, st);
+  else if (tr == 128 && to == 32) rc = launch_wgrad<128, 32>(a, nwg, st);
+  else if (tr == 64 && to == 128) rc = launch_wgrad<64, 128>(a, nwg, st);
+  else if (tr == 64 && to == 64) rc = launch_wgrad<64, 64>(a, nwg, st);
+  else if (tr == 64 && to == 32) rc = launch_wgrad<64, 32>(a, nwg, st);
+  else if (tr == 32 && to == 128) rc = launch_wgrad<32, 128>(a, nwg, st);
+  else if (tr == 32 && to == 64) rc = launch_wgrad<32, 64>(a, nwg, st);
+  else rc = launch_wgrad<32, 32>(a, nwg, st);
   if (rc) return rc;
   const int n = k * k * cin_real * cout;
   DRS_LAUNCH(wgrad_reduce_kernel, dim3((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), dim3(256), 0, st, slab,
-                     grad, nsplit, k * k, cin, cin_real, cout);
+                     grad, nsplit, k * k, cin, cin_real, cout, tr, a.plan);
   return DRS_LAUNCH_CHECK();
 }
 

@@ -84,8 +84,8 @@ __device__ __forceinline__ void live_tap_rows(int m0, int BM, int M, int S, int 
 // Filter gradient: a tile of filter rows belongs to tap rows u_first .. u_last; pixel rows y whose shifted rows y + u*rate - pad
 // all fall outside the image meet only halo zeros in X.  [lo, hi) = the pixel range (inside one image of S*S pixels) of the rows
 // that do meet image data; everything outside contributes exact zeros and is never fetched.
-__device__ __forceinline__ void live_pixel_range(int row_first, int row_last, int Cin, int k, int rate, int pad, int S, int enable,
-                                                 int& lo, int& hi) {
+__host__ __device__ __forceinline__ void live_pixel_range(int row_first, int row_last, int Cin, int k, int rate, int pad, int S, int enable,
+                                                          int& lo, int& hi) {
   const int dy_min = (row_first / Cin / k) * rate - pad, dy_max = (row_last / Cin / k) * rate - pad;
   int ylo = -dy_max > 0 ? -dy_max : 0;
   int yhi = S - dy_min < S ? S - dy_min : S;

@@ -368,9 +368,13 @@ struct Timed {
 
 #define DRS_TRY(expr) do { const int rc_ = (expr); if (rc_ != DRS_OK) return rc_; } while (0)
 
+// every sum over ranks goes through the host's callback; with a callback installed it does so at world == 1 too (an identity there:
+// lets a one-GPU box drive the whole collective path, RCCL included)
+inline bool collectives(const drs_net* n) { return n->world > 1 || n->allreduce != nullptr; }
+
 int all_reduce(drs_net* n, void* ptr, size_t count, int dtype, int async, hipStream_t st, int* handle) {
   if (handle) *handle = -1;
-  if (n->world <= 1) return DRS_OK;
+  if (!collectives(n)) return DRS_OK;
   if (!n->allreduce) return DRS_ERR_ARG;
   const int h = n->allreduce(n->comm_user, ptr, count, dtype, async, st);
   if (h < 0) return DRS_ERR_HIP;
@@ -379,7 +383,7 @@ int all_reduce(drs_net* n, void* ptr, size_t count, int dtype, int async, hipStr
 }
 
 int wait_handles(drs_net* n, const std::vector<int>& hs, hipStream_t st) {
-  if (n->world <= 1 || !n->wait) return DRS_OK;
+  if (!collectives(n) || !n->wait) return DRS_OK;
   for (int h : hs)
     if (h >= 0 && n->wait(n->comm_user, h, st) != 0) return DRS_ERR_HIP;
   return DRS_OK;
@@ -411,7 +415,7 @@ int forward_layers(drs_net* n, int B, int S, bool training, double count, hipStr
     }
     float* mm = bn + L.bn_off;
     float* mv = mm + L.cout;
-    if (training && n->world == 1) {
+    if (training && !collectives(n)) {
       DRS_TRY(drs_conv_stats_finish(partial, (int)M, drs_conv_mtile(L.cout), L.cout, count, mr, mm, mv, BN_DECAY, n->bessel, nullptr, st));
     } else if (training) {
       DRS_TRY(drs_conv_stats_reduce(partial, (int)M, drs_conv_mtile(L.cout), L.cout, sums, nullptr, st));
@@ -720,7 +724,7 @@ int drs_train_step(drs_net_t* n, int B, int S, float lr0, int flags, double glob
       DRS_TRY(drs_conv_wgrad(n->p<float>("act:" + in.name), B, S, in.P, in.C, 0, gz, L.halo, L.cout, 0, L.k, L.rate, L.pad_b, L.cin_k, L.cin, L.cout,
                              n->p<float>("slab"), grads + L.w_off, st));
     }
-    if (n->world > 1 && i > 0 && (nL - i) % 2 == 0) {      // every second layer: one bucket
+    if (collectives(n) && i > 0 && (nL - i) % 2 == 0) {      // every second layer: one bucket
       int h;
       DRS_TRY(all_reduce(n, grads + L.w_off, bucket_hi - L.w_off, F32, 1, st, &h));
       pending.push_back(h);
@@ -780,7 +784,7 @@ int drs_train_step(drs_net_t* n, int B, int S, float lr0, int flags, double glob
     deferred = i;
   }
   DRS_TRY(filter_gradient(deferred));
-  if (n->world > 1) {
+  if (collectives(n)) {
     int h;
     DRS_TRY(all_reduce(n, grads, bucket_hi, F32, 1, st, &h));                         // the remaining (earliest) layers
     pending.push_back(h);

@@ -29,12 +29,15 @@ class TorchComm(object):
                 dist.init_process_group(backend=backend)
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
+        # DRS_FORCE_COLLECTIVES=1: issue every collective of the step at world 1 too (sums over one rank: identities).  A one-GPU box
+        # can then drive the real RCCL path -- communicator bound to the device, async work handles, stream waits -- end to end.
+        self.collective = self.world > 1 or os.environ.get("DRS_FORCE_COLLECTIVES") == "1"
         # The collectives of one communicator run in order on ITS stream: a 2 KB sync-BN sum issued behind a 4 MB gradient bucket
         # waits for the bucket.  In the step's schedule a bucket (~0.15 ms on 8 GPUs) is followed by >= 0.35 ms of kernels before the
         # next batch-norm sum is issued, so the queue is normally empty by then and ONE communicator is the default.  DRS_BN_COMM=1
         # gives the latency-bound sums (<= SMALL elements) a communicator of their own (they then overtake the buckets); it is opt-in
         # because no multi-GPU node was available to this build to measure either choice.
-        two = self.world > 1 and os.environ.get("DRS_BN_COMM") == "1"
+        two = self.collective and os.environ.get("DRS_BN_COMM") == "1"
         self.small = dist.new_group(ranks=list(range(self.world))) if two else None
 
     SMALL = 4096
@@ -43,14 +46,14 @@ class TorchComm(object):
         return self.small if t.numel() <= self.SMALL else None
 
     def all_reduce_sum(self, t):
-        if self.world > 1:
+        if self.collective:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self._group(t))
         return t
 
     def all_reduce_sum_async(self, t):
         """start a sum all-reduce on the collective's own stream (overlaps the kernels enqueued afterwards);
         returns a handle for wait()."""
-        if self.world > 1:
+        if self.collective:
             return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self._group(t), async_op=True)
         return None
 

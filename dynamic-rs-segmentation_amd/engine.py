@@ -67,7 +67,7 @@ class EngineNet(DilatedNet):
         assert (c0.value, p0.value) == p.buffers["x0"]
         self._gs_pending = getattr(self, "_gs_pending", 0)
         _lib.query("drs_net_global_step", self.h, int(self._gs_pending))
-        if self.comm.world > 1:
+        if self.comm.collective:
             self._install_comm()
 
     def _alloc(self):

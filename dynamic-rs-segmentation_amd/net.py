@@ -60,6 +60,7 @@ class NoComm(object):
     """Single-process stand-in for the collective interface (see dist.py)."""
     world = 1
     rank = 0
+    collective = False
 
     def all_reduce_sum(self, t):
         return t
@@ -411,7 +412,7 @@ class DilatedNet(object):
                         L.k, L.rate, L.pad_b, L.cin_k, L.cout, _ptr(self.z[i]), L.cout, 0, 0, _ptr(stats), st)
             bo = p.bn_offsets[L.name]
             mm, mv = self.bn[bo:bo + L.cout], self.bn[bo + L.cout:bo + 2 * L.cout]
-            if training and self.comm.world == 1:
+            if training and not self.comm.collective:
                 # tile statistics -> (mean, rstd) and the moving averages in one launch
                 _lib.call("drs_conv_stats_finish", _ptr(self.partial), M, self._mtile(i), L.cout, float(count), _ptr(self.mean_rstd[i]),
                           _ptr(mm), _ptr(mv), BN_DECAY, self.bessel, None, st)
@@ -547,7 +548,7 @@ class DilatedNet(object):
                 self._k("conv_wgrad", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_wgrad", _ptr(xin), B, S, Pin, ldin, cin_off,
                         _ptr(self.gz), L.halo, L.cout, 0, L.k, L.rate, L.pad_b, L.cin_k, L.cin, L.cout, _ptr(self.slab),
                         self.grads[goff:].data_ptr(), st)
-            if self.comm.world > 1 and i > 0 and (nL - i) % 2 == 0:                   # every second layer: one bucket
+            if self.comm.collective and i > 0 and (nL - i) % 2 == 0:                   # every second layer: one bucket
                 pending.append(self.comm.all_reduce_sum_async(self.grads[goff:bucket_hi]))
                 bucket_hi = goff
 
@@ -604,7 +605,7 @@ class DilatedNet(object):
                             acc, None, st)
             deferred_wgrad = (lambda i=i: filter_gradient(i))
         deferred_wgrad()
-        if self.comm.world > 1:
+        if self.comm.collective:
             pending.append(self.comm.all_reduce_sum_async(self.grads[0:bucket_hi]))      # the remaining (earliest) layers
             pending.append(self.comm.all_reduce_sum_async(self.grads[woff:]))            # classifier, SE layers and every bias (small)
             self.comm.all_reduce_sum(self.scalars[:1])

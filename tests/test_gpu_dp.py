@@ -60,6 +60,57 @@ def test_two_rank_step_equals_single_rank(tmp_path):
     np.testing.assert_array_equal(r["conf"], res["conf"].cpu().numpy())
 
 
+def _rccl_worker(rank, world, port, out, engine):
+    """ONE rank on the real backend ('nccl' = RCCL) with every collective of the step forced on (sums over one rank are identities):
+    communicator bound to the device, asynchronous gradient buckets, sync-BN sums, stream waits -- the code an 8-GPU run executes."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", DRS_FORCE_COLLECTIVES="1")
+    import torch.distributed as dist
+    from drs_amd.dist import TorchComm
+    from drs_amd.net import DilatedNet
+    torch.cuda.set_device(0)
+    comm = TorchComm("nccl")
+    assert comm.collective and comm.world == 1 and dist.get_backend() == "nccl"
+    x, y = _inputs()
+    d = DilatedNet(NET, CH, K, 0.005, b_max=B, s_max=S, device="cuda:0", seed=3, comm=comm, engine=engine)
+    calls = []
+    real = comm.all_reduce_sum_async
+    comm.all_reduce_sum_async = lambda t: (calls.append(t.numel()), real(t))[1]
+    losses = []
+    for _ in range(3):
+        d.feed(x, y, S)
+        res = d.train_step(B, S, 0.01)
+        losses.append(d.loss_value(res["loss_parts"]))
+    torch.cuda.synchronize()
+    assert len(calls) >= 3 * 3, calls                       # gradient buckets and backward BN sums went through the communicator
+    np.savez(out, grads=d.grads.cpu().numpy(), params=d.params.cpu().numpy(), bn=d.bn.cpu().numpy(), losses=np.asarray(losses),
+             conf=res["conf"].cpu().numpy())
+    comm.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("engine", [True, False], ids=["step-level", "op-level"])
+def test_rccl_collectives_at_world_one_leave_the_step_unchanged(tmp_path, engine):
+    from drs_amd.net import DilatedNet
+    out = str(tmp_path / "rccl.npz")
+    mp.spawn(_rccl_worker, args=(1, 29700 + os.getpid() % 1000, out, engine), nprocs=1, join=True)
+    x, y = _inputs()
+    d = DilatedNet(NET, CH, K, 0.005, b_max=B, s_max=S, device="cuda:0", seed=3, engine=engine)
+    losses = []
+    for _ in range(3):
+        d.feed(x, y, S)
+        res = d.train_step(B, S, 0.01)
+        losses.append(d.loss_value(res["loss_parts"]))
+    torch.cuda.synchronize()
+    r = np.load(out)
+    # identities on the data; the only difference allowed is the multi-rank form of the batch-norm statistics (tile sums -> fp64
+    # sums -> all-reduce -> finish, against the fused finish): same arithmetic, so the three steps must agree to rounding
+    np.testing.assert_allclose(r["losses"], losses, rtol=1e-6)
+    np.testing.assert_allclose(r["params"], d.params.cpu().numpy(), rtol=0, atol=1e-6 * float(d.params.abs().max()))
+    np.testing.assert_allclose(r["bn"], d.bn.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_array_equal(r["conf"], res["conf"].cpu().numpy())
+    print("RCCL world-1 run vs no communicator: params bitwise equal = %s" % np.array_equal(r["params"], d.params.cpu().numpy()))
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # data parallelism behind the reference's command line (isprs:1987-2138): two processes through cli.main, placed by the
 # launcher's environment (dist.from_env), against the single-process run.

@@ -1,0 +1,104 @@
+"""CPU: how drs_conv_wgrad cuts the pixel dimension of the filter gradient into workgroups (conv_mfma.hip, WgradPlan).
+
+The library works the cut out on the host with the very code the kernels run (`wgrad_assign` is host + device); the development
+entry point drs_debug_wgrad_cut lists the workgroups of a launch.  Checked here, without a GPU, before any kernel relies on it:
+every (row tile, column tile) has its splits 0 .. n-1 exactly once, their chunk ranges tile [0, chunks) without gap or overlap,
+n stays inside what drs_conv_wgrad_splits tells callers to size the slab by, and -- the point of the cut by live pixels -- the
+workgroups of a launch all multiply (nearly) the same number of live chunks.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from drs_amd import _lib
+
+
+def _live_range(row_first, row_last, cin, k, rate, pad, S):
+    """restatement of live_pixel_range (drs_common.hpp): image rows whose shifted rows meet image data for some tap row of the tile"""
+    dy_min = (row_first // cin // k) * rate - pad
+    dy_max = (row_last // cin // k) * rate - pad
+    ylo, yhi = max(0, -dy_max), min(S, S - dy_min)
+    if ylo >= yhi:
+        ylo, yhi = 0, S
+    return ylo * S, yhi * S
+
+
+def _cut(B, S, k, rate, pad, cin, cout):
+    lib = _lib.load()
+    lib.drs_debug_wgrad_cut.restype = C.c_int
+    lib.drs_debug_wgrad_cut.argtypes = [C.c_int] * 7 + [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    cap = 1 << 16
+    out = np.zeros((cap, 5), dtype=np.int32)
+    nt = np.zeros(256, dtype=np.int32)
+    tr = C.c_int()
+    n = lib.drs_debug_wgrad_cut(B, S, k, rate, pad, cin, cout, out.ctypes.data, cap, nt.ctypes.data, C.addressof(tr))
+    assert 0 < n <= cap
+    return out[:n], nt, tr.value
+
+
+def _live_chunks(cbeg, cend, lo, hi, S2):
+    """32-pixel chunks of [cbeg, cend) that hold a pixel of some image's live range [b*S2+lo, b*S2+hi)"""
+    c = np.arange(cbeg, cend, dtype=np.int64)
+    first, last = 32 * c, 32 * c + 31
+    live = np.zeros(len(c), dtype=bool)
+    for b in range(int(first[0] // S2) if len(c) else 0, int(last[-1] // S2) + 1 if len(c) else 0):
+        live |= (last >= b * S2 + lo) & (first < b * S2 + hi)
+    return int(live.sum())
+
+
+# Dilated8Pooling's layers (k, rate, pad_before, cin as the kernel sees it, cout) and the other kernel sizes of the net tables
+D8P = [(5, 1, 2, 8, 64), (5, 1, 2, 64, 64), (4, 2, 3, 64, 128), (4, 2, 3, 128, 128), (3, 4, 4, 128, 192), (3, 4, 4, 192, 192),
+       (3, 8, 8, 192, 256), (3, 8, 8, 256, 256)]
+
+
+@pytest.mark.parametrize("B,S", [(16, 64), (32, 64), (128, 64), (128, 25), (128, 85), (16, 45), (3, 9), (1, 100)])
+def test_cut_is_a_partition_and_balanced(B, S):
+    lib = _lib.load()
+    for (k, rate, pad, cin, cout) in D8P:
+        wg, nt, tr = _cut(B, S, k, rate, pad, cin, cout)
+        rows = k * k * cin
+        ntr = -(-rows // tr)
+        nchunks = -(-B * S * S // 32)
+        bound = _lib.query("drs_conv_wgrad_splits", B, S, k, cin, cout)
+        seen = {}
+        for rt, ct, sp, cb, ce in wg:
+            assert 0 <= rt < ntr and 0 <= sp < nt[rt] <= bound, (rt, sp, nt[rt], bound)
+            assert (rt, ct, sp) not in seen
+            assert 0 <= cb <= ce <= nchunks
+            seen[(rt, ct, sp)] = (cb, ce)
+        ncol = 1 + max(ct for _, ct, _, _, _ in wg)
+        assert len(seen) == sum(int(nt[r]) for r in range(ntr)) * ncol == len(wg)
+        lens = []
+        for rt in range(ntr):
+            lo, hi = _live_range(rt * tr, min((rt + 1) * tr, rows) - 1, cin, k, rate, pad, S)
+            for ct in range(ncol):
+                edge = 0
+                for sp in range(int(nt[rt])):
+                    cb, ce = seen[(rt, ct, sp)]
+                    assert cb == edge, "gap or overlap between the splits of a tile"
+                    edge = ce
+                    if ct == 0:
+                        lens.append(_live_chunks(cb, ce, lo, hi, S * S))
+                assert edge == nchunks
+        lens = np.asarray(lens)
+        # workgroup lengths in live chunks: equal up to the rounding of n per class and the chunks that straddle a boundary
+        if len(set(int(x) for x in nt[:ntr])) > 1 or S % 32 == 0:
+            spread = (lens.max() - lens.min()) / max(1.0, lens.mean())
+            assert spread <= 0.2 or lens.max() - lens.min() <= 3, (B, S, k, rate, cin, cout, lens.min(), lens.mean(), lens.max())
+
+
+def test_equal_cut_still_available():
+    lib = _lib.load()
+    old = lib.drs_debug_wgrad_balance(0)
+    try:
+        wg, nt, tr = _cut(128, 64, 3, 8, 8, 256, 256)
+        assert len(set(int(x) for x in nt[:18])) == 1
+        per = {}
+        for rt, ct, sp, cb, ce in wg:
+            per.setdefault((rt, ct), []).append((sp, cb, ce))
+        for v in per.values():
+            v.sort()
+            assert v[0][1] == 0 and v[-1][2] == 128 * 64 * 64 // 32 and all(v[i][2] == v[i + 1][1] for i in range(len(v) - 1))
+    finally:
+        lib.drs_debug_wgrad_balance(old)

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Time the training step at a given local batch (what one rank sees under data parallelism), no collectives."""
+"""Time the training step at a given local batch (what one rank sees under data parallelism).  Default: no collectives;
+`comm=rccl`: every collective of the step issued through RCCL at world 1 (identities; DRS_FORCE_COLLECTIVES), `comm=rccl2`: the same
+with the second communicator for the small sums (DRS_BN_COMM)."""
 import os, sys, time
 import numpy as np
 import torch
@@ -8,12 +10,20 @@ from drs_amd.net import DilatedNet, KernelTimer
 from drs_amd import patches as P
 from drs_amd.synthetic import make_tile, grid_instances
 
-def main(B=16, S=64, steps=20, arith="f32"):
+def main(B=16, S=64, steps=20, arith="f32", comm_kind="none"):
     dev = "cuda:0"
+    comm = None
+    if comm_kind != "none":
+        os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", DRS_FORCE_COLLECTIVES="1")
+        if comm_kind == "rccl2":
+            os.environ["DRS_BN_COMM"] = "1"
+        from drs_amd.dist import TorchComm
+        torch.cuda.set_device(0)
+        comm = TorchComm("nccl")
     tile, lab = make_tile(1024, 1024, 5, 6, seed=1234)
     pool = P.TilePool([tile], [lab], dev)
     inst = grid_instances(1024, 1024, S, 25, 4096, seed=0)
-    net = DilatedNet("dilated_grsl_rate8", 5, 6, 0.005, b_max=B, s_max=S, device=dev, arith=arith)
+    net = DilatedNet("dilated_grsl_rate8", 5, 6, 0.005, b_max=B, s_max=S, device=dev, arith=arith, comm=comm)
     np.random.seed(0)
     def step(i):
         rows = inst[(i * B) % 4000:(i * B) % 4000 + B]
@@ -33,9 +43,11 @@ def main(B=16, S=64, steps=20, arith="f32"):
     for i in range(3): step(i)
     summ = net.timer.summary(); net.timer = None
     ksum = sum(d["ms"] for d in summ.values()) / 3
-    print(arith, "B=%d S=%d: %.2f ms/step  (%.0f patches/s; x%d ranks = %.0f)  host enqueue %.2f ms/step, timed kernels %.2f ms" % (B, S, dt * 1e3, B / dt, 128 // B, 128 / dt, host * 1e3, ksum))
+    print(arith, "comm=" + comm_kind, "B=%d S=%d: %.2f ms/step  (%.0f patches/s; x%d ranks = %.0f)  host enqueue %.2f ms/step, timed kernels %.2f ms" % (B, S, dt * 1e3, B / dt, 128 // B, 128 / dt, host * 1e3, ksum))
     for k, d in sorted(summ.items()): print("   %-18s %6.3f ms/step" % (k, d["ms"] / 3))
 
 if __name__ == "__main__":
     kw = dict(a.split("=") for a in sys.argv[1:])
-    main(int(kw.get("B", 16)), int(kw.get("S", 64)), int(kw.get("steps", 20)), kw.get("arith", "f32"))
+    main(int(kw.get("B", 16)), int(kw.get("S", 64)), int(kw.get("steps", 20)), kw.get("arith", "f32"), kw.get("comm", "none"))
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
