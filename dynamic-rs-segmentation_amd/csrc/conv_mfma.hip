@@ -1002,6 +1002,7 @@ int pick_wgrad_rows(int rows) {
 int pick_wgrad_cols(int tr, int cout) { return (tr == 128 && cout % 192 == 0 && cout % 128 != 0 && g_wgrad_variant != 0) ? 192 : pick_tile(cout); }
 
 int g_wgrad_balance = 1;     // development switch (drs_debug_wgrad_balance): 0 = equal chunk ranges (and the old rule for skipping), 1 = cut by live pixels
+int g_wgrad_len = 96;       // development switch (drs_debug_wgrad_len): chunks per workgroup small launches aim at
 int g_wgrad_target_big = 0;  // development switch: workgroups aimed at on launches with many tiles and pixels under the live cut (0 = default)
 
 // workgroups a filter-gradient launch of `work` chunk-tiles (32-pixel chunks x tiles) aims at
@@ -1010,7 +1011,7 @@ int wgrad_target(long long work, int ntile, int nchunks, bool balanced) {
   // >= 96 chunks each, down to one round of 512 (sweeps at B = 16 / 32 in profiles/r02/wgrad_ablation.txt).  Launches with many
   // tiles and pixels: with equal chunk ranges and the dead chunks skipped the workgroups differ in length by up to a quarter and
   // two rounds quantise the gain away, so twice as many (measured at B = 128: conv6 3.48 -> 3.01 ms, conv8 5.19 -> 4.85).
-  long long fit = work / 96;
+  long long fit = work / g_wgrad_len;
   fit = fit < 512 ? 512 : (fit > g_wgrad_target ? g_wgrad_target : fit);
   const bool big = ntile >= 24 && nchunks >= 8192;
   if (!balanced) return big ? 2 * g_wgrad_target : (int)fit;
@@ -1157,6 +1158,8 @@ int drs_debug_skip_taps(int v) { const int old = drs_g_skip_halo_taps; if (v >= 
 int drs_debug_wgrad_target(int v) { const int old = g_wgrad_target; if (v > 0) g_wgrad_target = v; return old; }
 
 int drs_debug_wgrad_balance(int v) { const int old = g_wgrad_balance; if (v >= 0) g_wgrad_balance = v; return old; }
+
+int drs_debug_wgrad_len(int v) { const int old = g_wgrad_len; if (v > 0) g_wgrad_len = v; return old; }
 
 int drs_debug_wgrad_target_big(int v) { const int old = g_wgrad_target_big; if (v >= 0) g_wgrad_target_big = v; return old; }
 
