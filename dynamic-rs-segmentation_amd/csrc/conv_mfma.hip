@@ -17,6 +17,7 @@
 // accumulator VGPRs; A tile [BM][32] and B tile [32][BN] are staged through LDS (register prefetch of the next
 // K-step while the current one is multiplied).
 #include "drs_common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -33,6 +34,7 @@ struct ConvArgs {
   int k, rate, pad, Cin, Cout;
   int accumulate;
   int skip_halo;
+  int korder;           // K loop order: 0 = (tap row, tap column, channel chunk), 1 = (channel chunk, tap row, tap column)
   float rcpS, rcpSS;
 };
 
@@ -165,10 +167,13 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 128) ? 3 : 1) void conv_ig
 #pragma unroll
       for (int i = 0; i < NA; ++i) { uint32_t o = offA[i]; asm volatile("" : "+v"(o)); ra[i] = *reinterpret_cast<const f32x4*>(ab + o); }   // (opaque: keeps the 32-bit offset form, global_load v, voff, s[base])
     }
-    const char* wb = wlive + (size_t)(uint32_t)(ks * BK) * (uint32_t)a.Cout * 4u;
+    const char* wb = wlive + (size_t)(uint32_t)((PACK ? ks : ((lu - u_lo) * a.k + lv) * cpt + lc) * BK) * (uint32_t)a.Cout * 4u;
 #pragma unroll
     for (int i = 0; i < NB; ++i) { uint32_t o = offB[i]; asm volatile("" : "+v"(o)); rb[i] = *reinterpret_cast<const f32x4*>(wb + o); }
-    if (!PACK) { if (++lc == cpt) { lc = 0; if (++lv == a.k) { lv = 0; ++lu; } } }
+    if (!PACK) {      // K-step order as in conv_dma_kernel (ConvArgs::korder), so the two forms add in the same order
+      if (a.korder) { if (++lv == a.k) { lv = 0; if (++lu == u_hi) { lu = u_lo; ++lc; } } }
+      else if (++lc == cpt) { lc = 0; if (++lv == a.k) { lv = 0; ++lu; } }
+    }
   };
   auto lstore = [&]() {
 #pragma unroll
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
     float* sa = lds + stage * STAGE;
     float* sb = sa + ASTAGE;
     const char* ab = inb + (size_t)(uint32_t)((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK + half * HK) * 4u;
-    const char* wb = wlive + (size_t)(uint32_t)(ks * BK + half * HK) * (uint32_t)a.Cout * 4u;
+    const char* wb = wlive + (size_t)(uint32_t)((((lu - u_lo) * a.k + lv) * cpt + lc) * BK + half * HK) * (uint32_t)a.Cout * 4u;
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
       uint32_t o = offA[i]; asm volatile("" : "+v"(o));
@@ -307,7 +312,12 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
       __builtin_amdgcn_global_load_lds(wb + o, (lds_ptr)(sb + (wave + 4 * i) * 256), 16, 0, 0);
     }
   };
-  auto next_kstep = [&]() { if (++lc == cpt) { lc = 0; if (++lv == a.k) { lv = 0; ++lu; } } };
+  // channel-major order: the k*k shifted reads of one 32-channel chunk follow each other, so the lines a tap shares with the one
+  // before it (a column shift keeps 7/8 of a row) and with the neighbouring tiles' taps are still in L2 when they are read again
+  auto next_kstep = [&]() {
+    if (a.korder) { if (++lv == a.k) { lv = 0; if (++lu == u_hi) { lu = u_lo; ++lc; } } }
+    else if (++lc == cpt) { lc = 0; if (++lv == a.k) { lv = 0; ++lu; } }
+  };
 
   // fragment addresses (floats): A row r = arow + 32 mi, piece c = 2 q + h in slot c ^ ((r >> 2) & 3); B row k, column
   const int arow = wm * WTM + li, bcolw = wn * WTN + li;
@@ -945,6 +955,8 @@ __global__ void pad_cin_kernel(const float* __restrict__ w, float* __restrict__ 
   }
 }
 
+int env_int(const char* name, int dflt) { const char* e = std::getenv(name); return e && *e ? std::atoi(e) : dflt; }
+int g_conv_korder = env_int("DRS_CONV_KORDER", 1);       // development switch (drs_debug_conv_korder / environment): K-loop order, 1 = channel-major (ConvArgs::korder)
 int g_conv_variant = -1;     // development switch (drs_debug_conv_variant): 0 = register-staged tiles, 1 = LDS-DMA double-buffered halves, -1 = per tile
 
 template <int BM, int BN, int WM, int WN>
@@ -1163,6 +1175,8 @@ int drs_debug_wgrad_len(int v) { const int old = g_wgrad_len; if (v > 0) g_wgrad
 
 int drs_debug_wgrad_target_big(int v) { const int old = g_wgrad_target_big; if (v >= 0) g_wgrad_target_big = v; return old; }
 
+int drs_debug_conv_korder(int v) { const int old = g_conv_korder; if (v >= 0) g_conv_korder = v; return old; }
+
 int drs_debug_conv_variant(int v) { const int old = g_conv_variant; if (v >= -1) g_conv_variant = v; return old; }
 
 int drs_debug_wgrad_variant(int v) { const int old = g_wgrad_variant; if (v >= -1) g_wgrad_variant = v; return old; }
@@ -1187,6 +1201,7 @@ int drs_conv_forward(const float* in, int B, int S, int P, int ld_in, int coff_i
   a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout; a.accumulate = accumulate;
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
   a.skip_halo = drs_skip_halo_taps_fwd(M, cout);
+  a.korder = g_conv_korder;
   hipStream_t st = (hipStream_t)stream;
   switch (pick_tile(cout)) {
     case 128: return launch_conv<128, 128, 2, 2>(a, st);
