@@ -34,7 +34,6 @@ struct ConvArgs {
   int k, rate, pad, Cin, Cout;
   int accumulate;
   int skip_halo;
-  int korder;           // K loop order: 0 = (tap row, tap column, channel chunk), 1 = (channel chunk, tap row, tap column)
   float rcpS, rcpSS;
 };
 
@@ -170,10 +169,7 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 128) ? 3 : 1) void conv_ig
     const char* wb = wlive + (size_t)(uint32_t)((PACK ? ks : ((lu - u_lo) * a.k + lv) * cpt + lc) * BK) * (uint32_t)a.Cout * 4u;
 #pragma unroll
     for (int i = 0; i < NB; ++i) { uint32_t o = offB[i]; asm volatile("" : "+v"(o)); rb[i] = *reinterpret_cast<const f32x4*>(wb + o); }
-    if (!PACK) {      // K-step order as in conv_dma_kernel (ConvArgs::korder), so the two forms add in the same order
-      if (a.korder) { if (++lv == a.k) { lv = 0; if (++lu == u_hi) { lu = u_lo; ++lc; } } }
-      else if (++lc == cpt) { lc = 0; if (++lv == a.k) { lv = 0; ++lu; } }
-    }
+    if (!PACK) { if (++lv == a.k) { lv = 0; if (++lu == u_hi) { lu = u_lo; ++lc; } } }     // K-step order as in conv_dma_kernel: the two forms add in the same order
   };
   auto lstore = [&]() {
 #pragma unroll
@@ -312,12 +308,12 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
       __builtin_amdgcn_global_load_lds(wb + o, (lds_ptr)(sb + (wave + 4 * i) * 256), 16, 0, 0);
     }
   };
-  // channel-major order: the k*k shifted reads of one 32-channel chunk follow each other, so the lines a tap shares with the one
-  // before it (a column shift keeps 7/8 of a row) and with the neighbouring tiles' taps are still in L2 when they are read again
-  auto next_kstep = [&]() {
-    if (a.korder) { if (++lv == a.k) { lv = 0; if (++lu == u_hi) { lu = u_lo; ++lc; } } }
-    else if (++lc == cpt) { lc = 0; if (++lv == a.k) { lv = 0; ++lu; } }
-  };
+  // K order (channel chunk, tap row, tap column): the k*k shifted reads of one 32-channel chunk follow each other, so the lines a
+  // tap shares with the one before it (a column shift keeps 7/8 of a row) and with the neighbouring tiles' taps are still in L2
+  // when they are read again.  Against (tap row, tap column, chunk), in-process A/B with a run-time switch (profiles/r02/
+  // conv_korder_ab.txt): fabric-side fetch per launch 6.1 -> 0.9 GB (conv6), 7.8 -> 2.2 GB (conv8); forward -1 %, dgrad -2.4 %.
+  // (The switch itself is gone: it sent the loop counters to scratch memory and their arithmetic to the vector ALU, -7 %.)
+  auto next_kstep = [&]() { if (++lv == a.k) { lv = 0; if (++lu == u_hi) { lu = u_lo; ++lc; } } };
 
   // fragment addresses (floats): A row r = arow + 32 mi, piece c = 2 q + h in slot c ^ ((r >> 2) & 3); B row k, column
   const int arow = wm * WTM + li, bcolw = wn * WTN + li;
@@ -955,8 +951,6 @@ __global__ void pad_cin_kernel(const float* __restrict__ w, float* __restrict__ 
   }
 }
 
-int env_int(const char* name, int dflt) { const char* e = std::getenv(name); return e && *e ? std::atoi(e) : dflt; }
-int g_conv_korder = env_int("DRS_CONV_KORDER", 1);       // development switch (drs_debug_conv_korder / environment): K-loop order, 1 = channel-major (ConvArgs::korder)
 int g_conv_variant = -1;     // development switch (drs_debug_conv_variant): 0 = register-staged tiles, 1 = LDS-DMA double-buffered halves, -1 = per tile
 
 template <int BM, int BN, int WM, int WN>
@@ -1175,8 +1169,6 @@ int drs_debug_wgrad_len(int v) { const int old = g_wgrad_len; if (v > 0) g_wgrad
 
 int drs_debug_wgrad_target_big(int v) { const int old = g_wgrad_target_big; if (v >= 0) g_wgrad_target_big = v; return old; }
 
-int drs_debug_conv_korder(int v) { const int old = g_conv_korder; if (v >= 0) g_conv_korder = v; return old; }
-
 int drs_debug_conv_variant(int v) { const int old = g_conv_variant; if (v >= -1) g_conv_variant = v; return old; }
 
 int drs_debug_wgrad_variant(int v) { const int old = g_wgrad_variant; if (v >= -1) g_wgrad_variant = v; return old; }
@@ -1201,7 +1193,6 @@ int drs_conv_forward(const float* in, int B, int S, int P, int ld_in, int coff_i
   a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout; a.accumulate = accumulate;
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
   a.skip_halo = drs_skip_halo_taps_fwd(M, cout);
-  a.korder = g_conv_korder;
   hipStream_t st = (hipStream_t)stream;
   switch (pick_tile(cout)) {
     case 128: return launch_conv<128, 128, 2, 2>(a, st);

@@ -9,7 +9,6 @@ DEV = "cuda:0"
 def main(B=128, S=64, layers="4,8", reps=3, skip=1, target=0, fwd=0, variant=-1):
     _lib.load()
     _lib.load().drs_debug_skip_taps(skip)
-    _lib.load().drs_debug_conv_korder(int(os.environ.get("DRS_CONV_KORDER", "1")))
     if target:
         _lib.load().drs_debug_wgrad_target(target)
     plan = Plan("dilated_grsl_rate8", 5, 6, first_cin_pad=32)
