@@ -241,9 +241,9 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
   constexpr int HK = 16;                         // channels per pipeline stage (half a K-step)
   constexpr int ASTAGE = BM * HK, STAGE = ASTAGE + HK * BN;   // floats
   constexpr int IA = (BM / 16) / 4;              // A DMA instructions per wave and half (16 pixel rows each)
-  constexpr int BRPI = 256 / BN;                 // B k-rows per DMA instruction (1 KiB / row bytes)
-  constexpr int IB = (HK / BRPI) / 4;            // B DMA instructions per wave and half
-  static_assert(IA >= 1 && IB >= 1, "tile / wave layout");
+  constexpr int BQ = BN / 4;                     // 16-byte pieces per B k-row
+  constexpr int IB = HK * BQ / 64 / 4;           // B DMA instructions per wave and half: the half image [HK][BN] as one linear run of 1-KiB pieces
+  static_assert(IA >= 1 && IB >= 1 && IB * 4 * 64 == HK * BQ, "tile / wave layout");
 
   __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
 
@@ -267,10 +267,13 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
     offA[i] = (padded_pixel_off(p, a.S, a.P, a.ld_in, a.rcpS, a.rcpSS, -a.pad, -a.pad) + (uint32_t)a.coff_in) * 4u +
               (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) * 16);
   }
-  // B: instruction j covers k-rows BRPI j + lane / (BN / 4), this lane the 16-byte piece lane % (BN / 4) of its row
+  // B: instruction j moves pieces 64 j + lane of the linear half image: piece f is the 16-byte column f % BQ of k-row f / BQ
+  // (BN = 192: a k-row is 768 B, so an instruction spans rows; every lane has its own (row, column) per instruction)
 #pragma unroll
-  for (int i = 0; i < IB; ++i)
-    offB[i] = (uint32_t)((((wave + 4 * i) * BRPI + lane / (BN / 4)) * a.Cout + n0 + (lane % (BN / 4)) * 4)) * 4u;
+  for (int i = 0; i < IB; ++i) {
+    const int f = 64 * (wave + 4 * i) + lane;
+    offB[i] = (uint32_t)(((f / BQ) * a.Cout + n0 + (f % BQ) * 4)) * 4u;
+  }
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -993,6 +996,10 @@ namespace {
 int g_wgrad_target = 2048;   // workgroups the pixel split of the filter gradient aims at: two rounds of the 4 x 256 resident 128x128 DMA workgroups (sweep in profiles/r02/wgrad_ablation.txt; development switch drs_debug_wgrad_target)
 
 int pick_tile(int c) { return c % 128 == 0 ? 128 : (c % 64 == 0 ? 64 : 32); }
+int g_conv_wide192 = 1;      // development switch (drs_debug_conv_wide192): Cout = 192 as one 128 x 192 tile (0: three 128 x 64 tiles)
+// forward / input-gradient N tile: Cout = 192 (conv5 / conv6, and the input gradients of conv6 / conv7) takes ONE 192-wide tile
+// (wave tile 64 x 96: 6 MFMAs per 5 fragment reads, the A tile fetched once instead of three times) in the LDS-DMA form
+int pick_conv_tile(int c, int cin) { return (g_conv_wide192 && c % 192 == 0 && c % 128 != 0 && cin % 32 == 0 && g_conv_variant != 0) ? 192 : pick_tile(c); }
 
 // wgrad row tile: rows = k*k*Cin may be cut anywhere (a tile spans taps, the last one may be ragged), so take the
 // tall 128-row tile whenever the ragged remainder wastes little; measured MFMA-busy: 128-row tiles 75 %, 64: 65-73 %, 32: 46 %
@@ -1169,6 +1176,8 @@ int drs_debug_wgrad_len(int v) { const int old = g_wgrad_len; if (v > 0) g_wgrad
 
 int drs_debug_wgrad_target_big(int v) { const int old = g_wgrad_target_big; if (v >= 0) g_wgrad_target_big = v; return old; }
 
+int drs_debug_conv_wide192(int v) { const int old = g_conv_wide192; if (v >= 0) g_conv_wide192 = v; return old; }
+
 int drs_debug_conv_variant(int v) { const int old = g_conv_variant; if (v >= -1) g_conv_variant = v; return old; }
 
 int drs_debug_wgrad_variant(int v) { const int old = g_wgrad_variant; if (v >= -1) g_wgrad_variant = v; return old; }
@@ -1194,7 +1203,8 @@ int drs_conv_forward(const float* in, int B, int S, int P, int ld_in, int coff_i
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
   a.skip_halo = drs_skip_halo_taps_fwd(M, cout);
   hipStream_t st = (hipStream_t)stream;
-  switch (pick_tile(cout)) {
+  switch (pick_conv_tile(cout, cin)) {
+    case 192: DRS_LAUNCH((conv_dma_kernel<128, 192, 2, 2>), dim3(((a.M + 127) / 128) * (cout / 192)), dim3(256), 0, st, a); return DRS_LAUNCH_CHECK();
     case 128: return launch_conv<128, 128, 2, 2>(a, st);
     case 64:  return launch_conv<128, 64, 2, 2>(a, st);     // in-process A/B against 256 x 64: -4..-9 % at B = 128, -2..-12 % at B = 16
     default:  return launch_conv<256, 32, 4, 1>(a, st);

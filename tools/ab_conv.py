@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""In-process A/B of the forward / input-gradient kernel forms (0 = register-staged, 1 = LDS-DMA) on the Dilated8Pooling shapes
-(development aid): interleaved repetitions on one device, best-of per arm, bitwise comparison of the outputs.
-    python tools/ab_conv.py [B=128] [S=64]"""
+"""In-process A/B of the forward / input-gradient kernel on the Dilated8Pooling shapes (development aid): interleaved repetitions on
+one device, best-of per arm, bitwise comparison of the outputs.  mode=variant: kernel forms (0 = register-staged, 1 = LDS-DMA);
+mode=wide192: Cout = 192 as three 128x64 tiles (0) or one 128x192 tile (1).
+    python tools/ab_conv.py [B=128] [S=64] [mode=variant]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,8 +10,9 @@ from drs_amd import _lib
 from drs_amd.nets import Plan
 DEV = "cuda:0"
 
-def main(B=128, S=64, rounds=4):
+def main(B=128, S=64, rounds=4, mode="variant"):
     lib = _lib.load()
+    setter = lib.drs_debug_conv_variant if mode == "variant" else lib.drs_debug_conv_wide192
     plan = Plan("dilated_grsl_rate8", 5, 6, first_cin_pad=8)
     st = torch.cuda.current_stream(DEV).cuda_stream
     M = B * S * S
@@ -29,7 +31,7 @@ def main(B=128, S=64, rounds=4):
         row = "%-6s" % L.name
         for r in range(rounds):
             for v in (0, 1):
-                lib.drs_debug_conv_variant(v)
+                setter(v)
                 for d in ("fwd", "dgrad"):
                     cin, cout, inp, pad = (L.cin_k, L.cout, x, L.pad_b) if d == "fwd" else (L.cout, L.cin_k, g, L.pad_a)
                     z = torch.zeros(M * cout, device=DEV)
@@ -55,7 +57,8 @@ def main(B=128, S=64, rounds=4):
         print(row + ("  bitwise equal" if same else "  OUTPUTS DIFFER"), flush=True)
     print("total  " + "  ".join("%s v%d %.3f ms" % (d, v, tot[(v, d)]) for d in ("fwd", "dgrad") for v in (0, 1)))
     lib.drs_debug_conv_variant(-1)
+    lib.drs_debug_conv_wide192(1)
 
 if __name__ == "__main__":
     kw = dict(a.split("=") for a in sys.argv[1:])
-    main(int(kw.get("B", 128)), int(kw.get("S", 64)))
+    main(int(kw.get("B", 128)), int(kw.get("S", 64)), int(kw.get("rounds", 4)), kw.get("mode", "variant"))
