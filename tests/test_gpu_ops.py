@@ -503,9 +503,22 @@ def test_filter_gradient_chunk_walk_over_patch_sides(lib, S, B):
                          gw.data_ptr(), stream())
                 torch.cuda.synchronize()
                 outs.append(gw)
+        # the cut of the pixel dimension: by live pixels (default, above) and in equal chunk ranges -- other partial sums, same gradient
+        raw.drs_debug_wgrad_variant(-1)
+        raw.drs_debug_skip_taps(1)
+        raw.drs_debug_wgrad_balance(0)
+        nsp = lib.query("drs_conv_wgrad_splits", B, S, k, cin, cout)
+        slab = torch.zeros(nsp * w.size, dtype=torch.float32, device=DEV)
+        gw_eq = torch.full((w.size,), 7.0, dtype=torch.float32, device=DEV)
+        lib.call("drs_conv_wgrad", xd.data_ptr(), B, S, P, cin, 0, gd.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout, slab.data_ptr(),
+                 gw_eq.data_ptr(), stream())
+        torch.cuda.synchronize()
     finally:
         raw.drs_debug_wgrad_variant(-1)
         raw.drs_debug_skip_taps(1)
+        raw.drs_debug_wgrad_balance(1)
     assert rel_err(outs[0].cpu().numpy().reshape(gw_ref.shape), gw_ref) < 1e-5
     for o in outs[1:]:
         assert torch.equal(outs[0], o)
+    assert rel_err(gw_eq.cpu().numpy().reshape(gw_ref.shape), gw_ref) < 1e-5
+    assert float((gw_eq - outs[0]).abs().max() / outs[0].abs().max()) < 2e-6
