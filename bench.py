@@ -189,6 +189,11 @@ def main():
                     help="arithmetic of the convolution kernels: exact fp32 MFMA (default) or split-bf16 (conv_split.hip)")
     args = ap.parse_args()
     ar = ARITH[args.arith]
+    # stdout carries the ONE JSON line and nothing else: RCCL prints a version banner, gloo its connection lines, straight to file
+    # descriptor 1 of every rank.  From here on descriptor 1 is stderr; the JSON line goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -371,7 +376,7 @@ def main():
             "train_tflops": round(value * 3 * 2 * net.plan.mac_per_pixel() * PATCH * PATCH / 1e12, 2),
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "opt_in_arithmetic": opt_in,
         }
-        print(json.dumps(line))
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if comm:
         comm.barrier()
         torch.distributed.destroy_process_group()
