@@ -21,6 +21,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver; must be set before the runtime starts
+
 import numpy as np
 import torch
 

@@ -123,6 +123,7 @@ def from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
         return "cuda:0", None
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (what RCCL needs here); read when the runtime starts
     rehearsal = os.environ.get("DRS_DIST_REHEARSAL") == "1"
     local = 0 if rehearsal else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
