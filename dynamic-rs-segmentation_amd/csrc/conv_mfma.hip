@@ -434,6 +434,7 @@ __host__ __device__ __forceinline__ void wgrad_assign(const WgradArgs& a, int TR
     int r = 0, seen = 0;
     for (; r < a.ntr; ++r)
       if (a.plan.cls[r] >= j) { if (seen == want) break; ++seen; }
+    r = r < a.ntr ? r : a.ntr - 1;              // (cannot happen for a plan of wgrad_live_plan; never index past the tables)
     tile = r * a.nto + pos % a.nto;
     nr = a.plan.n[a.plan.cls[r]];
   }

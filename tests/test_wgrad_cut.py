@@ -47,15 +47,25 @@ def _live_chunks(cbeg, cend, lo, hi, S2):
     return int(live.sum())
 
 
-# Dilated8Pooling's layers (k, rate, pad_before, cin as the kernel sees it, cout) and the other kernel sizes of the net tables
-D8P = [(5, 1, 2, 8, 64), (5, 1, 2, 64, 64), (4, 2, 3, 64, 128), (4, 2, 3, 128, 128), (3, 4, 4, 128, 192), (3, 4, 4, 192, 192),
-       (3, 8, 8, 192, 256), (3, 8, 8, 256, 256)]
+def _all_conv_shapes():
+    """(k, rate, pad_before, cin as the kernel sees it, cout) of every convolution of every net table of the three scripts"""
+    from drs_amd.nets import Plan, known_net_types
+    shapes = set()
+    for nt in known_net_types():
+        for ch in (3, 4, 5):
+            for L in Plan(nt, ch, 6, first_cin_pad=8).layers:
+                shapes.add((L.k, L.rate, L.pad_b, L.cin_k, L.cout))
+    return sorted(shapes)
+
+
+SHAPES = _all_conv_shapes()
 
 
 @pytest.mark.parametrize("B,S", [(16, 64), (32, 64), (128, 64), (128, 25), (128, 85), (16, 45), (3, 9), (1, 100)])
 def test_cut_is_a_partition_and_balanced(B, S):
     lib = _lib.load()
-    for (k, rate, pad, cin, cout) in D8P:
+    assert len(SHAPES) >= 40
+    for (k, rate, pad, cin, cout) in SHAPES:
         wg, nt, tr = _cut(B, S, k, rate, pad, cin, cout)
         rows = k * k * cin
         ntr = -(-rows // tr)
