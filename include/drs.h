@@ -241,6 +241,8 @@ int drs_softmax_accumulate(const float* prob, const unsigned int* occur, int h, 
  *   allreduce(user, dev_ptr, count, dtype (0 f32, 1 f64, 3 i32), async, stream) -> handle >= 0, or < 0 on failure; in-place sum;
  *       async = 1: may return before the sum is done, the library then calls wait(user, handle, stream) before it reads the data;
  *       async = 0: the sum must be ordered before later work on `stream`.
+ *   With a callback installed the sums go through it at world = 1 too (identities there): a single-GPU host can drive the whole
+ *   collective path.  world = 1 and no callback: the sums are skipped and batch norm uses its fused single-rank finish.
  */
 typedef struct drs_net drs_net_t;
 typedef int (*drs_allreduce_fn)(void* user, void* dev_ptr, size_t count, int dtype, int async, void* stream);
