@@ -177,6 +177,73 @@ def test_two_ranks_through_the_command_line_equal_one_process(tmp_path):
     assert float(np.abs(a - b).max() / np.abs(b).max()) < 5e-4          # same patches, sizes and augmentation; sums grouped differently
 
 
+# the coffee / contest command lines under the launcher (coffee:1106-1150, contest:1229-1271): flip-by-index sampling, float16
+# patches, void mask -- two ranks against one process
+FLAVOUR_ARGV = {
+    "coffee": ["coffee_dilated_random.py", "synthetic:2x60x60x3/", "synthetic:1x60x60x3/", "OUT", "none", "0.01", "0.001", "6", "3", "25", "10",
+               "dilated_icpr_rate6_small", "multi_fixed", "9,13", "loss"],
+    "contest": ["contest_dilated_random.py", "synthetic:80x70x3/", "OUT", "none", "0.01", "0.001", "4", "3", "25", "10", "dilated_grsl",
+                "multi_fixed", "9,13", "acc", "train"],
+}
+
+
+def _flavour_main(which):
+    from drs_amd import cli
+    return cli.main_coffee if which == "coffee" else cli.main_contest
+
+
+def _flavour_worker(rank, world, port, root, which):
+    import random
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      DRS_DIST_REHEARSAL="1")
+    import torch.distributed as dist
+    os.chdir(root)
+    random.seed(60 + rank)
+    np.random.seed(70 + rank)
+    argv = list(FLAVOUR_ARGV[which])
+    argv[argv.index("OUT")] = os.path.join(root, "dp_")
+    net = _flavour_main(which)(argv)
+    assert net.comm.world == 2
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.save(os.path.join(root, "dp_params.npy"), net.params.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("which", ["coffee", "contest"])
+def test_two_ranks_through_the_coffee_and_contest_command_lines(tmp_path, which):
+    import random
+    from drs_amd.net import NoComm
+
+    class _SyncOnly(NoComm):
+        sync_rng = True
+    root2, root1 = str(tmp_path / "two"), str(tmp_path / "one")
+    os.makedirs(root2)
+    os.makedirs(root1)
+    env0 = dict(os.environ)
+    try:
+        mp.spawn(_flavour_worker, args=(2, 30300 + os.getpid() % 1000, root2, which), nprocs=2, join=True)
+    finally:
+        os.environ.clear()
+        os.environ.update(env0)
+    cwd = os.getcwd()
+    os.chdir(root1)
+    try:
+        random.seed(60)
+        np.random.seed(70)
+        argv = list(FLAVOUR_ARGV[which])
+        argv[argv.index("OUT")] = os.path.join(root1, "sp_")
+        net = _flavour_main(which)(argv, device="cuda:0", comm=_SyncOnly())
+    finally:
+        os.chdir(cwd)
+    torch.cuda.synchronize()
+    files = sorted(os.listdir(root2))
+    assert "dp_model-3.npz" in files and not [f for f in files if ".tmp" in f]
+    a, b = np.load(os.path.join(root2, "dp_params.npy")), net.params.cpu().numpy()
+    assert float(np.abs(a - b).max() / np.abs(b).max()) < 1e-3          # same patches, sizes and augmentation; sums grouped differently
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # band-partitioned sliding-window inference: window rows cut into one band per rank, boundary rows exchanged,
 # uint8 label bands gathered -- against the single-process map.
