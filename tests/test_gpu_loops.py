@@ -291,3 +291,27 @@ def test_tensorflow_bundle_checkpoint_roundtrip(tmp_path):
     a.feed(x, None, S)
     b.feed(x, None, S)
     assert torch.equal(a.forward(B, S)[1], b.forward(B, S)[1])
+
+
+@pytest.mark.parametrize("script,args,expect", [
+    ("isprs_dilated_random.py", ["synthetic:70x80x5/vaihingen/", "OUT", "none", "a,b", "c", "0.01", "0.005", "4", "2", "25", "10", "dilated8_grsl",
+                                 "multi_fixed", "9,13", "acc", "training"], "model-2.npz"),
+    ("coffee_dilated_random.py", ["synthetic:2x60x60x3/", "synthetic:1x60x60x3/", "OUT", "none", "0.01", "0.001", "6", "2", "25", "10",
+                                  "dilated_icpr_rate6_small", "multi_fixed", "9,13", "loss"], "model-2.npz"),
+    ("contest_dilated_random.py", ["synthetic:80x70x3/", "OUT", "none", "0.01", "0.001", "4", "2", "25", "10", "dilated_grsl", "multi_fixed", "9,13",
+                                   "acc", "train"], "model-2.npz"),
+])
+def test_entry_scripts_run_as_processes(tmp_path, script, args, expect):
+    """the three scripts at the repository root, started the way a user of the reference starts them (own process, positional
+    arguments): exit status 0, the reference's progress lines, the checkpoint where the reference puts it"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path) + "/"
+    argv = [out if a == "OUT" else a for a in args]
+    r = subprocess.run([sys.executable, os.path.join(root, script)] + argv, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert os.path.isfile(out + expect), os.listdir(out)
+    assert "Iter" in r.stdout or "iter" in r.stdout or "Step" in r.stdout, r.stdout[-1000:]
+    r = subprocess.run([sys.executable, os.path.join(root, script), "too", "few"], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
