@@ -584,6 +584,198 @@ __global__ __launch_bounds__(256, BN <= 128 ? 3 : 2) void conv_split_half_kernel
 #endif
 }
 
+// ---- three terms on the 16x16x32 MFMA shape.  The chip holds a higher clock under v_mfma_f32_16x16x32_bf16 than under the 32x32x16
+// form (bare loops on random operands, 4 workgroups per CU: 1.75 against 1.33 PFLOP/s, tools/ubench/mfma_shape.hip), but its K of 32
+// is a whole K-step, two LDS stages of the half-stage image.  So one MFMA multiplies TWO of the six partial products of a 16-channel
+// half instead: its 32-deep K is [16 channels of one term | 16 channels of another], A-side and B-side chosen so that the pairs
+//   (a1 b0 + a2 b0), (a0 b1 + a0 b2), (a0 b0 + a1 b1)
+// come out -- three MFMAs per 16x16 tile and half, the same flops as six 32x32x16 ones per 32x32 tile.  A lane's k-chunk q = lane / 16
+// (8 of the 32 k) therefore reads piece q & 1 of the 32-byte image row of term T[q >> 1]; with 32-byte rows the 16 lanes of every
+// ds_read_b128 group already cover the 256-byte bank row once, so this image is NOT swizzled.
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv_split_half16_kernel(const SplitConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass has no LDS-DMA builtin; it only needs the launch stub
+  constexpr int BM = 128, WM = 2, WN = 2, NS = 3;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 16, TN = WTN / 16;
+  constexpr int HK = 16;                               // channels per half
+  constexpr int ROWB = HK * 2;                         // bytes per image row (32)
+  constexpr int PLANE_A = BM * ROWB, PLANE_B = BN * ROWB;
+  constexpr int STAGE = NS * (PLANE_A + PLANE_B);
+  constexpr int NIA = NS * (BM / 32), NIB = NS * (BN / 32);    // DMA instructions per half (32 rows each), over the 4 waves
+  static_assert(WTN % 16 == 0, "wave tile");
+
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 15, q = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+  const int ntn = a.Cout / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / ntn) * BM;
+  const int n0 = (tile % ntn) * BN;
+  const int Sp = a.S + 2 * a.P;
+  const int Ktot = a.k * a.k * a.Cin;
+
+  // DMA lane roles: a wave-instruction fills rows 32 j .. 32 j + 31 of one term plane; lane l fills row 32 j + (l >> 1), piece l & 1.
+  // Wave w takes row block j = w (+ 4, ...) of every term.
+  const int dpiece = (lane & 1) * 16;                 // bytes
+  uint32_t offA[BM / 128], offB[(BN + 127) / 128];
+#pragma unroll
+  for (int i = 0; i < BM / 128; ++i) {
+    int p = m0 + 32 * (wave + 4 * i) + (lane >> 1);
+    p = p < a.M ? p : a.M - 1;
+    offA[i] = (NS * (padded_pixel_off(p, a.S, a.P, a.ld_in, a.rcpS, a.rcpSS, -a.pad, -a.pad) + (uint32_t)a.coff_in)) * 2u + (uint32_t)dpiece;
+  }
+#pragma unroll
+  for (int i = 0; i < (BN + 127) / 128; ++i) {
+    int o = n0 + 32 * (wave + 4 * i) + (lane >> 1);
+    o = o < a.Cout ? o : a.Cout - 1;                    // (BN = 64 / 192: row blocks past the tile are not issued)
+    offB[i] = (uint32_t)(NS * o * Ktot) * 2u + (uint32_t)dpiece;
+  }
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.f;
+
+  const int cpt = a.Cin / BK;
+  int u_lo, u_hi;
+  live_tap_rows(m0, BM, a.M, a.S, a.k, a.rate, a.pad, a.rcpS, a.rcpSS, u_lo, u_hi);
+  if (!a.skip_halo) { u_lo = 0; u_hi = a.k; }
+  u_lo = __builtin_amdgcn_readfirstlane(u_lo);
+  u_hi = __builtin_amdgcn_readfirstlane(u_hi);
+  const int nks = (u_hi - u_lo) * a.k * cpt;
+  const char* inb = reinterpret_cast<const char*>(a.in);
+  const char* wbase = reinterpret_cast<const char*>(a.w);
+  int lu = u_lo, lv = 0, lc = 0;                       // (tap row, tap column, channel chunk) of the K-step being fetched
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+
+  auto issue = [&](int half, int stage) {
+    unsigned char* sa = lds + stage * STAGE;
+    unsigned char* sb = sa + NS * PLANE_A;
+    // fp32 element offset of (tap, chunk) in the slab -> term image: * NS, term s at + 32 s elements, half at + 16 elements
+    const uint32_t aoff = (uint32_t)(NS * ((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK) + half * HK) * 2u;
+    const uint32_t boff = (uint32_t)(NS * (((lu * a.k + lv) * cpt + lc) * BK) + half * HK) * 2u;
+    const char* ab = inb + (size_t)aoff;
+    const char* wb = wbase + (size_t)boff;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      // one scalar base per term, kept opaque: otherwise LLVM folds the term offset into a 64-bit VECTOR add per load
+      const char* as = ab + s * 64;
+      const char* ws = wb + s * 64;
+      asm volatile("" : "+s"(as));
+      asm volatile("" : "+s"(ws));
+#pragma unroll
+      for (int i = 0; i < BM / 128; ++i) {
+        uint32_t o = offA[i]; asm volatile("" : "+v"(o));
+        __builtin_amdgcn_global_load_lds(as + o, (lds_ptr)(sa + s * PLANE_A + (wave + 4 * i) * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < (BN + 127) / 128; ++i) {
+        if (32 * (wave + 4 * i) < BN) {                // wave-uniform
+          uint32_t o = offB[i]; asm volatile("" : "+v"(o));
+          __builtin_amdgcn_global_load_lds(ws + o, (lds_ptr)(sb + s * PLANE_B + (wave + 4 * i) * 1024), 16, 0, 0);
+        }
+      }
+    }
+  };
+  auto next_kstep = [&]() { if (++lv == a.k) { lv = 0; if (++lu == u_hi) { lu = u_lo; ++lc; } } };
+
+  // fragment offsets (bytes): row * 32 + (q & 1) * 16 inside the plane of the term this lane's k-chunk belongs to.
+  // kinds: 0 = [t0 | t1], 1 = [t0 | t0] (A) / [t1 | t2] (B), 2 = [t1 | t2] (A) / [t0 | t0] (B)
+  const int hi = q >> 1;
+  const uint32_t rowa = (uint32_t)((wm * WTM + li) * ROWB + (q & 1) * 16);
+  const uint32_t rowb = (uint32_t)((wn * WTN + li) * ROWB + (q & 1) * 16);
+  const uint32_t fa01 = rowa + (uint32_t)(hi ? 1 : 0) * PLANE_A, fa00 = rowa, fa12 = rowa + (uint32_t)(hi ? 2 : 1) * PLANE_A;
+  const uint32_t fb01 = rowb + (uint32_t)(hi ? 1 : 0) * PLANE_B, fb12 = rowb + (uint32_t)(hi ? 2 : 1) * PLANE_B, fb00 = rowb;
+  auto compute = [&](int stage) {
+    const unsigned char* sa = lds + stage * STAGE;
+    const unsigned char* sb = sa + NS * PLANE_A;
+    bf16x8 a01[TM], a00[TM], a12[TM], b01[TN], b12[TN], b00[TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+      a12[mi] = *reinterpret_cast<const bf16x8*>(sa + mi * 16 * ROWB + fa12);
+      a00[mi] = *reinterpret_cast<const bf16x8*>(sa + mi * 16 * ROWB + fa00);
+      a01[mi] = *reinterpret_cast<const bf16x8*>(sa + mi * 16 * ROWB + fa01);
+    }
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+      b00[ni] = *reinterpret_cast<const bf16x8*>(sb + ni * 16 * ROWB + fb00);
+      b12[ni] = *reinterpret_cast<const bf16x8*>(sb + ni * 16 * ROWB + fb12);
+      b01[ni] = *reinterpret_cast<const bf16x8*>(sb + ni * 16 * ROWB + fb01);
+    }
+    // smallest partial products first: (a1 b0 + a2 b0), (a0 b1 + a0 b2), (a0 b0 + a1 b1)
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a12[mi], b00[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00[mi], b12[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a01[mi], b01[ni], acc[mi][ni], 0, 0, 0);
+  };
+
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int ks = 0; ks < nks; ++ks) {
+    issue(1, 1);                                  // second half of this K-step lands while the first is multiplied
+    compute(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    next_kstep();
+    if (ks + 1 < nks) issue(0, 0);                // first half of the next K-step (every wave is done with stage 0)
+    compute(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: 16x16 C/D map col = lane & 15, row = 4 * (lane >> 4) + reg
+  float bv[TN];
+#pragma unroll
+  for (int ni = 0; ni < TN; ++ni) {
+    const int col = n0 + wn * WTN + ni * 16 + li;
+    bv[ni] = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * WTM + mi * 16 + 4 * q + r;
+        if (row < a.M) {
+          float v = acc[mi][ni][r] + bv[ni];
+          float* dst = a.out + (size_t)row * a.ld_out + a.coff_out + col;
+          if (a.accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+  }
+  if (a.stats) {      // the 16x16 C/D map puts a column in 4 lanes
+    const int rem = a.M - m0;
+    tile_column_stats<TN, WM, BN>(
+        reinterpret_cast<float*>(lds), t, wm, q == 0, (float)(rem < BM ? rem : BM), [&](int ni) { return wn * WTN + ni * 16 + li; },
+        [](float s) { s += __shfl_xor(s, 16); return s + __shfl_xor(s, 32); },
+        [&](int ni, auto f) {
+#pragma unroll
+          for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (m0 + wm * WTM + mi * 16 + 4 * q + r < a.M) f(acc[mi][ni][r] + bv[ni]);
+        },
+        a.stats + ((size_t)(m0 / BM) * a.Cout + n0) * 2);
+  }
+#endif
+}
+
 int g_variant = 1;      // 0: register-staged tiles everywhere, 1: LDS-DMA double-buffered tiles for the two-term arithmetic
                         // (development switch, see drs_debug_variant)
 
@@ -604,12 +796,27 @@ int dispatch_split(const SplitConvArgs& a, hipStream_t st) {
   // three terms: every form of the 128 x 128 tile (register-staged, LDS-DMA, half-stage LDS-DMA) runs into the same wall -- the
   // chip holds ~1.9 GHz with the matrix pipe ~48 % busy on these operands, whatever the kernel does (profiles/r02/split_forms.txt) --
   // so the half-stage form is used where it is the only one AT the wall: the 192-wide tile (+20 %) and the 256-wide one (+2 %)
+  if constexpr (NS == 3) {
+    if (g_variant == 3) {
+      const int mt = (a.M + 127) / 128;
+      if (a.Cout % 128 == 0) DRS_LAUNCH((conv_split_half16_kernel<128>), dim3(mt * (a.Cout / 128)), dim3(256), 0, st, a);
+      else if (a.Cout % 192 == 0) DRS_LAUNCH((conv_split_half16_kernel<192>), dim3(mt * (a.Cout / 192)), dim3(256), 0, st, a);
+      else DRS_LAUNCH((conv_split_half16_kernel<64>), dim3(mt * (a.Cout / 64)), dim3(256), 0, st, a);
+      return DRS_LAUNCH_CHECK();
+    }
+  }
   const bool half = g_variant == 2 || (g_variant == 1 && NS == 3 && g_wide);
   if (half && a.Cout % 256 == 0) {
     DRS_LAUNCH((conv_split_half_kernel<256, NS>), dim3(((a.M + 127) / 128) * (a.Cout / 256)), dim3(256), 0, st, a);
     return DRS_LAUNCH_CHECK();
   }
   if (half && a.Cout % 192 == 0 && a.Cout % 128 != 0) {
+    if constexpr (NS == 3) {      // the 16x16x32 form: conv5 1.49 -> 1.35 ms, conv6 2.15 -> 2.06 against the 32x32x16 half-stage form
+      if (g_variant == 1) {
+        DRS_LAUNCH((conv_split_half16_kernel<192>), dim3(((a.M + 127) / 128) * (a.Cout / 192)), dim3(256), 0, st, a);
+        return DRS_LAUNCH_CHECK();
+      }
+    }
     DRS_LAUNCH((conv_split_half_kernel<192, NS>), dim3(((a.M + 127) / 128) * (a.Cout / 192)), dim3(256), 0, st, a);
     return DRS_LAUNCH_CHECK();
   }
