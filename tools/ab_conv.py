@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """In-process A/B of the forward / input-gradient kernel on the Dilated8Pooling shapes (development aid): interleaved repetitions on
 one device, best-of per arm, bitwise comparison of the outputs.  mode=variant: kernel forms (0 = register-staged, 1 = LDS-DMA);
-mode=wide192: Cout = 192 as three 128x64 tiles (0) or one 128x192 tile (1).
+mode=wide192: Cout = 192 as three 128x64 tiles (0) or one 128x192 tile (1); mode=skip: all-halo tap rows skipped by the size rule (0) or always (1).
     python tools/ab_conv.py [B=128] [S=64] [mode=variant]"""
 import os, sys
 import torch
@@ -12,7 +12,7 @@ DEV = "cuda:0"
 
 def main(B=128, S=64, rounds=4, mode="variant"):
     lib = _lib.load()
-    setter = lib.drs_debug_conv_variant if mode == "variant" else lib.drs_debug_conv_wide192
+    setter = {"variant": lib.drs_debug_conv_variant, "wide192": lib.drs_debug_conv_wide192, "skip": (lambda v: lib.drs_debug_skip_taps(1 + v))}[mode]
     plan = Plan("dilated_grsl_rate8", 5, 6, first_cin_pad=8)
     st = torch.cuda.current_stream(DEV).cuda_stream
     M = B * S * S
@@ -58,6 +58,7 @@ def main(B=128, S=64, rounds=4, mode="variant"):
     print("total  " + "  ".join("%s v%d %.3f ms" % (d, v, tot[(v, d)]) for d in ("fwd", "dgrad") for v in (0, 1)))
     lib.drs_debug_conv_variant(-1)
     lib.drs_debug_conv_wide192(1)
+    lib.drs_debug_skip_taps(1)
 
 if __name__ == "__main__":
     kw = dict(a.split("=") for a in sys.argv[1:])
