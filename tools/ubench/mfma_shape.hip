@@ -10,8 +10,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // 64 x 64 wave tile, fp32: 2 x 2 tiles of 32x32x2 (4 accumulators), K advanced by 2 per MFMA group
+__device__ int g_prio_shift = -1;
+__device__ __forceinline__ void static_prio() {
+  const int sh = g_prio_shift;
+  if (sh >= 0) {
+    const int p = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> sh) & 3);
+    if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p == 3) __builtin_amdgcn_s_setprio(3);
+  }
+}
 template <int OCC>
 __global__ __launch_bounds__(256, OCC) void f32_32(const float* in, float* out, int iters) {
+  static_prio();
   f32x16 acc[4];
   for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float a[2][8], b[2][8];
@@ -102,7 +113,9 @@ int main(int argc, char** argv) {
   hipMemcpy(in, h.data(), 65536 * 4, hipMemcpyHostToDevice);
   const int per_cu = argc > 2 ? atoi(argv[2]) : 4;
   const int blocks = 256 * per_cu;   // default: 4 workgroups of 4 waves per CU, as the convolution kernels run
-  printf("%d workgroups of 4 waves per CU\n", per_cu);
+  const int shift = argc > 3 ? atoi(argv[3]) : -1;
+  hipMemcpyToSymbol(HIP_SYMBOL(g_prio_shift), &shift, sizeof(int));
+  printf("%d workgroups of 4 waves per CU, static priority shift %d\n", per_cu, shift);
   printf("%s operands\n", zero ? "all-zero" : "random");
   for (int round = 0; round < 2; ++round) {
     run(f32_32<1>, in, out, blocks, 2000, 8 * 4 * 2.0 * 32 * 32 * 2, "f32  32x32x2 (AGPR acc)");
