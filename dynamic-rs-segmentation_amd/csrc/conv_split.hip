@@ -796,6 +796,15 @@ int dispatch_split(const SplitConvArgs& a, hipStream_t st) {
   // three terms: every form of the 128 x 128 tile built here (register-staged, LDS-DMA, half-stage LDS-DMA, 16x16x32) ends at the
   // same rate, the ceiling of the 128^2-tile / two-barrier structure (profiles/r02/split_forms.txt); the half-stage forms are used
   // where the older ones were BELOW it: the 192-wide tile (+20 %) and the 256-wide one (+2 %)
+  if constexpr (NS == 3) {      // development arm (tools/bench_split.py SPLIT_CASES=33)
+    const int mt = (a.M + 127) / 128;
+    if (g_variant == 3) {       // the 16x16x32 form everywhere
+      if (a.Cout % 128 == 0) DRS_LAUNCH((conv_split_half16_kernel<128>), dim3(mt * (a.Cout / 128)), dim3(256), 0, st, a);
+      else if (a.Cout % 192 == 0) DRS_LAUNCH((conv_split_half16_kernel<192>), dim3(mt * (a.Cout / 192)), dim3(256), 0, st, a);
+      else DRS_LAUNCH((conv_split_half16_kernel<64>), dim3(mt * (a.Cout / 64)), dim3(256), 0, st, a);
+      return DRS_LAUNCH_CHECK();
+    }
+  }
   const bool half = g_variant == 2 || (g_variant == 1 && NS == 3 && g_wide);
   if (half && a.Cout % 256 == 0) {
     DRS_LAUNCH((conv_split_half_kernel<256, NS>), dim3(((a.M + 127) / 128) * (a.Cout / 256)), dim3(256), 0, st, a);
