@@ -63,7 +63,17 @@ __global__ void split_planes_kernel(const float* __restrict__ src, uint16_t* __r
 
 // forward filter:  row o, K index kf = tap*cin_pad + c          holds (c < cin ? w[tap][c][o] : 0)
 // gradient filter: row c, K index kd = (taps-1-tap)*cout + o    holds w[tap][c][o]        (c < cin)
-// term s of K index kk of a row of length Ktot sits at row*Ktot*NS + (kk & ~31)*NS + 32 s + (kk & 31)
+// NS = 2: term s of K index kk of a row of length Ktot sits at row*Ktot*NS + (kk & ~31)*NS + 32 s + (kk & 31)
+// NS = 3: blocked by 16-deep HALF K-steps -- [K/16][NS][rows][16]: term s of K index kk of row r (of nrows) sits at
+//         (((kk >> 4) * NS + s) * nrows + r) * 16 + (kk & 15).  The B tile of one half K-step and term is then ONE contiguous run of
+//         32-byte rows: the forward kernels fetch it in whole cache lines (with the row-major form a 16-channel piece is 32 bytes out
+//         of every K*NS*2, a quarter of each line fetched; an ablation put the filter fetch at a third of the forward kernel's time)
+template <int NS>
+__device__ __forceinline__ size_t filter_term_off(int row, int kk, int s, int nrows, int Ktot) {
+  if constexpr (NS == 3) return ((size_t)((kk >> 4) * NS + s) * nrows + row) * 16 + (kk & 15);
+  else return (size_t)row * Ktot * NS + (size_t)(kk & ~31) * NS + 32 * s + (kk & 31);
+}
+
 template <int NS>
 __global__ void filter_split_kernel(const float* __restrict__ w, int taps, int cin, int cin_pad, int cout,
                                     uint16_t* __restrict__ wf, uint16_t* __restrict__ wd) {
@@ -72,24 +82,27 @@ __global__ void filter_split_kernel(const float* __restrict__ w, int taps, int c
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nf + nd; i += gridDim.x * blockDim.x) {
     float v;
     uint16_t* dst;
+    int row, kk, nrows, ktot;
     if (i < nf) {
       const int c = i % cin_pad;
       const int rest = i / cin_pad;
       const int tap = rest % taps, o = rest / taps;
       v = c < cin ? w[((size_t)tap * cin + c) * cout + o] : 0.f;
-      dst = wf + (size_t)(i & ~31) * NS + (i & 31);
+      dst = wf;
+      row = o; kk = tap * cin_pad + c; nrows = cout; ktot = taps * cin_pad;
     } else {
       const int j = i - nf;
       const int o = j % cout;
       const int rest = j / cout;
       const int tapr = rest % taps, c = rest / taps;
       v = w[((size_t)(taps - 1 - tapr) * cin + c) * cout + o];
-      dst = wd + (size_t)(j & ~31) * NS + (j & 31);
+      dst = wd;
+      row = c; kk = tapr * cout + o; nrows = cin; ktot = taps * cout;
     }
     uint32_t t[NS];
     split_terms<NS>(v, t);
 #pragma unroll
-    for (int s = 0; s < NS; ++s) dst[32 * s] = (uint16_t)t[s];
+    for (int s = 0; s < NS; ++s) dst[filter_term_off<NS>(row, kk, s, nrows, ktot)] = (uint16_t)t[s];
   }
 }
 
@@ -170,7 +183,12 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const SplitConvArgs a) 
 #pragma unroll
       for (int i = 0; i < NA; ++i) ra[s][i] = *reinterpret_cast<const u32x4*>(a.in + offA[i] + soff + 32 * s);
 #pragma unroll
-      for (int i = 0; i < NB; ++i) rb[s][i] = *reinterpret_cast<const u32x4*>(a.w + offB[i] + NS * ks * BK + 32 * s);
+      for (int i = 0; i < NB; ++i) {
+        if constexpr (NS == 3)      // blocked filter image: this thread's 16-byte chunk (t & 3) is half (t & 3) >> 1, piece t & 1 of its row
+          rb[s][i] = *reinterpret_cast<const u32x4*>(a.w + ((size_t)((ks * 2 + ((t & 3) >> 1)) * NS + s) * a.Cout + (n0 + lrow + 64 * i)) * 16 + (t & 1) * 8);
+        else
+          rb[s][i] = *reinterpret_cast<const u32x4*>(a.w + offB[i] + NS * ks * BK + 32 * s);
+      }
     }
     if (++lc == cpt) { lc = 0; if (++lv == a.k) { lv = 0; ++lu; } }
   };
@@ -451,7 +469,7 @@ __global__ __launch_bounds__(256, BN <= 128 ? 3 : 2) void conv_split_half_kernel
   for (int i = 0; i < (BN + 127) / 128; ++i) {
     int o = n0 + 32 * (wave + 4 * i) + (lane >> 1);
     o = o < a.Cout ? o : a.Cout - 1;                    // (BN = 64 / 192: row blocks past the tile are not issued)
-    offB[i] = (uint32_t)(NS * o * Ktot) * 2u + (uint32_t)dpiece;
+    offB[i] = NS == 3 ? (uint32_t)o * 32u + (uint32_t)dpiece : (uint32_t)(NS * o * Ktot) * 2u + (uint32_t)dpiece;
   }
 
   f32x16 acc[TM][TN];
@@ -479,14 +497,16 @@ __global__ __launch_bounds__(256, BN <= 128 ? 3 : 2) void conv_split_half_kernel
     unsigned char* sb = sa + NS * PLANE_A;
     // fp32 element offset of (tap, chunk) in the slab -> term image: * NS, term s at + 32 s elements, half at + 16 elements
     const uint32_t aoff = (uint32_t)(NS * ((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK) + half * HK) * 2u;
-    const uint32_t boff = (uint32_t)(NS * (((lu * a.k + lv) * cpt + lc) * BK) + half * HK) * 2u;
+    const uint32_t boff = NS == 3 ? (uint32_t)(((((lu * a.k + lv) * cpt + lc) * 2 + half) * NS) * a.Cout) * 32u
+                                  : (uint32_t)(NS * (((lu * a.k + lv) * cpt + lc) * BK) + half * HK) * 2u;
+    const uint32_t bterm = NS == 3 ? (uint32_t)a.Cout * 32u : 64u;       // bytes from one term's rows to the next
     const char* ab = inb + (size_t)aoff;
     const char* wb = wbase + (size_t)boff;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       // one scalar base per term, kept opaque: otherwise LLVM folds the term offset into a 64-bit VECTOR add per load
       const char* as = ab + s * 64;
-      const char* ws = wb + s * 64;
+      const char* ws = wb + s * bterm;
       asm volatile("" : "+s"(as));
       asm volatile("" : "+s"(ws));
 #pragma unroll
@@ -632,7 +652,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_half16_kernel(const SplitCo
   for (int i = 0; i < (BN + 127) / 128; ++i) {
     int o = n0 + 32 * (wave + 4 * i) + (lane >> 1);
     o = o < a.Cout ? o : a.Cout - 1;                    // (BN = 64 / 192: row blocks past the tile are not issued)
-    offB[i] = (uint32_t)(NS * o * Ktot) * 2u + (uint32_t)dpiece;
+    offB[i] = NS == 3 ? (uint32_t)o * 32u + (uint32_t)dpiece : (uint32_t)(NS * o * Ktot) * 2u + (uint32_t)dpiece;
   }
 
   f32x4 acc[TM][TN];
@@ -660,14 +680,16 @@ __global__ __launch_bounds__(256, 2) void conv_split_half16_kernel(const SplitCo
     unsigned char* sb = sa + NS * PLANE_A;
     // fp32 element offset of (tap, chunk) in the slab -> term image: * NS, term s at + 32 s elements, half at + 16 elements
     const uint32_t aoff = (uint32_t)(NS * ((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK) + half * HK) * 2u;
-    const uint32_t boff = (uint32_t)(NS * (((lu * a.k + lv) * cpt + lc) * BK) + half * HK) * 2u;
+    const uint32_t boff = NS == 3 ? (uint32_t)(((((lu * a.k + lv) * cpt + lc) * 2 + half) * NS) * a.Cout) * 32u
+                                  : (uint32_t)(NS * (((lu * a.k + lv) * cpt + lc) * BK) + half * HK) * 2u;
+    const uint32_t bterm = NS == 3 ? (uint32_t)a.Cout * 32u : 64u;       // bytes from one term's rows to the next
     const char* ab = inb + (size_t)aoff;
     const char* wb = wbase + (size_t)boff;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       // one scalar base per term, kept opaque: otherwise LLVM folds the term offset into a 64-bit VECTOR add per load
       const char* as = ab + s * 64;
-      const char* ws = wb + s * 64;
+      const char* ws = wb + s * bterm;
       asm volatile("" : "+s"(as));
       asm volatile("" : "+s"(ws));
 #pragma unroll
@@ -793,32 +815,24 @@ int g_wide = 1;         // development switch (drs_debug_split_wide): 256-wide N
 
 template <int NS>
 int dispatch_split(const SplitConvArgs& a, hipStream_t st) {
-  // three terms: every form of the 128 x 128 tile built here (register-staged, LDS-DMA, half-stage LDS-DMA, 16x16x32) ends at the
-  // same rate, the ceiling of the 128^2-tile / two-barrier structure (profiles/r02/split_forms.txt); the half-stage forms are used
-  // where the older ones were BELOW it: the 192-wide tile (+20 %) and the 256-wide one (+2 %)
-  if constexpr (NS == 3) {      // development arm (tools/bench_split.py SPLIT_CASES=33)
+  // three terms (bf16x6): the 16x16x32 half-stage form on every tile width (with the blocked filter image it is the fastest form on
+  // every Dilated8Pooling shape, profiles/r02/split_forms.txt); development arms: 0 = register-staged, 2 = 32x32x16 half-stage
+  if constexpr (NS == 3) {
     const int mt = (a.M + 127) / 128;
-    if (g_variant == 3) {       // the 16x16x32 form everywhere
+    if (g_variant == 1 || g_variant == 3) {
       if (a.Cout % 128 == 0) DRS_LAUNCH((conv_split_half16_kernel<128>), dim3(mt * (a.Cout / 128)), dim3(256), 0, st, a);
       else if (a.Cout % 192 == 0) DRS_LAUNCH((conv_split_half16_kernel<192>), dim3(mt * (a.Cout / 192)), dim3(256), 0, st, a);
       else DRS_LAUNCH((conv_split_half16_kernel<64>), dim3(mt * (a.Cout / 64)), dim3(256), 0, st, a);
       return DRS_LAUNCH_CHECK();
     }
-  }
-  const bool half = g_variant == 2 || (g_variant == 1 && NS == 3 && g_wide);
-  if (half && a.Cout % 256 == 0) {
-    DRS_LAUNCH((conv_split_half_kernel<256, NS>), dim3(((a.M + 127) / 128) * (a.Cout / 256)), dim3(256), 0, st, a);
-    return DRS_LAUNCH_CHECK();
-  }
-  if (half && a.Cout % 192 == 0 && a.Cout % 128 != 0) {
-    if constexpr (NS == 3) {      // the 16x16x32 form: conv5 1.49 -> 1.35 ms, conv6 2.15 -> 2.06 against the 32x32x16 half-stage form
-      if (g_variant == 1) {
-        DRS_LAUNCH((conv_split_half16_kernel<192>), dim3(((a.M + 127) / 128) * (a.Cout / 192)), dim3(256), 0, st, a);
-        return DRS_LAUNCH_CHECK();
-      }
+    if (g_variant == 2 && g_wide && a.Cout % 256 == 0) {
+      DRS_LAUNCH((conv_split_half_kernel<256, NS>), dim3(mt * (a.Cout / 256)), dim3(256), 0, st, a);
+      return DRS_LAUNCH_CHECK();
     }
-    DRS_LAUNCH((conv_split_half_kernel<192, NS>), dim3(((a.M + 127) / 128) * (a.Cout / 192)), dim3(256), 0, st, a);
-    return DRS_LAUNCH_CHECK();
+    if (g_variant == 2 && a.Cout % 192 == 0 && a.Cout % 128 != 0) {
+      DRS_LAUNCH((conv_split_half_kernel<192, NS>), dim3(mt * (a.Cout / 192)), dim3(256), 0, st, a);
+      return DRS_LAUNCH_CHECK();
+    }
   }
   if (a.Cout % 128 == 0) return launch_split<128, 128, 2, 2, NS>(a, st);
   if (a.Cout % 192 == 0) return launch_split<128, 192, 2, 2, NS>(a, st);
