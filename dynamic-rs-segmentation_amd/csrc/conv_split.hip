@@ -1230,6 +1230,198 @@ __global__ __launch_bounds__((TO / 64) * 128) void wgrad_split_dma_kernel(const 
 #endif
 }
 
+// ---- the LDS-DMA filter gradient in HALF stages (as wgrad_dma_kernel does it for exact fp32): the double-buffered image holds two
+// 16-pixel halves of a 32-pixel chunk, so three terms of both operands take 48 KB (TO = 128) and three workgroups share a CU; one
+// v_mfma_f32_32x32x16_bf16 k-step per half; the DMA of half h + 1 lands while half h is multiplied.  Swizzles, lane roles and the
+// order of every sum are those of wgrad_split_dma_kernel (its swizzle is periodic in 16 pixel rows).
+template <int TO, int NS>
+__global__ __launch_bounds__((TO / 64) * 128) void wgrad_split_half_kernel(const SplitWgradArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass has no LDS-DMA builtin; it only needs the launch stub
+  constexpr int TR = 128;
+  constexpr int WC = TO / 64;
+  constexpr int NW = 2 * WC;                    // waves
+  constexpr int BP = 32;
+  constexpr int XROW = TR * 2, GROW = TO * 2;   // bytes per image row
+  constexpr int HP = 16;                        // pixels per stage
+  constexpr int XT = HP * XROW, GT = HP * GROW; // bytes per term half tile
+  constexpr int STAGE = NS * (XT + GT);
+  constexpr int IX = 4 / NW;                    // X DMA instructions per wave, term and half (4 pixel rows each)
+  constexpr int IG = (GT / 1024) / NW;          // G DMA instructions per wave, term and half (4 or 8 pixel rows each)
+  static_assert(IX >= 1 && IG >= 1, "wave layout");
+  constexpr int GRPI = 1024 / GROW;             // pixel rows per G instruction
+
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+  __shared__ uint32_t tabx[2][BP], tabg[2][BP];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 31, h = lane >> 5;
+  const int wr = wave / WC, wc = wave % WC;
+
+  const int ntile = a.ntr * a.nto;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = id / ntile;
+  const int tile = id % ntile;
+  const int R0 = (tile / a.nto) * TR;
+  const int o0 = a.o_base + (tile % a.nto) * TO;
+  const int rows_all = a.k * a.k * a.Cin;
+  const int Sxp = a.S + 2 * a.Px;
+
+  // DMA lane roles.  X instruction j: pixel row 4 j + (lane >> 4), slot lane & 15 <- source chunk slot ^ fX(row)
+  uint32_t xconst[IX];
+  int xrow[IX];
+#pragma unroll
+  for (int i = 0; i < IX; ++i) {
+    const int j = wave + NW * i;
+    xrow[i] = 4 * j + (lane >> 4);
+    const int chunk = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (j & 3));
+    int R = R0 + chunk * 8;
+    R = R < rows_all ? R : 0;
+    const int tap = R / a.Cin, c0 = R % a.Cin;
+    const int u = tap / a.k, v = tap % a.k;
+    xconst[i] = (uint32_t)(NS * ((u * a.rate * Sxp + v * a.rate) * a.ld_x + a.coff_x + (c0 & ~31)) + (c0 & 31));
+  }
+  uint32_t gconst;
+  int grow[IG];
+  {
+    const int slot = TO == 128 ? (lane & 15) : (lane & 7);
+    const int chunk = TO == 128 ? (slot ^ ((((lane >> 4) & 3) << 2) | (wave & 3))) : (slot ^ (((lane >> 4) & 1) << 2));
+    const int og0 = o0 + chunk * 8;
+    gconst = (uint32_t)(NS * (a.coff_g + (og0 & ~31)) + (og0 & 31));
+#pragma unroll
+    for (int i = 0; i < IG; ++i) grow[i] = GRPI * (wave + NW * i) + (TO == 128 ? (lane >> 4) : (lane >> 3));
+  }
+  static_assert(TO == 64 || NW == 4, "the TO = 128 G swizzle uses j & 3 == wave");
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int nchunks_total = (a.M + BP - 1) / BP;
+  const int cbeg = split * a.chunks_per_split;
+  int cend = cbeg + a.chunks_per_split;
+  cend = cend < nchunks_total ? cend : nchunks_total;
+
+  // chunks whose pixel rows meet only halo zeros for this tile's tap rows are jumped over (wgrad_kernel in conv_mfma.hip)
+  int live_lo, live_hi;
+  {
+    const int rlast = (R0 + TR < rows_all ? R0 + TR : rows_all) - 1;
+    live_pixel_range(R0, rlast, a.Cin, a.k, a.rate, a.pad, a.S, a.skip_halo, live_lo, live_hi);
+  }
+  const int S2 = a.S * a.S;
+  auto next_chunk = [&](int c) { return next_live_chunk(c, S2, a.rcpSS, live_lo, live_hi); };
+  auto fill_tables = [&](int chunk, int slot) {
+    if (t < BP && chunk < cend) {
+      const int p = chunk * BP + t;
+      const int pc = p < a.M ? p : a.M - 1;
+      tabx[slot][t] = padded_pixel_off(pc, a.S, a.Px, a.ld_x, a.rcpS, a.rcpSS, -a.pad, -a.pad);
+      tabg[slot][t] = p < a.M ? padded_pixel_off(pc, a.S, a.Pg, a.ld_g, a.rcpS, a.rcpSS, 0, 0) : 0u;   // 0 = a halo pixel: zeros
+    }
+  };
+  auto issue = [&](int slot, int half, int stage) {       // half `half` of the chunk whose pixel offsets are in table slot `slot`
+    const uint32_t* tx = tabx[slot] + half * HP;
+    const uint32_t* tg = tabg[slot] + half * HP;
+    unsigned char* sb = lds + stage * STAGE;
+    uint32_t ox[IX], og[IG];
+#pragma unroll
+    for (int i = 0; i < IX; ++i) ox[i] = NS * tx[xrow[i]] + xconst[i];
+#pragma unroll
+    for (int i = 0; i < IG; ++i) og[i] = NS * tg[grow[i]] + gconst;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int i = 0; i < IX; ++i)
+        __builtin_amdgcn_global_load_lds(a.x + ox[i] + 32 * s,
+                                         (__attribute__((address_space(3))) void*)(sb + s * XT + (wave + NW * i) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < IG; ++i)
+        __builtin_amdgcn_global_load_lds(a.g + og[i] + 32 * s,
+                                         (__attribute__((address_space(3))) void*)(sb + NS * XT + s * GT + (wave + NW * i) * 1024), 16, 0, 0);
+    }
+  };
+
+  int ck0 = next_chunk(cbeg - 1);
+  if (ck0 < cend) {
+    int ck1 = next_chunk(ck0);
+    // transposing-read offsets (bytes inside a term tile, kk = 0): lane 4q+p of a 16-lane group addresses pixel row
+    // r0 + q, 16-byte chunk c0 + (p >> 1), half p & 1, with r0 = 16 kk + 8 h + 4 j2 and c0 = the group's 16 columns
+    const int l16 = lane & 15, q = l16 >> 2, pp = l16 & 3, g1 = (lane >> 4) & 1;
+    uint32_t xo[2][2], go[2][2];      // [mi | ni][j2]
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int j2 = 0; j2 < 2; ++j2) {
+        const int row = 8 * h + 4 * j2 + q;
+        const int fx = (q << 2) | ((2 * h + j2) & 3);
+        const int chx = (wr * 8 + m * 4 + g1 * 2 + (pp >> 1)) ^ fx;
+        xo[m][j2] = (uint32_t)(XROW * row + 16 * chx + 8 * (pp & 1));
+        if (TO == 128) {
+          const int chg = (wc * 8 + m * 4 + g1 * 2 + (pp >> 1)) ^ fx;
+          go[m][j2] = (uint32_t)(GROW * row + 16 * chg + 8 * (pp & 1));
+        } else {
+          const int chg = (m * 4 + g1 * 2 + (pp >> 1)) ^ (((q >> 1) & 1) << 2);
+          go[m][j2] = (uint32_t)(GROW * row + 16 * chg + 8 * (pp & 1));
+        }
+      }
+    fill_tables(ck0, 0);
+    fill_tables(ck1, 1);
+    __syncthreads();
+    issue(0, 0, 0);
+    __syncthreads();
+    auto compute = [&](int stage) {
+      const uint16_t* sx = reinterpret_cast<const uint16_t*>(lds + stage * STAGE);
+      const uint16_t* sg = reinterpret_cast<const uint16_t*>(lds + stage * STAGE + NS * XT);
+      bf16x8 fa[NS][2], fb[NS][2];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) fa[s][mi] = tr_frag(sx + (s * XT + xo[mi][0]) / 2, sx + (s * XT + xo[mi][1]) / 2);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) fb[s][ni] = tr_frag(sg + (s * GT + go[ni][0]) / 2, sg + (s * GT + go[ni][1]) / 2);
+      }
+#pragma unroll
+      for (int d = NS - 1; d >= 0; --d)
+#pragma unroll
+        for (int i = 0; i <= d; ++i)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][mi], fb[d - i][ni], acc[mi][ni], 0, 0, 0);
+    };
+    for (int it = 0; ck0 < cend; ++it) {
+      const int slot = it & 1;                    // table slot of the chunk being multiplied
+      const int ck2 = next_chunk(ck1);
+      issue(slot, 1, 1);                          // its second half lands while the first is multiplied
+      compute(0);
+      __syncthreads();                            // (drains the DMA; every wave has issued from this chunk's table slot)
+      if (ck1 < cend) issue(slot ^ 1, 0, 0);      // first half of the next chunk
+      fill_tables(ck2, slot);
+      compute(1);
+      __syncthreads();
+      ck0 = ck1;
+      ck1 = ck2;
+    }
+  }
+  const size_t rows_total = (size_t)rows_all;
+  float* dst = a.slab + ((size_t)split * rows_total + R0) * a.Cout + o0;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int col = wc * 64 + ni * 32 + li;
+        if (R0 + row < rows_all) dst[(size_t)row * a.Cout + col] = acc[mi][ni][r];
+      }
+#endif
+}
+
 // grad[tap][c][o] = sum over splits (fixed order) of slab[split][tap][c (of cin_pad)][o], c < cin_real
 __global__ void wgrad_split_reduce_kernel(const float* __restrict__ slab, float* __restrict__ grad, int nsplit, int taps,
                                           int cin_pad, int cin_real, int cout) {
@@ -1261,9 +1453,11 @@ int launch_wgrad_split(const SplitWgradArgs& a, int nsplit, hipStream_t st) {
   return DRS_LAUNCH_CHECK();
 }
 
-inline bool wgrad_dma(int nterms, int Pg) { return g_variant != 0 && nterms == 2 && Pg > 0; }
-int split_wgrad_rows(int rows, int Pg, int nterms) {
-  if (wgrad_dma(nterms, Pg)) return 128;       // the LDS-DMA kernel: 128-row tiles only, zeros fetched from the halo
+// the LDS-DMA filter gradient: two terms (wgrad_split_dma_kernel) and three (wgrad_split_half_kernel, 128-wide column tiles only;
+// development arm 6 = register-staged everywhere)
+inline bool wgrad_dma(int nterms, int Pg, int cout = 128) { return g_variant != 0 && g_variant != 6 && Pg > 0 && (nterms == 2 || cout >= 128); }
+int split_wgrad_rows(int rows, int Pg, int nterms, int cout) {
+  if (wgrad_dma(nterms, Pg, cout)) return 128;       // the LDS-DMA kernel: 128-row tiles only, zeros fetched from the halo
   const int n128 = (rows + 127) / 128;
   return (double)rows / (n128 * 128.0) >= 0.85 ? 128 : 64;
 }
@@ -1326,9 +1520,9 @@ int drs_conv_forward_split(const unsigned short* in, int B, int S, int P, int ld
 
 int drs_conv_wgrad_split_splits(int B, int S, int k, int cin, int cout, int Pg, int nterms) {
   const long long M = (long long)B * S * S;
-  const int tr = split_wgrad_rows(k * k * cin, Pg, nterms), to = cout % 128 == 0 ? 128 : 64;
+  const int tr = split_wgrad_rows(k * k * cin, Pg, nterms, cout), to = cout % 128 == 0 ? 128 : 64;
   int ntile = ((k * k * cin + tr - 1) / tr) * (cout / to);
-  if ((wgrad_dma(nterms, Pg) || nterms == 3) && to == 64 && cout > 64) ntile = ((k * k * cin + tr - 1) / tr) * ((cout / 128) + 1);   // 128-wide tiles + one 64-wide
+  if ((wgrad_dma(nterms, Pg, cout) || nterms == 3) && to == 64 && cout > 64) ntile = ((k * k * cin + tr - 1) / tr) * ((cout / 128) + 1);   // 128-wide tiles + one 64-wide
   const int nchunks = (int)((M + 31) / 32);
   int want = ((ntile >= 24 && nchunks >= 8192) ? 3072 : 1536) / ntile;      // see drs_conv_wgrad_splits (conv_mfma.hip)
   int maxs = (nchunks + 31) / 32;
@@ -1352,7 +1546,7 @@ int drs_conv_wgrad_split(const unsigned short* x, int B, int S, int Px, int ld_x
   a.x = x; a.S = S; a.Px = Px; a.ld_x = ld_x; a.coff_x = coff_x;
   a.g = g; a.Pg = Pg; a.ld_g = ld_g; a.coff_g = coff_g; a.M = (int)M;
   a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout; a.slab = slab;
-  const int tr = split_wgrad_rows(k * k * cin, Pg, nsplit_terms), to = cout % 128 == 0 ? 128 : 64;
+  const int tr = split_wgrad_rows(k * k * cin, Pg, nsplit_terms, cout), to = cout % 128 == 0 ? 128 : 64;
   a.ntr = (k * k * cin + tr - 1) / tr; a.nto = cout / to;
   const int nsplit = drs_conv_wgrad_split_splits(B, S, k, cin, cout, Pg, nsplit_terms);
   const int nchunks = (int)((M + 31) / 32);
@@ -1362,20 +1556,22 @@ int drs_conv_wgrad_split(const unsigned short* x, int B, int S, int Px, int ld_x
   a.skip_halo = drs_skip_halo_taps_wgrad(M);
   hipStream_t st = (hipStream_t)stream;
   int rc = DRS_OK;
-  if (wgrad_dma(nsplit_terms, Pg)) {
-    // 128-wide column tiles wherever they fit, one 64-wide tile for what is left (Cout = 64, 192)
+  if (wgrad_dma(nsplit_terms, Pg, cout)) {
+    // 128-wide column tiles wherever they fit, one 64-wide tile for what is left (Cout = 64, 192); three terms: the 64-wide rest
+    // goes to the register-staged kernel (the half-stage form loses 8 % there)
     const int n128 = cout / 128, rest = cout % 128;
     if (n128) {
       a.nto = n128; a.o_base = 0;
       const dim3 grid(nsplit * a.ntr * a.nto);
-      DRS_LAUNCH((wgrad_split_dma_kernel<128, 2>), grid, dim3(256), 0, st, a);
+      if (nsplit_terms == 3) DRS_LAUNCH((wgrad_split_half_kernel<128, 3>), grid, dim3(256), 0, st, a);
+      else DRS_LAUNCH((wgrad_split_dma_kernel<128, 2>), grid, dim3(256), 0, st, a);
       rc = DRS_LAUNCH_CHECK();
     }
     if (rest && rc == DRS_OK) {
       a.nto = 1; a.o_base = n128 * 128;
       const dim3 grid(nsplit * a.ntr);
-      DRS_LAUNCH((wgrad_split_dma_kernel<64, 2>), grid, dim3(128), 0, st, a);
-      rc = DRS_LAUNCH_CHECK();
+      if (nsplit_terms == 3) rc = launch_wgrad_split<128, 64, 3>(a, nsplit, st);
+      else { DRS_LAUNCH((wgrad_split_dma_kernel<64, 2>), grid, dim3(128), 0, st, a); rc = DRS_LAUNCH_CHECK(); }
     }
   } else if (nsplit_terms == 2) {
     if (tr == 128 && to == 128) rc = launch_wgrad_split<128, 128, 2>(a, nsplit, st);
