@@ -95,8 +95,9 @@ def test_heldout_pixel_accuracy_matches_cpu_oracle_over_seeds():
     assert abs(late_d.mean() - late_t.mean()) <= 3.0 * se_loss + 0.03 * late_t.mean()
 
 
-def test_trained_weights_label_the_heldout_tile_alike():
-    """The tight half of the accuracy parity: train on the HIP path until the net has learnt the synthetic classes, then label the
+@pytest.mark.parametrize("arith", ["f32", "bf16x6"])
+def test_trained_weights_label_the_heldout_tile_alike(arith):
+    """The tight half of the accuracy parity (on the default exact-fp32 kernels and on the opt-in three-term bf16 arithmetic): train on the HIP path until the net has learnt the synthetic classes, then label the
     held-out tile by sliding window (isprs:1241-1284) with the HIP path and with the CPU oracle FROM THE SAME trained variables
     (moving statistics included).  No chaos between the two here, so the label maps and the pixel accuracies must agree closely."""
     from drs_amd import loops, patches as P
@@ -107,7 +108,7 @@ def test_trained_weights_label_the_heldout_tile_alike():
     held, held_lab = make_tile(96, 96, CH, K, seed=4, n_seeds=12, class_signal=0.6)
     mean, std = tile[:, :, :3].mean(axis=(0, 1)), tile[:, :, :3].std(axis=(0, 1))
     inst = grid_instances(192, 192, S2, 8, B2 * steps, seed=7)
-    d = DilatedNet(NET, CH, K, WD, b_max=B2, s_max=S2, device=DEV, seed=33)
+    d = DilatedNet(NET, CH, K, WD, b_max=B2, s_max=S2, device=DEV, seed=33, arith=arith)
     pool = P.TilePool([tile], [lab], DEV)
     losses = []
     for i in range(steps):
@@ -137,7 +138,7 @@ def test_trained_weights_label_the_heldout_tile_alike():
     avg_d = (prob_d.view(96, 96, K) / occ_d.view(96, 96, 1).float()).cpu().numpy()
     avg_t = prob_t / occ_t
     err = float(np.abs(avg_d - avg_t).max() / np.abs(avg_t).max())
-    print("held-out tile, same trained variables: pixel accuracy HIP %.4f  CPU oracle %.4f  (chance %.3f); label maps agree on %.4f of the "
+    print(arith, "held-out tile, same trained variables: pixel accuracy HIP %.4f  CPU oracle %.4f  (chance %.3f); label maps agree on %.4f of the "
           "pixels; averaged logits differ by %.2e of their range" % (acc_d, acc_t, 1.0 / K, agree, err))
     assert acc_t > 3.0 / K                                  # the net has learnt the task
     assert err < 1e-3                                       # north star: logits within 1e-3 relative
