@@ -421,190 +421,14 @@ __global__ __launch_bounds__(256) void conv_split_dma_kernel(const SplitConvArgs
 #endif
 }
 
-// ---- the same GEMM as conv_dma_kernel does it for exact fp32 (conv_mfma.hip): operands by LDS-DMA into a double-buffered image
-// of 16-channel HALF K-steps (one v_mfma_f32_32x32x16_bf16 k-step each), so that all NS terms of both operands fit 3 workgroups
-// on a CU (NS = 3, 128 x 128: 2 x 24 KB); every global address is (wave-uniform base in SGPRs) + (loop-invariant 32-bit byte offset
-// of this lane), the (channel chunk, tap row, tap column) counters live in SGPRs -- the K loop issues no vector-ALU instruction
-// besides its MFMAs (VALU instructions of any wave on a SIMD take issue slots from its matrix pipe) -- and the K order is
-// channel-major (the k*k shifted reads of one 32-channel chunk follow each other: L2).  An image row is the bare 32 B of one
-// pixel's 16 channels of one term; a DMA wave-instruction fills 32 rows; the 16-byte piece c of row r sits in slot c ^ ((r >> 3) & 1),
-// realised on the source address, which makes the 16 lanes of every ds_read_b128 group cover the 256-byte bank row once.
-template <int BN, int NS>
-__global__ __launch_bounds__(256, BN <= 128 ? 3 : 2) void conv_split_half_kernel(const SplitConvArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)   // the host pass has no LDS-DMA builtin; it only needs the launch stub
-  constexpr int BM = 128, WM = 2, WN = 2;
-  constexpr int WTM = BM / WM, WTN = BN / WN;
-  constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int HK = 16;                               // channels per half
-  constexpr int ROWB = HK * 2;                         // bytes per image row (32)
-  constexpr int PLANE_A = BM * ROWB, PLANE_B = BN * ROWB;
-  constexpr int STAGE = NS * (PLANE_A + PLANE_B);
-  constexpr int NIA = NS * (BM / 32), NIB = NS * (BN / 32);    // DMA instructions per half (32 rows each), over the 4 waves
-  static_assert(WTN % 32 == 0, "wave tile");
-
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
-
-  const int t = threadIdx.x;
-  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int li = lane & 31, h = lane >> 5;
-  const int wm = wave / WN, wn = wave % WN;
-  const int ntn = a.Cout / BN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (tile / ntn) * BM;
-  const int n0 = (tile % ntn) * BN;
-  const int Sp = a.S + 2 * a.P;
-  const int Ktot = a.k * a.k * a.Cin;
-
-  // DMA lane roles: a wave-instruction fills rows 32 j .. 32 j + 31 of one term plane; lane l fills row 32 j + (l >> 1), slot l & 1,
-  // with source piece (l & 1) ^ ((row >> 3) & 1) = (l & 1) ^ ((l >> 4) & 1).  Wave w takes row block j = w (+ 4, ...) of every term.
-  const int dpiece = ((lane & 1) ^ ((lane >> 4) & 1)) * 16;                 // bytes
-  uint32_t offA[BM / 128], offB[(BN + 127) / 128];
-#pragma unroll
-  for (int i = 0; i < BM / 128; ++i) {
-    int p = m0 + 32 * (wave + 4 * i) + (lane >> 1);
-    p = p < a.M ? p : a.M - 1;
-    offA[i] = (NS * (padded_pixel_off(p, a.S, a.P, a.ld_in, a.rcpS, a.rcpSS, -a.pad, -a.pad) + (uint32_t)a.coff_in)) * 2u + (uint32_t)dpiece;
-  }
-#pragma unroll
-  for (int i = 0; i < (BN + 127) / 128; ++i) {
-    int o = n0 + 32 * (wave + 4 * i) + (lane >> 1);
-    o = o < a.Cout ? o : a.Cout - 1;                    // (BN = 64 / 192: row blocks past the tile are not issued)
-    offB[i] = NS == 3 ? (uint32_t)o * 32u + (uint32_t)dpiece : (uint32_t)(NS * o * Ktot) * 2u + (uint32_t)dpiece;
-  }
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-  const int cpt = a.Cin / BK;
-  int u_lo, u_hi;
-  live_tap_rows(m0, BM, a.M, a.S, a.k, a.rate, a.pad, a.rcpS, a.rcpSS, u_lo, u_hi);
-  if (!a.skip_halo) { u_lo = 0; u_hi = a.k; }
-  u_lo = __builtin_amdgcn_readfirstlane(u_lo);
-  u_hi = __builtin_amdgcn_readfirstlane(u_hi);
-  const int nks = (u_hi - u_lo) * a.k * cpt;
-  const char* inb = reinterpret_cast<const char*>(a.in);
-  const char* wbase = reinterpret_cast<const char*>(a.w);
-  int lu = u_lo, lv = 0, lc = 0;                       // (tap row, tap column, channel chunk) of the K-step being fetched
-  typedef __attribute__((address_space(3))) void* lds_ptr;
-
-  auto issue = [&](int half, int stage) {
-    unsigned char* sa = lds + stage * STAGE;
-    unsigned char* sb = sa + NS * PLANE_A;
-    // fp32 element offset of (tap, chunk) in the slab -> term image: * NS, term s at + 32 s elements, half at + 16 elements
-    const uint32_t aoff = (uint32_t)(NS * ((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK) + half * HK) * 2u;
-    const uint32_t boff = NS == 3 ? (uint32_t)(((((lu * a.k + lv) * cpt + lc) * 2 + half) * NS) * a.Cout) * 32u
-                                  : (uint32_t)(NS * (((lu * a.k + lv) * cpt + lc) * BK) + half * HK) * 2u;
-    const uint32_t bterm = NS == 3 ? (uint32_t)a.Cout * 32u : 64u;       // bytes from one term's rows to the next
-    const char* ab = inb + (size_t)aoff;
-    const char* wb = wbase + (size_t)boff;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      // one scalar base per term, kept opaque: otherwise LLVM folds the term offset into a 64-bit VECTOR add per load
-      const char* as = ab + s * 64;
-      const char* ws = wb + s * bterm;
-      asm volatile("" : "+s"(as));
-      asm volatile("" : "+s"(ws));
-#pragma unroll
-      for (int i = 0; i < BM / 128; ++i) {
-        uint32_t o = offA[i]; asm volatile("" : "+v"(o));
-        __builtin_amdgcn_global_load_lds(as + o, (lds_ptr)(sa + s * PLANE_A + (wave + 4 * i) * 1024), 16, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < (BN + 127) / 128; ++i) {
-        if (32 * (wave + 4 * i) < BN) {                // wave-uniform
-          uint32_t o = offB[i]; asm volatile("" : "+v"(o));
-          __builtin_amdgcn_global_load_lds(ws + o, (lds_ptr)(sb + s * PLANE_B + (wave + 4 * i) * 1024), 16, 0, 0);
-        }
-      }
-    }
-  };
-  auto next_kstep = [&]() { if (++lv == a.k) { lv = 0; if (++lu == u_hi) { lu = u_lo; ++lc; } } };
-
-  // fragment offsets (bytes inside a plane): row * 32 + ((h ^ ((row >> 3) & 1)) * 16); row = tile row + li, tile rows multiples of 32
-  const uint32_t fsw = (uint32_t)((h ^ ((li >> 3) & 1)) * 16);
-  const uint32_t fra = (uint32_t)((wm * WTM + li) * ROWB) + fsw;
-  const uint32_t frb = (uint32_t)((wn * WTN + li) * ROWB) + fsw;
-  auto compute = [&](int stage) {
-    const unsigned char* sa = lds + stage * STAGE;
-    const unsigned char* sb = sa + NS * PLANE_A;
-    bf16x8 fa[NS][TM], fb[NS][TN];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-#pragma unroll
-      for (int mi = 0; mi < TM; ++mi) fa[s][mi] = *reinterpret_cast<const bf16x8*>(sa + s * PLANE_A + mi * 32 * ROWB + fra);
-#pragma unroll
-      for (int ni = 0; ni < TN; ++ni) fb[s][ni] = *reinterpret_cast<const bf16x8*>(sb + s * PLANE_B + ni * 32 * ROWB + frb);
-    }
-    // partial products a_i * b_j, i + j < NS, smallest terms first
-#pragma unroll
-    for (int d = NS - 1; d >= 0; --d)
-#pragma unroll
-      for (int i = 0; i <= d; ++i)
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < TN; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][mi], fb[d - i][ni], acc[mi][ni], 0, 0, 0);
-  };
-
-  issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int ks = 0; ks < nks; ++ks) {
-    issue(1, 1);                                  // second half of this K-step lands while the first is multiplied
-    compute(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    next_kstep();
-    if (ks + 1 < nks) issue(0, 0);                // first half of the next K-step (every wave is done with stage 0)
-    compute(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-
-  // ---- epilogue (as conv_split_kernel): C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  float bv[TN];
-#pragma unroll
-  for (int ni = 0; ni < TN; ++ni) {
-    const int col = n0 + wn * WTN + ni * 32 + li;
-    bv[ni] = a.bias ? a.bias[col] : 0.f;
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row < a.M) {
-          float v = acc[mi][ni][r] + bv[ni];
-          float* dst = a.out + (size_t)row * a.ld_out + a.coff_out + col;
-          if (a.accumulate) v += *dst;
-          *dst = v;
-        }
-      }
-    }
-  }
-  if (a.stats) {
-    const int rem = a.M - m0;
-    tile_column_stats<TN, WM, BN>(
-        reinterpret_cast<float*>(lds), t, wm, h == 0, (float)(rem < BM ? rem : BM), [&](int ni) { return wn * WTN + ni * 32 + li; },
-        [](float s) { return s + __shfl_xor(s, 32); },
-        [&](int ni, auto f) {
-#pragma unroll
-          for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              if (m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < a.M) f(acc[mi][ni][r] + bv[ni]);
-        },
-        a.stats + ((size_t)(m0 / BM) * a.Cout + n0) * 2);
-  }
-#endif
-}
-
-// ---- three terms on the 16x16x32 MFMA shape.  The chip holds a higher clock under v_mfma_f32_16x16x32_bf16 than under the 32x32x16
+// ---- three terms (bf16x6), the half-stage form: operands by LDS-DMA into a double-buffered image of 16-channel HALF K-steps, so that
+// all three terms of both operands fit (48 KB) and two to three workgroups share a CU; every global address is (wave-uniform base in
+// SGPRs) + (loop-invariant 32-bit byte offset of this lane), the (channel chunk, tap row, tap column) counters live in SGPRs -- the K loop
+// issues no vector-ALU instruction besides its MFMAs -- and the K order is channel-major, as in conv_dma_kernel (conv_mfma.hip).  An image
+// row is the bare 32 B of one pixel's 16 channels of one term; a DMA wave-instruction fills 32 rows; the filter image is blocked by half
+// K-steps (filter_term_off), so a B tile is one contiguous run.  (A 32x32x16 form of this kernel, a 128x256 tile, rings of 3 / 4 stages
+// and a whole-K-step A image were measured and dropped: profiles/r02/split_forms.txt.)
+// On the 16x16x32 MFMA shape:  The chip holds a higher clock under v_mfma_f32_16x16x32_bf16 than under the 32x32x16
 // form (bare loops on random operands, 4 workgroups per CU: 1.75 against 1.33 PFLOP/s, tools/ubench/mfma_shape.hip), but its K of 32
 // is a whole K-step, two LDS stages of the half-stage image.  So one MFMA multiplies TWO of the six partial products of a 16-channel
 // half instead: its 32-deep K is [16 channels of one term | 16 channels of another], A-side and B-side chosen so that the pairs
@@ -622,7 +446,6 @@ __global__ __launch_bounds__(256, 2) void conv_split_half16_kernel(const SplitCo
   constexpr int ROWB = HK * 2;                         // bytes per image row (32)
   constexpr int PLANE_A = BM * ROWB, PLANE_B = BN * ROWB;
   constexpr int STAGE = NS * (PLANE_A + PLANE_B);
-  constexpr int NIA = NS * (BM / 32), NIB = NS * (BN / 32);    // DMA instructions per half (32 rows each), over the 4 waves
   static_assert(WTN % 16 == 0, "wave tile");
 
   __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
@@ -805,32 +628,21 @@ template <int BM, int BN, int WM, int WN, int NS>
 int launch_split(const SplitConvArgs& a, hipStream_t st) {
   const int mt = (a.M + BM - 1) / BM, nt = a.Cout / BN;
   // three terms: the double-buffered LDS-DMA image (96 KiB) leaves one workgroup per CU; the register-staged kernel keeps two
-  if (g_variant == 2) DRS_LAUNCH((conv_split_half_kernel<BN, NS>), dim3(mt * nt), dim3(256), 0, st, a);
-  else if (g_variant == 0 || NS == 3) DRS_LAUNCH((conv_split_kernel<BM, BN, WM, WN, NS>), dim3(mt * nt), dim3(256), 0, st, a);
+  if (g_variant == 0 || NS == 3) DRS_LAUNCH((conv_split_kernel<BM, BN, WM, WN, NS>), dim3(mt * nt), dim3(256), 0, st, a);
   else DRS_LAUNCH((conv_split_dma_kernel<BM, BN, WM, WN, NS>), dim3(mt * nt), dim3(256), 0, st, a);
   return DRS_LAUNCH_CHECK();
 }
 
-int g_wide = 1;         // development switch (drs_debug_split_wide): 256-wide N tiles in the half-stage form
-
 template <int NS>
 int dispatch_split(const SplitConvArgs& a, hipStream_t st) {
   // three terms (bf16x6): the 16x16x32 half-stage form on every tile width (with the blocked filter image it is the fastest form on
-  // every Dilated8Pooling shape, profiles/r02/split_forms.txt); development arms: 0 = register-staged, 2 = 32x32x16 half-stage
+  // every Dilated8Pooling shape, profiles/r02/split_forms.txt); development arm: 0 = register-staged
   if constexpr (NS == 3) {
     const int mt = (a.M + 127) / 128;
-    if (g_variant == 1 || g_variant == 3) {
+    if (g_variant != 0) {
       if (a.Cout % 128 == 0) DRS_LAUNCH((conv_split_half16_kernel<128>), dim3(mt * (a.Cout / 128)), dim3(256), 0, st, a);
       else if (a.Cout % 192 == 0) DRS_LAUNCH((conv_split_half16_kernel<192>), dim3(mt * (a.Cout / 192)), dim3(256), 0, st, a);
       else DRS_LAUNCH((conv_split_half16_kernel<64>), dim3(mt * (a.Cout / 64)), dim3(256), 0, st, a);
-      return DRS_LAUNCH_CHECK();
-    }
-    if (g_variant == 2 && g_wide && a.Cout % 256 == 0) {
-      DRS_LAUNCH((conv_split_half_kernel<256, NS>), dim3(mt * (a.Cout / 256)), dim3(256), 0, st, a);
-      return DRS_LAUNCH_CHECK();
-    }
-    if (g_variant == 2 && a.Cout % 192 == 0 && a.Cout % 128 != 0) {
-      DRS_LAUNCH((conv_split_half_kernel<192, NS>), dim3(mt * (a.Cout / 192)), dim3(256), 0, st, a);
       return DRS_LAUNCH_CHECK();
     }
   }
@@ -1471,7 +1283,6 @@ extern "C" {
 /* development switch between kernel variants (not part of the documented ABI) */
 int drs_debug_variant(int v) { const int old = g_variant; if (v >= 0) g_variant = v; return old; }
 
-int drs_debug_split_wide(int v) { const int old = g_wide; if (v >= 0) g_wide = v; return old; }
 
 int drs_split_conv_mtile(int cout) { (void)cout; return 128; }
 
