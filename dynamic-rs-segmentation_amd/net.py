@@ -108,7 +108,9 @@ class DilatedNet(object):
         if arith not in ARITH_TERMS:
             raise ValueError("arith must be one of %s" % sorted(ARITH_TERMS))
         self.arith, self.ns = arith, ARITH_TERMS[arith]
-        self.plan = Plan(net_type, channels, num_classes, first_cin_pad=32 if self.ns else 8)
+        # (the few-band first block stays on the exact-fp32 kernels in every arithmetic: its packed K-steps multiply 8 padded bands where the
+        # split kernels would multiply 32 -- 0.13 against 0.34 ms forward, 0.19 against 0.50 ms filter gradient at B = 128)
+        self.plan = Plan(net_type, channels, num_classes, first_cin_pad=8)
         self.wd = float(weight_decay)
         self.b_max, self.s_max = int(b_max), int(s_max)
         self.dev = torch.device(device)
@@ -286,7 +288,8 @@ class DilatedNet(object):
     # ------------------------------------------------------------------ split-bf16 arithmetic
     def _split_fwd(self, i):
         """conv block i runs its forward and filter-gradient passes on the split-bf16 kernels (tile shapes need Cout % 64)."""
-        return self.ns > 0 and self.plan.layers[i].cout % 64 == 0
+        L = self.plan.layers[i]
+        return self.ns > 0 and L.cout % 64 == 0 and L.cin_k % 32 == 0
 
     def _mtile(self, i):
         """pixels per row of the batch-norm statistics slab the forward convolution of block i writes"""
