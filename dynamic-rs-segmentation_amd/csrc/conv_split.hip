@@ -436,10 +436,12 @@ __global__ __launch_bounds__(256) void conv_split_dma_kernel(const SplitConvArgs
 // come out -- three MFMAs per 16x16 tile and half, the same flops as six 32x32x16 ones per 32x32 tile.  A lane's k-chunk q = lane / 16
 // (8 of the 32 k) therefore reads piece q & 1 of the 32-byte image row of term T[q >> 1]; with 32-byte rows the 16 lanes of every
 // ds_read_b128 group already cover the 256-byte bank row once, so this image is NOT swizzled.
-template <int BN>
-__global__ __launch_bounds__(256, 2) void conv_split_half16_kernel(const SplitConvArgs a) {
+template <int BM, int BN>
+__global__ __launch_bounds__(BM * 2, 2) void conv_split_half16_kernel(const SplitConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass has no LDS-DMA builtin; it only needs the launch stub
-  constexpr int BM = 128, WM = 2, WN = 2, NS = 3;
+  // BM = 256 (8 waves, 4 x 2): the filter tile is fetched once per 256 pixels -- half the L2 requests for B per product
+  constexpr int WM = BM / 64, WN = 2, NS = 3, NW = WM * WN;
+  static_assert(BM == 128 || BM == 256, "one A row block of 32 pixels per wave and term");
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 16, TN = WTN / 16;
   constexpr int HK = 16;                               // channels per half
@@ -462,18 +464,18 @@ __global__ __launch_bounds__(256, 2) void conv_split_half16_kernel(const SplitCo
   const int Ktot = a.k * a.k * a.Cin;
 
   // DMA lane roles: a wave-instruction fills rows 32 j .. 32 j + 31 of one term plane; lane l fills row 32 j + (l >> 1), piece l & 1.
-  // Wave w takes row block j = w (+ 4, ...) of every term.
+  // Wave w takes A row block w and B row blocks w, w + NW, ... of every term.
   const int dpiece = (lane & 1) * 16;                 // bytes
-  uint32_t offA[BM / 128], offB[(BN + 127) / 128];
-#pragma unroll
-  for (int i = 0; i < BM / 128; ++i) {
-    int p = m0 + 32 * (wave + 4 * i) + (lane >> 1);
+  constexpr int IBW = (BN / 32 + NW - 1) / NW;          // B row blocks per wave and term (some waves have fewer)
+  uint32_t offA[1], offB[IBW];
+  {
+    int p = m0 + 32 * wave + (lane >> 1);
     p = p < a.M ? p : a.M - 1;
-    offA[i] = (NS * (padded_pixel_off(p, a.S, a.P, a.ld_in, a.rcpS, a.rcpSS, -a.pad, -a.pad) + (uint32_t)a.coff_in)) * 2u + (uint32_t)dpiece;
+    offA[0] = (NS * (padded_pixel_off(p, a.S, a.P, a.ld_in, a.rcpS, a.rcpSS, -a.pad, -a.pad) + (uint32_t)a.coff_in)) * 2u + (uint32_t)dpiece;
   }
 #pragma unroll
-  for (int i = 0; i < (BN + 127) / 128; ++i) {
-    int o = n0 + 32 * (wave + 4 * i) + (lane >> 1);
+  for (int i = 0; i < IBW; ++i) {
+    int o = n0 + 32 * (wave + NW * i) + (lane >> 1);
     o = o < a.Cout ? o : a.Cout - 1;                    // (BN = 64 / 192: row blocks past the tile are not issued)
     offB[i] = NS == 3 ? (uint32_t)o * 32u + (uint32_t)dpiece : (uint32_t)(NS * o * Ktot) * 2u + (uint32_t)dpiece;
   }
@@ -515,16 +517,15 @@ __global__ __launch_bounds__(256, 2) void conv_split_half16_kernel(const SplitCo
       const char* ws = wb + s * bterm;
       asm volatile("" : "+s"(as));
       asm volatile("" : "+s"(ws));
-#pragma unroll
-      for (int i = 0; i < BM / 128; ++i) {
-        uint32_t o = offA[i]; asm volatile("" : "+v"(o));
-        __builtin_amdgcn_global_load_lds(as + o, (lds_ptr)(sa + s * PLANE_A + (wave + 4 * i) * 1024), 16, 0, 0);
+      {
+        uint32_t o = offA[0]; asm volatile("" : "+v"(o));
+        __builtin_amdgcn_global_load_lds(as + o, (lds_ptr)(sa + s * PLANE_A + wave * 1024), 16, 0, 0);
       }
 #pragma unroll
-      for (int i = 0; i < (BN + 127) / 128; ++i) {
-        if (32 * (wave + 4 * i) < BN) {                // wave-uniform
+      for (int i = 0; i < IBW; ++i) {
+        if (32 * (wave + NW * i) < BN) {               // wave-uniform
           uint32_t o = offB[i]; asm volatile("" : "+v"(o));
-          __builtin_amdgcn_global_load_lds(ws + o, (lds_ptr)(sb + s * PLANE_B + (wave + 4 * i) * 1024), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds(ws + o, (lds_ptr)(sb + s * PLANE_B + (wave + NW * i) * 1024), 16, 0, 0);
         }
       }
     }
@@ -604,10 +605,14 @@ __global__ __launch_bounds__(256, 2) void conv_split_half16_kernel(const SplitCo
       }
     }
   }
-  if (a.stats) {      // the 16x16 C/D map puts a column in 4 lanes
-    const int rem = a.M - m0;
-    tile_column_stats<TN, WM, BN>(
-        reinterpret_cast<float*>(lds), t, wm, q == 0, (float)(rem < BM ? rem : BM), [&](int ni) { return wn * WTN + ni * 16 + li; },
+  if (a.stats) {      // per 128-pixel statistics row (a 256-pixel tile holds two: waves wm 0-1 and 2-3); the 16x16 C/D map puts a column in 4 lanes
+    const int hrow = wm >> 1;                                  // which 128-pixel half of the tile this wave belongs to
+    const int mh = m0 + 128 * hrow;
+    const int rem = a.M - mh;
+    const float nrow = rem <= 0 ? 1.f : (float)(rem < 128 ? rem : 128);
+    float* dst = a.stats + ((size_t)(mh / 128) * a.Cout + n0) * 2;
+    tile_column_stats<TN, 2, BN>(
+        reinterpret_cast<float*>(lds) + hrow * 4 * BN, t - 256 * hrow, wm & 1, q == 0, nrow, [&](int ni) { return wn * WTN + ni * 16 + li; },
         [](float s) { s += __shfl_xor(s, 16); return s + __shfl_xor(s, 32); },
         [&](int ni, auto f) {
 #pragma unroll
@@ -616,7 +621,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_half16_kernel(const SplitCo
             for (int r = 0; r < 4; ++r)
               if (m0 + wm * WTM + mi * 16 + 4 * q + r < a.M) f(acc[mi][ni][r] + bv[ni]);
         },
-        a.stats + ((size_t)(m0 / BM) * a.Cout + n0) * 2);
+        rem > 0 ? dst : nullptr);
   }
 #endif
 }
@@ -636,13 +641,15 @@ int launch_split(const SplitConvArgs& a, hipStream_t st) {
 template <int NS>
 int dispatch_split(const SplitConvArgs& a, hipStream_t st) {
   // three terms (bf16x6): the 16x16x32 half-stage form on every tile width (with the blocked filter image it is the fastest form on
-  // every Dilated8Pooling shape, profiles/r02/split_forms.txt); development arm: 0 = register-staged
+  // every Dilated8Pooling shape, profiles/r02/split_forms.txt), 256-pixel tiles of 8 waves where Cout is a multiple of 128 (the filter tile
+  // fetched once per 256 pixels: +5-7 % on conv7 / conv8); development arms: 0 = register-staged, 8 = 128-pixel tiles only
   if constexpr (NS == 3) {
     const int mt = (a.M + 127) / 128;
     if (g_variant != 0) {
-      if (a.Cout % 128 == 0) DRS_LAUNCH((conv_split_half16_kernel<128>), dim3(mt * (a.Cout / 128)), dim3(256), 0, st, a);
-      else if (a.Cout % 192 == 0) DRS_LAUNCH((conv_split_half16_kernel<192>), dim3(mt * (a.Cout / 192)), dim3(256), 0, st, a);
-      else DRS_LAUNCH((conv_split_half16_kernel<64>), dim3(mt * (a.Cout / 64)), dim3(256), 0, st, a);
+      if (a.Cout % 128 == 0 && g_variant != 8) DRS_LAUNCH((conv_split_half16_kernel<256, 128>), dim3(((a.M + 255) / 256) * (a.Cout / 128)), dim3(512), 0, st, a);
+      else if (a.Cout % 128 == 0) DRS_LAUNCH((conv_split_half16_kernel<128, 128>), dim3(mt * (a.Cout / 128)), dim3(256), 0, st, a);
+      else if (a.Cout % 192 == 0) DRS_LAUNCH((conv_split_half16_kernel<128, 192>), dim3(mt * (a.Cout / 192)), dim3(256), 0, st, a);
+      else DRS_LAUNCH((conv_split_half16_kernel<128, 64>), dim3(mt * (a.Cout / 64)), dim3(256), 0, st, a);
       return DRS_LAUNCH_CHECK();
     }
   }

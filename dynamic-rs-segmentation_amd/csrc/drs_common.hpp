@@ -138,7 +138,7 @@ __device__ __forceinline__ void tile_column_stats(float* red, int t, int wm, boo
     if (writer) red2[wm * BN + col(ni)] = q;
   }
   __syncthreads();
-  if (t < BN) {
+  if (t >= 0 && t < BN && dst) {
     float u1 = 0.f, u2 = 0.f;
 #pragma unroll
     for (int w = 0; w < WM; ++w) { u1 += red[w * BN + t]; u2 += red2[w * BN + t]; }
