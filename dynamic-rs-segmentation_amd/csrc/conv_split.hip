@@ -437,11 +437,12 @@ __global__ __launch_bounds__(256) void conv_split_dma_kernel(const SplitConvArgs
 // (8 of the 32 k) therefore reads piece q & 1 of the 32-byte image row of term T[q >> 1]; with 32-byte rows the 16 lanes of every
 // ds_read_b128 group already cover the 256-byte bank row once, so this image is NOT swizzled.
 template <int BM, int BN>
-__global__ __launch_bounds__(BM * 2, 2) void conv_split_half16_kernel(const SplitConvArgs a) {
+__global__ __launch_bounds__((BM / 64) * (BN == 256 ? 4 : 2) * 64, 2) void conv_split_half16_kernel(const SplitConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass has no LDS-DMA builtin; it only needs the launch stub
   // BM = 256 (8 waves, 4 x 2): the filter tile is fetched once per 256 pixels -- half the L2 requests for B per product
-  constexpr int WM = BM / 64, WN = 2, NS = 3, NW = WM * WN;
-  static_assert(BM == 128 || BM == 256, "one A row block of 32 pixels per wave and term");
+  // BN = 256 (8 waves, 2 x 4): the activation tile is fetched once for all 256 output channels -- half the L2 requests for A
+  constexpr int WM = BM / 64, WN = BN == 256 ? 4 : 2, NS = 3, NW = WM * WN;
+  static_assert((BM == 128 || BM == 256) && NW <= 8, "tile / wave layout");
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 16, TN = WTN / 16;
   constexpr int HK = 16;                               // channels per half
@@ -467,11 +468,13 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_split_half16_kernel(const Spli
   // Wave w takes A row block w and B row blocks w, w + NW, ... of every term.
   const int dpiece = (lane & 1) * 16;                 // bytes
   constexpr int IBW = (BN / 32 + NW - 1) / NW;          // B row blocks per wave and term (some waves have fewer)
-  uint32_t offA[1], offB[IBW];
-  {
-    int p = m0 + 32 * wave + (lane >> 1);
+  constexpr int IAW = (BM / 32 + NW - 1) / NW;          // A row blocks per wave and term
+  uint32_t offA[IAW], offB[IBW];
+#pragma unroll
+  for (int i = 0; i < IAW; ++i) {
+    int p = m0 + 32 * (wave + NW * i) + (lane >> 1);
     p = p < a.M ? p : a.M - 1;
-    offA[0] = (NS * (padded_pixel_off(p, a.S, a.P, a.ld_in, a.rcpS, a.rcpSS, -a.pad, -a.pad) + (uint32_t)a.coff_in)) * 2u + (uint32_t)dpiece;
+    offA[i] = (NS * (padded_pixel_off(p, a.S, a.P, a.ld_in, a.rcpS, a.rcpSS, -a.pad, -a.pad) + (uint32_t)a.coff_in)) * 2u + (uint32_t)dpiece;
   }
 #pragma unroll
   for (int i = 0; i < IBW; ++i) {
@@ -517,9 +520,12 @@ __global__ __launch_bounds__(BM * 2, 2) void conv_split_half16_kernel(const Spli
       const char* ws = wb + s * bterm;
       asm volatile("" : "+s"(as));
       asm volatile("" : "+s"(ws));
-      {
-        uint32_t o = offA[0]; asm volatile("" : "+v"(o));
-        __builtin_amdgcn_global_load_lds(as + o, (lds_ptr)(sa + s * PLANE_A + wave * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < IAW; ++i) {
+        if (32 * (wave + NW * i) < BM) {               // wave-uniform
+          uint32_t o = offA[i]; asm volatile("" : "+v"(o));
+          __builtin_amdgcn_global_load_lds(as + o, (lds_ptr)(sa + s * PLANE_A + (wave + NW * i) * 1024), 16, 0, 0);
+        }
       }
 #pragma unroll
       for (int i = 0; i < IBW; ++i) {
@@ -641,12 +647,13 @@ int launch_split(const SplitConvArgs& a, hipStream_t st) {
 template <int NS>
 int dispatch_split(const SplitConvArgs& a, hipStream_t st) {
   // three terms (bf16x6): the 16x16x32 half-stage form on every tile width (with the blocked filter image it is the fastest form on
-  // every Dilated8Pooling shape, profiles/r02/split_forms.txt), 256-pixel tiles of 8 waves where Cout is a multiple of 128 (the filter tile
-  // fetched once per 256 pixels: +5-7 % on conv7 / conv8); development arms: 0 = register-staged, 8 = 128-pixel tiles only
+  // every Dilated8Pooling shape, profiles/r02/split_forms.txt), 8-wave tiles where Cout allows: 128 x 256 (the activation tile fetched once
+  // for all 256 output channels: conv7 +10 %, conv8 +3 % over 256 x 128) or 256 x 128 (the filter tile fetched once per 256 pixels); development arms: 0 = register-staged, 8 = 128-pixel tiles only
   if constexpr (NS == 3) {
     const int mt = (a.M + 127) / 128;
     if (g_variant != 0) {
-      if (a.Cout % 128 == 0 && g_variant != 8) DRS_LAUNCH((conv_split_half16_kernel<256, 128>), dim3(((a.M + 255) / 256) * (a.Cout / 128)), dim3(512), 0, st, a);
+      if (a.Cout % 256 == 0 && g_variant != 8) DRS_LAUNCH((conv_split_half16_kernel<128, 256>), dim3(mt * (a.Cout / 256)), dim3(512), 0, st, a);
+      else if (a.Cout % 128 == 0 && g_variant != 8) DRS_LAUNCH((conv_split_half16_kernel<256, 128>), dim3(((a.M + 255) / 256) * (a.Cout / 128)), dim3(512), 0, st, a);
       else if (a.Cout % 128 == 0) DRS_LAUNCH((conv_split_half16_kernel<128, 128>), dim3(mt * (a.Cout / 128)), dim3(256), 0, st, a);
       else if (a.Cout % 192 == 0) DRS_LAUNCH((conv_split_half16_kernel<128, 192>), dim3(mt * (a.Cout / 192)), dim3(256), 0, st, a);
       else DRS_LAUNCH((conv_split_half16_kernel<128, 64>), dim3(mt * (a.Cout / 64)), dim3(256), 0, st, a);
