@@ -5,6 +5,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdrs_hip.so")
+DEV_LIB_PATH = os.path.join(_HERE, "libdrs_hip_dev.so")     # the same sources with -DDRS_DEV: + the switches of include/drs_dev.h
 
 _p, _i, _f, _d = C.c_void_p, C.c_int, C.c_float, C.c_double
 _sz, _u64 = C.c_size_t, C.c_ulonglong
@@ -13,6 +14,8 @@ _sz, _u64 = C.c_size_t, C.c_ulonglong
 SIGNATURES = {
     "drs_conv_mtile": (_i, [_i]),
     "drs_conv_forward": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p]),
+    "drs_conv_workspace_floats": (_sz, [_i]),
+    "drs_conv_forward_ws": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p, _sz, _p]),
     "drs_conv_wgrad_splits": (_i, [_i, _i, _i, _i, _i]),
     "drs_conv_wgrad": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "drs_filter_flip_transpose": (_i, [_p, _p, _i, _i, _i, _p]),
@@ -69,6 +72,11 @@ SIGNATURES = {
     "drs_net_global_step": (C.c_longlong, [_p, C.c_longlong]),
     "drs_net_learning_rate": (_f, [_p, _f]),
     "drs_net_set_comm": (_i, [_p, _i, _i, _p, _p, _p]),
+    "drs_rccl_available": (_i, []),
+    "drs_rccl_unique_id": (_i, [_p]),
+    "drs_rccl_comm_create": (_i, [_i, _i, _p, C.POINTER(_p)]),
+    "drs_rccl_comm_destroy": (_i, [_p]),
+    "drs_net_set_rccl": (_i, [_p, _i, _i, _p, _p, _p]),
     "drs_train_step": (_i, [_p, _i, _i, _f, _i, _d, _p]),
     "drs_forward": (_i, [_p, _i, _i, _i, _i, _p]),
     "drs_apply_update": (_i, [_p, _f, _p]),
@@ -82,31 +90,76 @@ WAIT_FN = C.CFUNCTYPE(_i, _p, _i, _p)
 WANT_LOGITS, WITH_LABELS, USE_ACC_MASK, USE_LOSS_MASK, NO_UPDATE = 1, 2, 4, 8, 16
 
 
+# include/drs_dev.h (libdrs_hip_dev.so only)
+DEV_SIGNATURES = {
+    "drs_debug_skip_taps": (_i, [_i]), "drs_debug_conv_variant": (_i, [_i]), "drs_debug_conv_wide192": (_i, [_i]),
+    "drs_debug_conv_splitk": (_i, [_i]),
+    "drs_debug_wgrad_variant": (_i, [_i]), "drs_debug_wgrad_balance": (_i, [_i]), "drs_debug_wgrad_target": (_i, [_i]),
+    "drs_debug_wgrad_target_big": (_i, [_i]), "drs_debug_wgrad_len": (_i, [_i]), "drs_debug_wgrad_minchunks": (_i, [_i]), "drs_debug_variant": (_i, [_i]),
+    "drs_debug_wgrad_cut": (_i, [_i] * 7 + [_p, _i, _p, _p]),
+}
+
+
 class DrsError(RuntimeError):
     pass
 
 
 _lib = None
+_dev = None
+
+
+def _open(path, signatures):
+    if not os.path.isfile(path):
+        raise DrsError("HIP library not built: %s is missing (run dynamic-rs-segmentation_amd/csrc/build.sh "
+                       "or __graft_entry__.build()); there is no CPU fallback" % path)
+    # PyTorch supplies device memory and streams, so the library must share ITS HIP runtime: import torch first
+    # (libdrs_hip.so then binds to the already-loaded libamdhip64.so.7 instead of pulling in a second copy)
+    import torch  # noqa: F401
+    lib = C.CDLL(path)
+    for name, (res, args) in signatures.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
 
 
 def load():
     """dlopen the library once and type every symbol of include/drs.h."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.isfile(LIB_PATH):
-        raise DrsError("HIP library not built: %s is missing (run dynamic-rs-segmentation_amd/csrc/build.sh "
-                       "or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
-    # PyTorch supplies device memory and streams, so the library must share ITS HIP runtime: import torch first
-    # (libdrs_hip.so then binds to the already-loaded libamdhip64.so.7 instead of pulling in a second copy)
-    import torch  # noqa: F401
-    lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
-        fn.restype = res
-        fn.argtypes = args
-    _lib = lib
-    return lib
+    if _lib is None:
+        _lib = _open(LIB_PATH, SIGNATURES)
+    return _lib
+
+
+class _Dev(object):
+    """the development build of the library (include/drs_dev.h): same entry points + the A/B switches.  Used by tools/ and by the
+    tests that hold two kernel forms equal; the package's product path never touches it."""
+
+    def __init__(self, lib):
+        self.lib = lib
+
+    def __getattr__(self, name):
+        return getattr(self.lib, name)
+
+    def load(self):
+        return self.lib
+
+    def call(self, name, *args):
+        rc = getattr(self.lib, name)(*args)
+        if rc != 0:
+            raise DrsError("%s -> %s" % (name, _STATUS.get(rc, rc)))
+
+    def query(self, name, *args):
+        return getattr(self.lib, name)(*args)
+
+
+def dev():
+    global _dev
+    if _dev is None:
+        sig = dict(SIGNATURES)
+        sig.update(DEV_SIGNATURES)
+        _dev = _Dev(_open(DEV_LIB_PATH, sig))
+    return _dev
 
 
 _STATUS = {1: "DRS_ERR_ARG (rejected argument)", 2: "DRS_ERR_HIP (launch failed)"}

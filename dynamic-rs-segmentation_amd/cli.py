@@ -119,16 +119,15 @@ def main(argv=None, device=None, comm=None):
     if train_dist is not None:
         rot = loops.rank0_cached(comm, tag + "_rotation.npy", lambda: SP.create_rotation_distribution(train_dist))
 
-    ms = None
-    if comm.rank == 0:
+    def mean_std():
         if os.path.isfile(tag + "_mean.npy"):
-            ms = (np.load(tag + "_mean.npy"), np.load(tag + "_std.npy"))
-        else:
-            dist_for_stats = train_dist or SP.create_distributions_over_classes(training_labels, reference_crop_size, reference_stride_crop)
-            ms = SP.dynamically_calculate_mean_and_std(training_data, dist_for_stats, crop_size=25)   # isprs:2109-2110
-            np.save(tag + "_mean.npy", ms[0])
-            np.save(tag + "_std.npy", ms[1])
-    mean_full, std_full = comm.broadcast_object(ms)
+            return (np.load(tag + "_mean.npy"), np.load(tag + "_std.npy"))
+        dist_for_stats = train_dist or SP.create_distributions_over_classes(training_labels, reference_crop_size, reference_stride_crop)
+        ms = SP.dynamically_calculate_mean_and_std(training_data, dist_for_stats, crop_size=25)   # isprs:2109-2110
+        np.save(tag + "_mean.npy", ms[0])
+        np.save(tag + "_std.npy", ms[1])
+        return ms
+    mean_full, std_full = loops.rank0_call(comm, mean_std, "the mean / std caches " + tag + "_{mean,std}.npy")
 
     if process == "training":
         return loops.train(training_data, training_labels, train_dist, rot, testing_data, testing_labels, test_dist,

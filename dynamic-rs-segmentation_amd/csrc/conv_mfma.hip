@@ -35,7 +35,17 @@ struct ConvArgs {
   int accumulate;
   int skip_halo;
   float rcpS, rcpSS;
+  // stream-K (sk_W > 0; conv_dma_kernel only): the launch has sk_W workgroups and the K-steps of ALL tiles, in tile-major order
+  // (sk_U = tiles * sk_nks of them), are cut into sk_W equal consecutive ranges; a tile that one range covers whole is finished
+  // by that workgroup, the others leave their partial sums in sk_slab and conv_sk_fixup_kernel adds them in a fixed order
+  float* sk_slab;
+  int sk_W, sk_nks, sk_U;
 };
+
+// first K-step (of the tile-major sequence) of workgroup w, and the workgroup that owns K-step x: the static cut both the
+// convolution kernel and the fix-up kernel work out for themselves
+__host__ __device__ __forceinline__ int sk_first_unit(int w, int U, int W) { return (int)((long long)w * U / W); }
+__host__ __device__ __forceinline__ int sk_owner(int x, int U, int W) { return (int)((((long long)x + 1) * W - 1) / U); }
 
 // Epilogue shared by the forward / input-gradient kernels: bias, optional accumulate, store, and the tile's batch-norm statistics.
 // C/D map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  `scratch`: LDS no wave reads any more.
@@ -232,7 +242,8 @@ __global__ __launch_bounds__(256, (BM == 256 || BN == 128) ? 3 : 1) void conv_ig
 // ds_read_b128 fragment reads stay conflict-free through a swizzle realised on the SOURCE address: the 16-byte piece c of pixel
 // row r sits in slot c ^ ((r >> 2) & 3) (the 16 lanes of every ds_read_b128 group then cover the 16 slots of the 256-byte bank
 // row once).  K order, accumulation order and epilogue are those of conv_igemm_kernel: results are bitwise the same.
-template <int BM, int BN, int WM, int WN>
+// SK: the stream-K form (a.sk_W workgroups, each a range of the tile-major K-step sequence); !SK: one workgroup per tile.
+template <int BM, int BN, int WM, int WN, bool SK>
 __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass has no LDS-DMA builtin; it only needs the launch stub
   static_assert(WM * WN == 4 && BM == 128, "4 waves, 128-pixel tiles");
@@ -252,29 +263,190 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
   const int li = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
   const int ntn = a.Cout / BN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (tile / ntn) * BM;
-  const int n0 = (tile % ntn) * BN;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int Sp = a.S + 2 * a.P;
+  const int cpt = a.Cin / BK;
+  const char* inb = reinterpret_cast<const char*>(a.in);
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  // fragment addresses (floats): A row r = arow + 32 mi, piece c = 2 q + h in slot c ^ ((r >> 2) & 3); B row k, column
+  const int arow = wm * WTM + li, bcolw = wn * WTN + li;
+  const int sw = (li >> 2) & 3;                 // (arow + 32 mi) >> 2 & 3 == (li >> 2) & 3: WTM and 32 are multiples of 16
 
-  // DMA lane roles.  A: instruction j covers pixel rows 16 j + (lane >> 2); this lane fills slot (lane & 3) of its row with
-  // the source piece (lane & 3) ^ ((row >> 2) & 3) = (lane & 3) ^ ((lane >> 4) & 3)
-  uint32_t offA[IA], offB[IB];
-#pragma unroll
-  for (int i = 0; i < IA; ++i) {
-    int p = m0 + (wave + 4 * i) * 16 + (lane >> 2);
-    p = p < a.M ? p : a.M - 1;
-    offA[i] = (padded_pixel_off(p, a.S, a.P, a.ld_in, a.rcpS, a.rcpSS, -a.pad, -a.pad) + (uint32_t)a.coff_in) * 4u +
-              (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) * 16);
+  // the K-steps this workgroup multiplies: one whole tile (tile = wg), or -- stream-K -- the range [u, u_end) of the tile-major
+  // sequence, i.e. the tail of one tile, whole tiles, the head of another
+  int u = 0, u_end = 1;
+  if (SK) {
+    u = __builtin_amdgcn_readfirstlane(sk_first_unit(wg, a.sk_U, a.sk_W));
+    u_end = __builtin_amdgcn_readfirstlane(sk_first_unit(wg + 1, a.sk_U, a.sk_W));
+    if (u >= u_end) return;
   }
-  // B: instruction j moves pieces 64 j + lane of the linear half image: piece f is the 16-byte column f % BQ of k-row f / BQ
-  // (BN = 192: a k-row is 768 B, so an instruction spans rows; every lane has its own (row, column) per instruction)
-#pragma unroll
-  for (int i = 0; i < IB; ++i) {
-    const int f = 64 * (wave + 4 * i) + lane;
-    offB[i] = (uint32_t)(((f / BQ) * a.Cout + n0 + (f % BQ) * 4)) * 4u;
-  }
+  bool first_seg = true;
+  for (;;) {
+    int tile = wg, kb = 0, ke = 0;
+    if (SK) {
+      tile = u / a.sk_nks;
+      kb = u - tile * a.sk_nks;
+      ke = kb + (u_end - u);
+      ke = ke < a.sk_nks ? ke : a.sk_nks;
+    }
+    const int m0 = (tile / ntn) * BM;
+    const int n0 = (tile % ntn) * BN;
 
+    // DMA lane roles.  A: instruction j covers pixel rows 16 j + (lane >> 2); this lane fills slot (lane & 3) of its row with
+    // the source piece (lane & 3) ^ ((row >> 2) & 3) = (lane & 3) ^ ((lane >> 4) & 3)
+    uint32_t offA[IA], offB[IB];
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      int p = m0 + (wave + 4 * i) * 16 + (lane >> 2);
+      p = p < a.M ? p : a.M - 1;
+      offA[i] = (padded_pixel_off(p, a.S, a.P, a.ld_in, a.rcpS, a.rcpSS, -a.pad, -a.pad) + (uint32_t)a.coff_in) * 4u +
+                (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) * 16);
+    }
+    // B: instruction j moves pieces 64 j + lane of the linear half image: piece f is the 16-byte column f % BQ of k-row f / BQ
+    // (BN = 192: a k-row is 768 B, so an instruction spans rows; every lane has its own (row, column) per instruction)
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      const int f = 64 * (wave + 4 * i) + lane;
+      offB[i] = (uint32_t)(((f / BQ) * a.Cout + n0 + (f % BQ) * 4)) * 4u;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    int u_lo, u_hi;
+    live_tap_rows(m0, BM, a.M, a.S, a.k, a.rate, a.pad, a.rcpS, a.rcpSS, u_lo, u_hi);
+    if (!a.skip_halo || SK) { u_lo = 0; u_hi = a.k; }          // (stream-K: every tile has the same number of K-steps)
+    u_lo = __builtin_amdgcn_readfirstlane(u_lo);
+    u_hi = __builtin_amdgcn_readfirstlane(u_hi);
+    const int nks = (u_hi - u_lo) * a.k * cpt;
+    if (!SK) ke = nks;
+    const char* wlive = reinterpret_cast<const char*>(a.w + (size_t)u_lo * a.k * a.Cin * a.Cout);
+    // (tap row, tap col, channel chunk) of the K-step being fetched; K-step j of a tile is (chunk, tap row, tap col) = (j / (rows k), ...)
+    int lu = u_lo, lv = 0, lc = 0;
+    if (SK && kb) {
+      const int per_chunk = (u_hi - u_lo) * a.k;
+      lc = kb / per_chunk;
+      const int rem = kb - lc * per_chunk;
+      lu = u_lo + rem / a.k;
+      lv = rem - (rem / a.k) * a.k;
+      lc = __builtin_amdgcn_readfirstlane(lc); lu = __builtin_amdgcn_readfirstlane(lu); lv = __builtin_amdgcn_readfirstlane(lv);
+    }
+
+    auto issue = [&](int half, int stage) {
+      float* sa = lds + stage * STAGE;
+      float* sb = sa + ASTAGE;
+      const char* ab = inb + (size_t)(uint32_t)((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK + half * HK) * 4u;
+      const char* wb = wlive + (size_t)(uint32_t)((((lu - u_lo) * a.k + lv) * cpt + lc) * BK + half * HK) * (uint32_t)a.Cout * 4u;
+#pragma unroll
+      for (int i = 0; i < IA; ++i) {
+        uint32_t o = offA[i]; asm volatile("" : "+v"(o));
+        __builtin_amdgcn_global_load_lds(ab + o, (lds_ptr)(sa + (wave + 4 * i) * 256), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < IB; ++i) {
+        uint32_t o = offB[i]; asm volatile("" : "+v"(o));
+        __builtin_amdgcn_global_load_lds(wb + o, (lds_ptr)(sb + (wave + 4 * i) * 256), 16, 0, 0);
+      }
+    };
+    // K order (channel chunk, tap row, tap column): the k*k shifted reads of one 32-channel chunk follow each other, so the lines a
+    // tap shares with the one before it (a column shift keeps 7/8 of a row) and with the neighbouring tiles' taps are still in L2
+    // when they are read again.  Against (tap row, tap column, chunk), in-process A/B with a run-time switch (profiles/r02/
+    // conv_korder_ab.txt): fabric-side fetch per launch 6.1 -> 0.9 GB (conv6), 7.8 -> 2.2 GB (conv8); forward -1 %, dgrad -2.4 %.
+    // (The switch itself is gone: it sent the loop counters to scratch memory and their arithmetic to the vector ALU, -7 %.)
+    auto next_kstep = [&]() { if (++lv == a.k) { lv = 0; if (++lu == u_hi) { lu = u_lo; ++lc; } } };
+
+    auto compute = [&](int stage) {
+      const float* As = lds + stage * STAGE;
+      const float* Bs = As + ASTAGE;
+      constexpr int NST = HK / 2;                 // MFMA k-steps per half
+      f32x4 af[2][TM];
+      float bf[2][TN];
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) af[0][mi] = *reinterpret_cast<const f32x4*>(&As[(arow + mi * 32) * HK + ((h ^ sw) * 4)]);
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni) bf[0][ni] = Bs[(h * 4) * BN + bcolw + ni * 32];
+#pragma unroll
+      for (int st = 0; st < NST; ++st) {
+        const int e = st & 3;
+        if (st + 1 < NST) {
+          const int q1 = (st + 1) >> 2, e1 = (st + 1) & 3;
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni) bf[(st + 1) & 1][ni] = Bs[(q1 * 8 + h * 4 + e1) * BN + bcolw + ni * 32];
+          if (e1 == 0) {
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+              af[q1 & 1][mi] = *reinterpret_cast<const f32x4*>(&As[(arow + mi * 32) * HK + (((2 * q1 + h) ^ sw) * 4)]);
+            __builtin_amdgcn_sched_group_barrier(0x100, TN + TM, 0);
+          } else {
+            __builtin_amdgcn_sched_group_barrier(0x100, TN, 0);
+          }
+        }
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(st >> 2) & 1][mi][e], bf[st & 1][ni], acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x8, TM * TN, 0);
+      }
+    };
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int ks = kb; ks < ke; ++ks) {
+      issue(1, 1);                                  // second half of this K-step lands while the first is multiplied
+      compute(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      next_kstep();
+      if (ks + 1 < ke) issue(0, 0);                 // first half of the next K-step (every wave is done with stage 0)
+      compute(1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    if (!SK || (kb == 0 && ke == nks)) {
+      conv_epilogue<BM, BN, WM, WN>(a, acc, lds, m0, n0);
+    } else {
+      // partial sums of a tile this workgroup shares with others: a piece of the slab in accumulator order (256-byte stores);
+      // a workgroup has at most two such segments, its first (piece 2 w) and its last (piece 2 w + 1)
+      float* piece = a.sk_slab + (size_t)(2 * wg + (first_seg ? 0 : 1)) * (BM * BN) + (size_t)wave * (TM * TN * 16 * 64) + lane;
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) piece[((mi * TN + ni) * 16 + r) * 64] = acc[mi][ni][r];
+    }
+    if (!SK) break;
+    u += ke - kb;
+    if (u >= u_end) break;
+    first_seg = false;
+    __syncthreads();                                // the epilogue's LDS scratch is free before the next segment's DMA lands
+  }
+#endif
+}
+
+// Stream-K fix-up: one workgroup per output tile.  A tile whose K-steps lie in ONE workgroup's range was finished there; the
+// others are the sum of the pieces their workgroups left in the slab, added in workgroup (= K) order, then the same epilogue
+// (bias, accumulate, store, batch-norm statistics of the tile) as the convolution kernel's.  Thread -> element mapping is the
+// convolution kernel's accumulator layout, so pieces are read as they were written.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_sk_fixup_kernel(const ConvArgs a) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  __shared__ float lds[2 * WM * BN];
+  const int tile = blockIdx.x;
+  const int x0 = tile * a.sk_nks;
+  const int w_first = sk_owner(x0, a.sk_U, a.sk_W), w_last = sk_owner(x0 + a.sk_nks - 1, a.sk_U, a.sk_W);
+  if (w_first == w_last) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ntn = a.Cout / BN;
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi)
@@ -282,96 +454,17 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
     for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-  const int cpt = a.Cin / BK;
-  int u_lo, u_hi;
-  live_tap_rows(m0, BM, a.M, a.S, a.k, a.rate, a.pad, a.rcpS, a.rcpSS, u_lo, u_hi);
-  if (!a.skip_halo) { u_lo = 0; u_hi = a.k; }
-  u_lo = __builtin_amdgcn_readfirstlane(u_lo);
-  u_hi = __builtin_amdgcn_readfirstlane(u_hi);
-  const int nks = (u_hi - u_lo) * a.k * cpt;
-  const char* wlive = reinterpret_cast<const char*>(a.w + (size_t)u_lo * a.k * a.Cin * a.Cout);
-  const char* inb = reinterpret_cast<const char*>(a.in);
-  int lu = u_lo, lv = 0, lc = 0;                // (tap row, tap col, channel chunk) of the K-step being fetched
-  typedef __attribute__((address_space(3))) void* lds_ptr;
-
-  auto issue = [&](int ks, int half, int stage) {
-    float* sa = lds + stage * STAGE;
-    float* sb = sa + ASTAGE;
-    const char* ab = inb + (size_t)(uint32_t)((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK + half * HK) * 4u;
-    const char* wb = wlive + (size_t)(uint32_t)((((lu - u_lo) * a.k + lv) * cpt + lc) * BK + half * HK) * (uint32_t)a.Cout * 4u;
+  for (int w = w_first; w <= w_last; ++w) {
+    const int slot = 2 * w + (sk_first_unit(w, a.sk_U, a.sk_W) >= x0 ? 0 : 1);      // the workgroup's first segment, or its last
+    const float* piece = a.sk_slab + (size_t)slot * (BM * BN) + (size_t)wave * (TM * TN * 16 * 64) + lane;
 #pragma unroll
-    for (int i = 0; i < IA; ++i) {
-      uint32_t o = offA[i]; asm volatile("" : "+v"(o));
-      __builtin_amdgcn_global_load_lds(ab + o, (lds_ptr)(sa + (wave + 4 * i) * 256), 16, 0, 0);
-    }
+    for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-    for (int i = 0; i < IB; ++i) {
-      uint32_t o = offB[i]; asm volatile("" : "+v"(o));
-      __builtin_amdgcn_global_load_lds(wb + o, (lds_ptr)(sb + (wave + 4 * i) * 256), 16, 0, 0);
-    }
-  };
-  // K order (channel chunk, tap row, tap column): the k*k shifted reads of one 32-channel chunk follow each other, so the lines a
-  // tap shares with the one before it (a column shift keeps 7/8 of a row) and with the neighbouring tiles' taps are still in L2
-  // when they are read again.  Against (tap row, tap column, chunk), in-process A/B with a run-time switch (profiles/r02/
-  // conv_korder_ab.txt): fabric-side fetch per launch 6.1 -> 0.9 GB (conv6), 7.8 -> 2.2 GB (conv8); forward -1 %, dgrad -2.4 %.
-  // (The switch itself is gone: it sent the loop counters to scratch memory and their arithmetic to the vector ALU, -7 %.)
-  auto next_kstep = [&]() { if (++lv == a.k) { lv = 0; if (++lu == u_hi) { lu = u_lo; ++lc; } } };
-
-  // fragment addresses (floats): A row r = arow + 32 mi, piece c = 2 q + h in slot c ^ ((r >> 2) & 3); B row k, column
-  const int arow = wm * WTM + li, bcolw = wn * WTN + li;
-  const int sw = (li >> 2) & 3;                 // (arow + 32 mi) >> 2 & 3 == (li >> 2) & 3: WTM and 32 are multiples of 16
-  auto compute = [&](int stage) {
-    const float* As = lds + stage * STAGE;
-    const float* Bs = As + ASTAGE;
-    constexpr int NST = HK / 2;                 // MFMA k-steps per half
-    f32x4 af[2][TM];
-    float bf[2][TN];
+      for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi) af[0][mi] = *reinterpret_cast<const f32x4*>(&As[(arow + mi * 32) * HK + ((h ^ sw) * 4)]);
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni) bf[0][ni] = Bs[(h * 4) * BN + bcolw + ni * 32];
-#pragma unroll
-    for (int st = 0; st < NST; ++st) {
-      const int e = st & 3;
-      if (st + 1 < NST) {
-        const int q1 = (st + 1) >> 2, e1 = (st + 1) & 3;
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) bf[(st + 1) & 1][ni] = Bs[(q1 * 8 + h * 4 + e1) * BN + bcolw + ni * 32];
-        if (e1 == 0) {
-#pragma unroll
-          for (int mi = 0; mi < TM; ++mi)
-            af[q1 & 1][mi] = *reinterpret_cast<const f32x4*>(&As[(arow + mi * 32) * HK + (((2 * q1 + h) ^ sw) * 4)]);
-          __builtin_amdgcn_sched_group_barrier(0x100, TN + TM, 0);
-        } else {
-          __builtin_amdgcn_sched_group_barrier(0x100, TN, 0);
-        }
-      }
-#pragma unroll
-      for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(st >> 2) & 1][mi][e], bf[st & 1][ni], acc[mi][ni], 0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x8, TM * TN, 0);
-    }
-  };
-
-  issue(0, 0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int ks = 0; ks < nks; ++ks) {
-    issue(ks, 1, 1);                              // second half of this K-step lands while the first is multiplied
-    compute(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    next_kstep();
-    if (ks + 1 < nks) issue(ks + 1, 0, 0);        // first half of the next K-step (every wave is done with stage 0)
-    compute(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] += piece[((mi * TN + ni) * 16 + r) * 64];
   }
   conv_epilogue<BM, BN, WM, WN>(a, acc, lds, m0, n0);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------ wgrad
@@ -957,14 +1050,68 @@ __global__ void pad_cin_kernel(const float* __restrict__ w, float* __restrict__ 
 
 int g_conv_variant = -1;     // development switch (drs_debug_conv_variant): 0 = register-staged tiles, 1 = LDS-DMA double-buffered halves, -1 = per tile
 
+int g_conv_splitk = -1;      // development switch (drs_debug_conv_splitk): -1 = stream-K by the rule below, 0 = never, n >= 1: n workgroups
+
+constexpr int SK_MAX_W = 768;          // most workgroups of a stream-K launch: 3 per CU
+constexpr int SK_MAX_TILES = 4096;     // from here on the tiles fill the chip many times over (and the all-halo tap rows are skipped instead)
+
+// Stream-K launch geometry of the forward / input-gradient pass: 0 = one workgroup per tile.
+// A launch of few tiles leaves CUs idle (B = 16, S = 25: 79 M tiles for 256 CUs) and ends with its longest K loop; a launch of a
+// few hundred tiles ends with a round that is nearly empty (B = 16, S = 65: 1058 tiles for 1024 places: 0.65 of the rate the same
+// kernel reaches at S = 75).  Cutting the K-steps of all tiles into W equal ranges, W a whole number of workgroups per CU, gives
+// every CU the same work whatever the tile count; the price is the partial-sum slab of the tiles that are cut (at most two
+// pieces per workgroup) and the fix-up launch.  Per-size table: profiles/r03/small_m.
+int sk_workgroups(int tiles, int nks, int bn, size_t ws_floats) {
+  if (g_conv_splitk == 0 || tiles >= SK_MAX_TILES || nks < 2) return 0;
+  const long long U = (long long)tiles * nks;
+  long long cap = (long long)(ws_floats / (2ull * 128 * (size_t)bn));
+  if (cap > SK_MAX_W) cap = SK_MAX_W;
+  if (cap < 1) return 0;
+  long long W;
+  if (g_conv_splitk > 0) {
+    W = g_conv_splitk;
+  } else {
+    // one workgroup per tile loads the busiest CU with ceil(tiles / 256) tiles: where that is within 7 % of the mean the plain
+    // launch is the faster one (no slab, no fix-up, 4 instead of 3 workgroups per CU); measured at B = 16, S = 25 .. 85
+    // (profiles/r03/ab_streamk_b16.log): plain 0.85-0.87 of the fp32 roof at a perfect fit and proportionally less otherwise,
+    // stream-K 0.78-0.85 at every tile count
+    const long long per = (tiles + 255) / 256;
+    if ((double)tiles >= 0.93 * 256.0 * (double)per) return 0;
+    const int MINU = 12;                                       // K-steps a workgroup should at least have (prologue + epilogue cost ~2)
+    const int occ = 3;                                         // workgroups a CU holds of the stream-K form (136 / 168 VGPRs)
+    long long per_cu = U / (256LL * MINU);
+    per_cu = per_cu < 1 ? 1 : (per_cu > occ ? occ : per_cu);
+    W = 256 * per_cu;
+    if (U < 256LL * MINU) W = U / MINU > 0 ? U / MINU : 1;
+  }
+  if (W > cap) W = cap;
+  if (W > U) W = U;
+  return (int)W;
+}
+
 template <int BM, int BN, int WM, int WN>
-int launch_conv(const ConvArgs& a, hipStream_t st) {
+int launch_conv_dma(ConvArgs& a, float* ws, size_t ws_floats, hipStream_t st) {
+  const int mt = (a.M + BM - 1) / BM, nt = a.Cout / BN;
+  const int nks = a.k * a.k * (a.Cin / BK);
+  const int W = ws ? sk_workgroups(mt * nt, nks, BN, ws_floats) : 0;
+  a.sk_W = W; a.sk_nks = nks; a.sk_U = mt * nt * nks; a.sk_slab = ws;
+  if (W) DRS_LAUNCH((conv_dma_kernel<BM, BN, WM, WN, true>), dim3(W), dim3(256), 0, st, a);
+  else DRS_LAUNCH((conv_dma_kernel<BM, BN, WM, WN, false>), dim3(mt * nt), dim3(256), 0, st, a);
+  int rc = DRS_LAUNCH_CHECK();
+  if (rc || !W) return rc;
+  if (a.sk_U % W == 0 && (a.sk_U / W) % nks == 0) return rc;        // every range is a whole number of tiles: nothing to add up
+  DRS_LAUNCH((conv_sk_fixup_kernel<BM, BN, WM, WN>), dim3(mt * nt), dim3(256), 0, st, a);
+  return DRS_LAUNCH_CHECK();
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_conv(ConvArgs& a, float* ws, size_t ws_floats, hipStream_t st) {
   const int mt = (a.M + BM - 1) / BM, nt = a.Cout / BN;
   if (a.Cin < BK) DRS_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN, true>), dim3(mt * nt), dim3(256), 0, st, a);
   else if constexpr (BM == 128) {
     const bool dma = g_conv_variant != 0;       // in-process A/B (tools/ab_conv.py): the DMA form is 1-6 % faster on every Dilated8Pooling shape at B = 128 and 4 % at B = 16
-    if (dma) DRS_LAUNCH((conv_dma_kernel<BM, BN, WM, WN>), dim3(mt * nt), dim3(256), 0, st, a);
-    else DRS_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN>), dim3(mt * nt), dim3(256), 0, st, a);
+    if (dma) return launch_conv_dma<BM, BN, WM, WN>(a, ws, ws_floats, st);
+    DRS_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN>), dim3(mt * nt), dim3(256), 0, st, a);
   } else DRS_LAUNCH((conv_igemm_kernel<BM, BN, WM, WN>), dim3(mt * nt), dim3(256), 0, st, a);
   return DRS_LAUNCH_CHECK();
 }
@@ -1017,6 +1164,7 @@ int pick_wgrad_cols(int tr, int cout) { return (tr == 128 && cout % 192 == 0 && 
 
 int g_wgrad_balance = 1;     // development switch (drs_debug_wgrad_balance): 0 = equal chunk ranges (and the old rule for skipping), 1 = cut by live pixels
 int g_wgrad_len = 96;       // development switch (drs_debug_wgrad_len): chunks per workgroup small launches aim at
+int g_wgrad_minchunks = 32; // development switch (drs_debug_wgrad_minchunks): fewest 32-pixel chunks a split may have
 int g_wgrad_target_big = 0;  // development switch: workgroups aimed at on launches with many tiles and pixels under the live cut (0 = default)
 
 // workgroups a filter-gradient launch of `work` chunk-tiles (32-pixel chunks x tiles) aims at
@@ -1047,7 +1195,7 @@ int wgrad_uniform_splits(int B, int S, int k, int cin, int cout) {
   const int ntile = ((k * k * cin + tr - 1) / tr) * (cout / to);
   const int nchunks = (int)((M + 31) / 32);
   int want = wgrad_target((long long)nchunks * ntile, ntile, nchunks, false) / ntile;
-  int maxs = (nchunks + 31) / 32;
+  int maxs = (nchunks + g_wgrad_minchunks - 1) / g_wgrad_minchunks;
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
@@ -1086,7 +1234,7 @@ bool wgrad_live_plan(int B, int S, int k, int rate, int pad, int cin, int cout, 
   for (int c = 0; c < nv; ++c) work += (double)cnt[c] * nto * B * vals[c] / 32.0;
   const int target = wgrad_target((long long)work, ntr * nto, nchunks, true);
   const double len = work / target;                          // chunks per workgroup
-  int maxs = (nchunks + 31) / 32;
+  int maxs = (nchunks + g_wgrad_minchunks - 1) / g_wgrad_minchunks;
   if (maxs > cap) maxs = cap;
   if (maxs < 1) maxs = 1;
   double frac[WG_MAXC];
@@ -1126,7 +1274,7 @@ bool wgrad_live_plan(int B, int S, int k, int rate, int pad, int cin, int cout, 
 
 int wgrad_bound_splits(int B, int S, int k, int cin, int cout) {
   const int u = wgrad_uniform_splits(B, S, k, cin, cout);
-  int maxs = (int)(((long long)B * S * S + 1023) / 1024);
+  int maxs = (int)(((long long)B * S * S + 32LL * g_wgrad_minchunks - 1) / (32LL * g_wgrad_minchunks));
   if (maxs < 1) maxs = 1;
   const int bound = u + u / 2 + 1;
   return bound < maxs ? bound : (maxs > u ? maxs : u);
@@ -1166,7 +1314,8 @@ int wgrad_setup(int B, int S, int k, int rate, int pad_before, int cin, int cout
 
 extern "C" {
 
-/* development switch (not part of the documented ABI): 0 = also multiply the filter taps / pixel chunks that meet only halo zeros */
+#ifdef DRS_DEV   /* development switches (include/drs_dev.h): only libdrs_hip_dev.so exports them; process-global */
+/* 0 = also multiply the filter taps / pixel chunks that meet only halo zeros */
 int drs_debug_skip_taps(int v) { const int old = drs_g_skip_halo_taps; if (v >= 0) drs_g_skip_halo_taps = v; return old; }
 
 int drs_debug_wgrad_target(int v) { const int old = g_wgrad_target; if (v > 0) g_wgrad_target = v; return old; }
@@ -1175,20 +1324,31 @@ int drs_debug_wgrad_balance(int v) { const int old = g_wgrad_balance; if (v >= 0
 
 int drs_debug_wgrad_len(int v) { const int old = g_wgrad_len; if (v > 0) g_wgrad_len = v; return old; }
 
+int drs_debug_wgrad_minchunks(int v) { const int old = g_wgrad_minchunks; if (v > 0) g_wgrad_minchunks = v; return old; }
+
 int drs_debug_wgrad_target_big(int v) { const int old = g_wgrad_target_big; if (v >= 0) g_wgrad_target_big = v; return old; }
 
 int drs_debug_conv_wide192(int v) { const int old = g_conv_wide192; if (v >= 0) g_conv_wide192 = v; return old; }
 
 int drs_debug_conv_variant(int v) { const int old = g_conv_variant; if (v >= -1) g_conv_variant = v; return old; }
 
+int drs_debug_conv_splitk(int v) { const int old = g_conv_splitk; if (v >= -1) g_conv_splitk = v; return old; }
+
 int drs_debug_wgrad_variant(int v) { const int old = g_wgrad_variant; if (v >= -1) g_wgrad_variant = v; return old; }
+
+#endif
 
 // M-tile height the forward/dgrad kernel uses for this Cout (= rows per BN-statistics slab row)
 int drs_conv_mtile(int cout) { return pick_tile(cout) >= 64 ? 128 : 256; }
 
-int drs_conv_forward(const float* in, int B, int S, int P, int ld_in, int coff_in, const float* w, const float* bias,
-                     int k, int rate, int pad_before, int cin, int cout, float* out, int ld_out, int coff_out,
-                     int accumulate, float* stats_partial, void* stream) {
+size_t drs_conv_workspace_floats(int cout) {
+  const int bn = pick_conv_tile(cout, 32);
+  return bn >= 64 ? 2ull * SK_MAX_W * 128 * (size_t)bn : 0;
+}
+
+int drs_conv_forward_ws(const float* in, int B, int S, int P, int ld_in, int coff_in, const float* w, const float* bias,
+                        int k, int rate, int pad_before, int cin, int cout, float* out, int ld_out, int coff_out,
+                        int accumulate, float* stats_partial, float* workspace, size_t workspace_floats, void* stream) {
   // cin: a multiple of 32, or 8 / 16 (few-band input: several taps share a K-step; w then has round_up(k*k*cin, 32) rows)
   if (!in || !w || !out || (cin % 32 && cin != 8 && cin != 16) || cout % 32 || k < 1 || rate < 1 || P < pad_before) return DRS_ERR_ARG;
   if (cin < 32 && (ld_in % 4 || coff_in % 4)) return DRS_ERR_ARG;
@@ -1203,19 +1363,29 @@ int drs_conv_forward(const float* in, int B, int S, int P, int ld_in, int coff_i
   a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout; a.accumulate = accumulate;
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
   a.skip_halo = drs_skip_halo_taps_fwd(M, cout);
+  a.sk_slab = nullptr; a.sk_W = 0; a.sk_nks = 0; a.sk_U = 0;
   hipStream_t st = (hipStream_t)stream;
+  if (!workspace) workspace_floats = 0;
   switch (pick_conv_tile(cout, cin)) {
-    case 192: DRS_LAUNCH((conv_dma_kernel<128, 192, 2, 2>), dim3(((a.M + 127) / 128) * (cout / 192)), dim3(256), 0, st, a); return DRS_LAUNCH_CHECK();
-    case 128: return launch_conv<128, 128, 2, 2>(a, st);
-    case 64:  return launch_conv<128, 64, 2, 2>(a, st);     // in-process A/B against 256 x 64: -4..-9 % at B = 128, -2..-12 % at B = 16
-    default:  return launch_conv<256, 32, 4, 1>(a, st);
+    case 192: return launch_conv_dma<128, 192, 2, 2>(a, workspace, workspace_floats, st);
+    case 128: return launch_conv<128, 128, 2, 2>(a, workspace, workspace_floats, st);
+    case 64:  return launch_conv<128, 64, 2, 2>(a, workspace, workspace_floats, st);     // in-process A/B against 256 x 64: -4..-9 % at B = 128, -2..-12 % at B = 16
+    default:  return launch_conv<256, 32, 4, 1>(a, workspace, workspace_floats, st);
   }
+}
+
+int drs_conv_forward(const float* in, int B, int S, int P, int ld_in, int coff_in, const float* w, const float* bias,
+                     int k, int rate, int pad_before, int cin, int cout, float* out, int ld_out, int coff_out,
+                     int accumulate, float* stats_partial, void* stream) {
+  return drs_conv_forward_ws(in, B, S, P, ld_in, coff_in, w, bias, k, rate, pad_before, cin, cout, out, ld_out, coff_out, accumulate,
+                             stats_partial, nullptr, 0, stream);
 }
 
 // upper bound of the splits any row tile of this layer is cut into, whatever its rate / padding (the cut by live pixels may give
 // the full tiles more splits than the equal cut has: up to half as many again): workspace = that many * k*k*cin * cout floats
 int drs_conv_wgrad_splits(int B, int S, int k, int cin, int cout) { return wgrad_bound_splits(B, S, k, cin, cout); }
 
+#ifdef DRS_DEV
 /* development aid (not part of the documented ABI): the workgroups drs_conv_wgrad would launch for this shape, worked out on the
    host by the kernels' own assignment code: out[5 i ..] = (row tile, column tile, split, first chunk, end chunk) of workgroup i,
    out_tile_splits[r] = splits of row tile r.  Returns the number of workgroups (also when it exceeds cap; nothing is then written
@@ -1234,6 +1404,7 @@ int drs_debug_wgrad_cut(int B, int S, int k, int rate, int pad_before, int cin, 
   }
   return nwg;
 }
+#endif
 
 int drs_conv_wgrad(const float* x, int B, int S, int Px, int ld_x, int coff_x, const float* g, int Pg, int ld_g,
                    int coff_g, int k, int rate, int pad_before, int cin, int cin_real, int cout, float* slab,

@@ -1294,8 +1294,9 @@ inline int grid_for(size_t n) { return (int)((n + 255) / 256 < 4096 ? (n + 255) 
 
 extern "C" {
 
-/* development switch between kernel variants (not part of the documented ABI) */
+#ifdef DRS_DEV   /* development switch between kernel variants (include/drs_dev.h; libdrs_hip_dev.so only) */
 int drs_debug_variant(int v) { const int old = g_variant; if (v >= 0) g_variant = v; return old; }
+#endif
 
 
 int drs_split_conv_mtile(int cout) { (void)cout; return 128; }
@@ -1343,7 +1344,9 @@ int drs_conv_forward_split(const unsigned short* in, int B, int S, int P, int ld
   return nsplit == 2 ? dispatch_split<2>(a, st) : dispatch_split<3>(a, st);
 }
 
-int drs_conv_wgrad_split_splits(int B, int S, int k, int cin, int cout, int Pg, int nterms) {
+// splits of the pixel dimension: *bound = the most any (b <= B, s <= S) is cut into (monotone in B and S: what a workspace sized
+// once for (b_max, s_max) needs -- the exact count is not monotone in S); returns the exact count for (B, S)
+static int wgrad_split_count(int B, int S, int k, int cin, int cout, int Pg, int nterms, int* bound) {
   const long long M = (long long)B * S * S;
   const int tr = split_wgrad_rows(k * k * cin, Pg, nterms, cout), to = cout % 128 == 0 ? 128 : 64;
   int ntile = ((k * k * cin + tr - 1) / tr) * (cout / to);
@@ -1354,8 +1357,15 @@ int drs_conv_wgrad_split_splits(int B, int S, int k, int cin, int cout, int Pg, 
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
   if (want < 1) want = 1;
+  if (bound) *bound = want;
   const int cps = (nchunks + want - 1) / want;
   return (nchunks + cps - 1) / cps;
+}
+
+int drs_conv_wgrad_split_splits(int B, int S, int k, int cin, int cout, int Pg, int nterms) {
+  int bound = 1;
+  (void)wgrad_split_count(B, S, k, cin, cout, Pg, nterms, &bound);
+  return bound;
 }
 
 int drs_conv_wgrad_split(const unsigned short* x, int B, int S, int Px, int ld_x, int coff_x, const unsigned short* g,
@@ -1373,7 +1383,7 @@ int drs_conv_wgrad_split(const unsigned short* x, int B, int S, int Px, int ld_x
   a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout; a.slab = slab;
   const int tr = split_wgrad_rows(k * k * cin, Pg, nsplit_terms, cout), to = cout % 128 == 0 ? 128 : 64;
   a.ntr = (k * k * cin + tr - 1) / tr; a.nto = cout / to;
-  const int nsplit = drs_conv_wgrad_split_splits(B, S, k, cin, cout, Pg, nsplit_terms);
+  const int nsplit = wgrad_split_count(B, S, k, cin, cout, Pg, nsplit_terms, nullptr);
   const int nchunks = (int)((M + 31) / 32);
   a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);

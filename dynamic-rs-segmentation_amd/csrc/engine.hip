@@ -24,6 +24,8 @@
 #include <string>
 #include <vector>
 
+__attribute__((visibility("hidden"))) int drs_rccl_all_reduce_sum(void* comm, void* ptr, size_t count, int dtype, hipStream_t stream);      // rccl_comm.hip
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------ net tables
@@ -142,6 +144,16 @@ struct drs_net {
   drs_allreduce_fn allreduce;
   drs_wait_fn wait;
   void* comm_user;
+  // library-side collectives (drs_net_set_rccl, rccl_comm.hip): `rccl_small` carries the latency-bound sums (sync-BN statistics,
+  // the loss, the confusion matrix) -- in the forward pass on the compute stream itself (nothing to overlap, no event hand-over),
+  // in the backward pass on `small_stream` under the filter gradient of the block above; `rccl_big` carries the gradient
+  // buckets on `comm_stream`.  Two communicators, so that a 2 KB sum never queues behind a 4 MB bucket.
+  void* rccl_small;
+  void* rccl_big;
+  hipStream_t comm_stream, small_stream;
+  bool own_comm_stream;
+  std::vector<hipEvent_t> comm_events;      // ring: [2 h] = data ready on the compute stream, [2 h + 1] = sum done on the side stream
+  int comm_next;
   // per-slab (B, S) of the pooling call that last zeroed its halo (the halo of a slab one block owns stays zero)
   std::vector<long long> halo_ok;
   bool timing;
@@ -295,7 +307,7 @@ void list_buffers(drs_net* n) {
     if (i != 0) n->add_buf("gact:" + s.name, M * s.C, F32);                       // gradient wrt it, [M][C]
   }
   int cmax = 0, hmax = 0;
-  size_t rows_fwd = 0, part = 0, slab = 0;
+  size_t rows_fwd = 0, part = 0, slab = 0, conv_ws = 0;
   for (size_t i = 0; i < n->layers.size(); ++i) {
     const Layer& L = n->layers[i];
     const std::string id = std::to_string(i);
@@ -312,7 +324,9 @@ void list_buffers(drs_net* n) {
         part = std::max(part, (size_t)drs_bn_backward_rows(b, s, L.cout, L.pool == 1) * L.cout * 2);
     slab = std::max(slab, (size_t)drs_conv_wgrad_splits(n->b_max, n->s_max, L.k, L.cin_k, L.cout) * L.k * L.k * L.cin_k * L.cout);
     if (i > 0) n->add_buf("wt" + id, (size_t)L.k * L.k * L.cin * L.cout, F32);   // flipped / transposed filter of the input-gradient pass
+    conv_ws = std::max(conv_ws, std::max(drs_conv_workspace_floats(L.cout), i > 0 ? drs_conv_workspace_floats(L.cin) : (size_t)0));
   }
+  n->add_buf("conv_ws", conv_ws, F32);          // partial-sum slab of the stream-K convolution launches (forward: N = cout, input gradient: N = cin)
   n->add_buf("sums", 2 * (size_t)cmax, F64);
   n->add_buf("colsum_scratch", drs_colsum_scratch_doubles(std::max(2 * cmax, n->c_last * n->K)), F64);
   n->add_buf("partial", std::max(rows_fwd * cmax * 2, part), F32);
@@ -350,13 +364,20 @@ void list_buffers(drs_net* n) {
   n->add_buf("loss_mask", M, U8);
 }
 
+// HIP-event bracket of one family's launches (drs_net_timing).  Events are recycled through drs_net::pool_events, and a run that
+// never asks for a summary stops recording at MAX_RECS instead of growing without bound.
+constexpr size_t MAX_RECS = 1 << 16;
 struct Timed {
   drs_net* n; hipStream_t st; int kind; TimeRec rec; bool on;
-  Timed(drs_net* n_, hipStream_t st_, int kind_, double work) : n(n_), st(st_), kind(kind_), on(n_->timing) {
+  static bool take(drs_net* n, hipEvent_t* e) {
+    if (!n->pool_events.empty()) { *e = n->pool_events.back(); n->pool_events.pop_back(); return true; }
+    return hipEventCreate(e) == hipSuccess;
+  }
+  Timed(drs_net* n_, hipStream_t st_, int kind_, double work) : n(n_), st(st_), kind(kind_), on(n_->timing && n_->recs.size() < MAX_RECS) {
     if (!on) return;
     rec.kind = kind; rec.work = work;
-    (void)hipEventCreate(&rec.e0);
-    (void)hipEventCreate(&rec.e1);
+    if (!take(n, &rec.e0)) { on = false; return; }
+    if (!take(n, &rec.e1)) { n->pool_events.push_back(rec.e0); on = false; return; }
     (void)hipEventRecord(rec.e0, st);
   }
   ~Timed() {
@@ -370,11 +391,28 @@ struct Timed {
 
 // every sum over ranks goes through the host's callback; with a callback installed it does so at world == 1 too (an identity there:
 // lets a one-GPU box drive the whole collective path, RCCL included)
-inline bool collectives(const drs_net* n) { return n->world > 1 || n->allreduce != nullptr; }
+inline bool collectives(const drs_net* n) { return n->world > 1 || n->allreduce != nullptr || n->rccl_small != nullptr; }
+
+constexpr int COMM_RING = 64;             // asynchronous sums in flight per step: 8 backward sync-BN sums + <= 6 gradient buckets
+constexpr size_t SMALL_BYTES = 16384;     // sums up to here go to the small communicator
 
 int all_reduce(drs_net* n, void* ptr, size_t count, int dtype, int async, hipStream_t st, int* handle) {
   if (handle) *handle = -1;
   if (!collectives(n)) return DRS_OK;
+  if (n->rccl_small) {
+    static const size_t esz[4] = {4, 8, 1, 4};
+    const bool small = count * esz[dtype] <= SMALL_BYTES || !n->rccl_big;
+    if (!async) return drs_rccl_all_reduce_sum(small ? n->rccl_small : n->rccl_big, ptr, count, dtype, st);
+    const int h = n->comm_next;
+    n->comm_next = (h + 1) % COMM_RING;
+    hipStream_t side = small ? n->small_stream : n->comm_stream;
+    if (hipEventRecord(n->comm_events[2 * h], st) != hipSuccess) return DRS_ERR_HIP;
+    if (hipStreamWaitEvent(side, n->comm_events[2 * h], 0) != hipSuccess) return DRS_ERR_HIP;
+    DRS_TRY(drs_rccl_all_reduce_sum(small ? n->rccl_small : n->rccl_big, ptr, count, dtype, side));
+    if (hipEventRecord(n->comm_events[2 * h + 1], side) != hipSuccess) return DRS_ERR_HIP;
+    if (handle) *handle = h;
+    return DRS_OK;
+  }
   if (!n->allreduce) return DRS_ERR_ARG;
   const int h = n->allreduce(n->comm_user, ptr, count, dtype, async, st);
   if (h < 0) return DRS_ERR_HIP;
@@ -383,6 +421,11 @@ int all_reduce(drs_net* n, void* ptr, size_t count, int dtype, int async, hipStr
 }
 
 int wait_handles(drs_net* n, const std::vector<int>& hs, hipStream_t st) {
+  if (n->rccl_small) {
+    for (int h : hs)
+      if (h >= 0 && hipStreamWaitEvent(st, n->comm_events[2 * h + 1], 0) != hipSuccess) return DRS_ERR_HIP;
+    return DRS_OK;
+  }
   if (!collectives(n) || !n->wait) return DRS_OK;
   for (int h : hs)
     if (h >= 0 && n->wait(n->comm_user, h, st) != 0) return DRS_ERR_HIP;
@@ -410,8 +453,9 @@ int forward_layers(drs_net* n, int B, int S, bool training, double count, hipStr
     float* mr = n->p<float>("mean_rstd" + id);
     {
       Timed t(n, st, K_CONV_FWD, 2.0 * M * L.k * L.k * L.cin * L.cout);
-      DRS_TRY(drs_conv_forward(n->p<float>("act:" + in.name), B, S, in.P, in.C, 0, weight_ptr(n, (int)i), params + L.b_off, L.k, L.rate, L.pad_b,
-                               L.cin_k, L.cout, z, L.cout, 0, 0, training ? partial : nullptr, st));
+      DRS_TRY(drs_conv_forward_ws(n->p<float>("act:" + in.name), B, S, in.P, in.C, 0, weight_ptr(n, (int)i), params + L.b_off, L.k, L.rate, L.pad_b,
+                                  L.cin_k, L.cout, z, L.cout, 0, 0, training ? partial : nullptr, n->p<float>("conv_ws"),
+                                  n->buf("conv_ws")->bytes / sizeof(float), st));
     }
     float* mm = bn + L.bn_off;
     float* mv = mm + L.cout;
@@ -478,20 +522,39 @@ int drs_net_create(const char* net_type, int channels, int num_classes, float we
   // the reference prints a red message and carries on with logits = None (isprs:1679-1680); the library rejects the name
   if (!t || channels < 1 || channels > 32 || num_classes < 1 || num_classes > 8 || b_max < 1 || s_max < 1) return DRS_ERR_ARG;
   if ((long long)b_max * s_max * s_max >= (1 << 24)) return DRS_ERR_ARG;
-  drs_net* n = new drs_net();
-  n->table = t; n->channels = channels; n->K = num_classes; n->wd = weight_decay; n->b_max = b_max; n->s_max = s_max;
-  n->bessel = bessel_moving_var ? 1 : 0; n->lr_decay = lr_decay_factor; n->global_step = 0;
-  n->world = 1; n->rank = 0; n->allreduce = nullptr; n->wait = nullptr; n->comm_user = nullptr; n->timing = false;
-  build_plan(n);
-  list_buffers(n);
-  n->halo_ok.assign(n->slabs.size(), -1);
+  drs_net* n = nullptr;
+  try {                                   // nothing throws across the boundary: an allocation failure of the host-side tables is a status
+    n = new drs_net();
+    n->table = t; n->channels = channels; n->K = num_classes; n->wd = weight_decay; n->b_max = b_max; n->s_max = s_max;
+    n->bessel = bessel_moving_var ? 1 : 0; n->lr_decay = lr_decay_factor; n->global_step = 0;
+    n->world = 1; n->rank = 0; n->allreduce = nullptr; n->wait = nullptr; n->comm_user = nullptr; n->timing = false;
+    n->rccl_small = n->rccl_big = nullptr; n->comm_stream = n->small_stream = nullptr; n->own_comm_stream = false; n->comm_next = 0;
+    build_plan(n);
+    list_buffers(n);
+    n->halo_ok.assign(n->slabs.size(), -1);
+  } catch (...) {
+    delete n;
+    return DRS_ERR_HIP;
+  }
   *out = n;
   return DRS_OK;
 }
 
+static void release_rccl(drs_net* n) {
+  for (auto e : n->comm_events) (void)hipEventDestroy(e);
+  n->comm_events.clear();
+  if (n->small_stream) (void)hipStreamDestroy(n->small_stream);
+  if (n->own_comm_stream && n->comm_stream) (void)hipStreamDestroy(n->comm_stream);
+  n->small_stream = n->comm_stream = nullptr;
+  n->own_comm_stream = false;
+  n->rccl_small = n->rccl_big = nullptr;
+}
+
 void drs_net_destroy(drs_net_t* n) {
   if (!n) return;
+  release_rccl(n);
   for (auto& r : n->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (auto e : n->pool_events) (void)hipEventDestroy(e);
   delete n;
 }
 
@@ -598,6 +661,30 @@ int drs_net_set_comm(drs_net_t* n, int world, int rank, drs_allreduce_fn allredu
   return DRS_OK;
 }
 
+// Data parallelism with the collectives issued by the library itself (RCCL through dlopen, rccl_comm.hip): comm_small / comm_big
+// are ncclComm_t of `world` ranks on this process's GPU (drs_rccl_comm_create, or the host's own from the same librccl);
+// comm_big may be NULL (everything then goes through comm_small); comm_stream (hipStream_t, may be NULL: the library then
+// creates one) carries the gradient buckets.  The communicators stay the caller's: destroy them after the net.
+// Passing comm_small = NULL returns the net to the callback / single-rank form.
+static int set_rccl_impl(drs_net_t* n, int world, int rank, void* comm_small, void* comm_big, void* comm_stream) {
+  if (!n || world < 1 || rank < 0 || rank >= world) return DRS_ERR_ARG;
+  release_rccl(n);
+  if (!comm_small) { n->world = 1; n->rank = 0; return DRS_OK; }
+  if (!drs_rccl_available()) return DRS_ERR_ARG;
+  n->comm_events.resize(2 * COMM_RING);
+  for (auto& e : n->comm_events)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return DRS_ERR_HIP;
+  if (hipStreamCreateWithFlags(&n->small_stream, hipStreamNonBlocking) != hipSuccess) return DRS_ERR_HIP;
+  if (comm_stream) { n->comm_stream = (hipStream_t)comm_stream; n->own_comm_stream = false; }
+  else {
+    if (hipStreamCreateWithFlags(&n->comm_stream, hipStreamNonBlocking) != hipSuccess) return DRS_ERR_HIP;
+    n->own_comm_stream = true;
+  }
+  n->world = world; n->rank = rank; n->rccl_small = comm_small; n->rccl_big = comm_big; n->comm_next = 0;
+  n->allreduce = nullptr; n->wait = nullptr; n->comm_user = nullptr;
+  return DRS_OK;
+}
+
 int drs_net_timing(drs_net_t* n, int enable) {
   if (!n) return DRS_ERR_ARG;
   n->timing = enable != 0;
@@ -619,8 +706,8 @@ int drs_net_timing_summary(drs_net_t* n, int kind, char* name, int name_cap, int
   if (launches) *launches = cnt;
   if (ms) *ms = tms;
   if (work) *work = w;
-  if (kind == K_NKIND - 1) {       // the last family closes a summary: drop the records
-    for (auto& r : n->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  if (kind == K_NKIND - 1) {       // the last family closes a summary: drop the records, keep their events for the next ones
+    for (auto& r : n->recs) { n->pool_events.push_back(r.e0); n->pool_events.push_back(r.e1); }
     n->recs.clear();
   }
   return DRS_OK;
@@ -630,7 +717,7 @@ int drs_net_num_timing_kinds(void) { return K_NKIND; }
 
 // is_training=False pass over the slab filled by drs_crop_normalize: pred (and logits when DRS_WANT_LOGITS); with DRS_WITH_LABELS
 // the confusion matrix of (labels, pred) is ADDED into conf (validation, isprs:1599), gated by acc_mask under DRS_USE_ACC_MASK
-int drs_forward(drs_net_t* n, int B, int S, int flags, int ignore_label, void* stream) {
+static int forward_impl(drs_net_t* n, int B, int S, int flags, int ignore_label, void* stream) {
   if (!n || !check_bs(n, B, S) || !all_bound(n)) return DRS_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const long long M = (long long)B * S * S;
@@ -669,7 +756,7 @@ int drs_apply_update(drs_net_t* n, float lr0, void* stream) {
 // isprs:1089-1099, 646-651), pred, conf (this step, all ranks), and the updated variables unless DRS_NO_UPDATE.
 // global_pixels = number of pixels the loss averages over on all ranks (<= 0: B*S*S*world; the contest form passes the number of
 // unmasked pixels).  Every rank must hold the same B (the batch-norm count is B*S*S*world).
-int drs_train_step(drs_net_t* n, int B, int S, float lr0, int flags, double global_pixels, void* stream) {
+static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, double global_pixels, void* stream) {
   if (!n || !check_bs(n, B, S) || !all_bound(n)) return DRS_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const long long M = (long long)B * S * S;
@@ -778,8 +865,9 @@ int drs_train_step(drs_net_t* n, int B, int S, float lr0, int flags, double glob
       const int acc = written[L.src] ? 1 : 0;
       written[L.src] = 1;
       Timed t(n, st, K_CONV_DGRAD, 2.0 * M * L.k * L.k * L.cin * L.cout);
-      DRS_TRY(drs_conv_forward(gz, B, S, L.halo, L.cout, 0, n->p<float>("wt" + id), nullptr, L.k, L.rate, L.pad_a, L.cout, L.cin,
-                               n->p<float>("gact:" + in.name), in.C, 0, acc, nullptr, st));
+      DRS_TRY(drs_conv_forward_ws(gz, B, S, L.halo, L.cout, 0, n->p<float>("wt" + id), nullptr, L.k, L.rate, L.pad_a, L.cout, L.cin,
+                                  n->p<float>("gact:" + in.name), in.C, 0, acc, nullptr, n->p<float>("conv_ws"),
+                                  n->buf("conv_ws")->bytes / sizeof(float), st));
     }
     deferred = i;
   }
@@ -797,6 +885,19 @@ int drs_train_step(drs_net_t* n, int B, int S, float lr0, int flags, double glob
   DRS_TRY(drs_scale_f64(scalars, 1, 1.0 / n_glob, st));
   if (!(flags & DRS_NO_UPDATE)) DRS_TRY(drs_apply_update(n, lr0, st));
   return DRS_OK;
+}
+
+// the entry points whose host side allocates (strings, vectors): an allocation failure is a status, nothing throws across the ABI
+int drs_forward(drs_net_t* n, int B, int S, int flags, int ignore_label, void* stream) {
+  try { return forward_impl(n, B, S, flags, ignore_label, stream); } catch (...) { return DRS_ERR_HIP; }
+}
+
+int drs_train_step(drs_net_t* n, int B, int S, float lr0, int flags, double global_pixels, void* stream) {
+  try { return train_step_impl(n, B, S, lr0, flags, global_pixels, stream); } catch (...) { return DRS_ERR_HIP; }
+}
+
+int drs_net_set_rccl(drs_net_t* n, int world, int rank, void* comm_small, void* comm_big, void* comm_stream) {
+  try { return set_rccl_impl(n, world, rank, comm_small, comm_big, comm_stream); } catch (...) { return DRS_ERR_HIP; }
 }
 
 }  // extern "C"

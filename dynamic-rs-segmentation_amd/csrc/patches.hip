@@ -100,13 +100,21 @@ __global__ void crop_kernel(const CropArgs a) {
           e = __dadd_rn(e, 0.01 * normal_from(r[0], r[1]));
         }
       }
-      if (a.quantize_f16) {       // numpy >= 2: float16 array (op) float32 scalar runs in float32, the assignment rounds to float16
-        float q = (float)(_Float16)(float)e;
+      if (a.quantize_f16) {
+        // coffee:293 casts the patches to float16, coffee:67-74 normalises in that array.  NumPy >= 2 (NEP 50) evaluates
+        // float16-array (op) numpy-scalar in the SCALAR's type when that is wider, and the assignment rounds to float16:
+        // 1 = float32 scalars (what coffee's own compute_image_mean gives: np.mean / np.std of float32 patches), 2 = float64 scalars
+        _Float16 q = (_Float16)(float)e;
         if (c < 3) {
-          q = (float)(_Float16)(q - (float)a.mean[c]);
-          q = (float)(_Float16)(q / (float)a.stdv[c]);
+          if (a.quantize_f16 == 2) {
+            q = (_Float16)((double)q - a.mean[c]);
+            q = (_Float16)((double)q / a.stdv[c]);
+          } else {
+            q = (_Float16)((float)q - (float)a.mean[c]);
+            q = (_Float16)((float)q / (float)a.stdv[c]);
+          }
         }
-        v[c] = q;
+        v[c] = (float)q;
         continue;
       }
       if (c < 3) e = __ddiv_rn(__dsub_rn(e, a.mean[c]), a.stdv[c]);

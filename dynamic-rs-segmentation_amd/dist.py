@@ -29,6 +29,7 @@ class TorchComm(object):
                 dist.init_process_group(backend=backend)
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
+        self.backend = dist.get_backend()
         # DRS_FORCE_COLLECTIVES=1: issue every collective of the step at world 1 too (sums over one rank: identities).  A one-GPU box
         # can then drive the real RCCL path -- communicator bound to the device, async work handles, stream waits -- end to end.
         self.collective = self.world > 1 or os.environ.get("DRS_FORCE_COLLECTIVES") == "1"

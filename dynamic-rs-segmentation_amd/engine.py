@@ -94,11 +94,48 @@ class EngineNet(DilatedNet):
             if self.h is not None and _lib._lib is not None:
                 _lib.load().drs_net_destroy(self.h)
                 self.h = None
+                for c in getattr(self, "_rccl", []):
+                    _lib.load().drs_rccl_comm_destroy(c)
+                self._rccl = []
         except Exception:
             pass
 
     # ------------------------------------------------------------------ data parallelism: the library's all-reduce callback
     def _install_comm(self):
+        """data parallelism: the step's sums are issued by the library itself through RCCL (drs_net_set_rccl) when the process group
+        is RCCL ('nccl') -- the host only carries the two 128-byte communicator ids from rank 0 to the other ranks; otherwise (gloo
+        rehearsals and CPU tests, DRS_COMM=torch, or RCCL not bindable) through the all-reduce callback into torch.distributed."""
+        import os
+        if getattr(self.comm, "backend", None) == "nccl" and os.environ.get("DRS_COMM", "rccl") != "torch":
+            try:
+                self._install_rccl()
+                return
+            except Exception as e:
+                if os.environ.get("DRS_COMM") == "rccl":
+                    raise
+                print("drs: library-side RCCL collectives unavailable (%r); using the torch.distributed callback" % (e,))
+        self._install_callback()
+
+    def _install_rccl(self):
+        if not _lib.query("drs_rccl_available"):
+            raise _lib.DrsError("librccl could not be bound")
+        ids = []
+        for _ in range(2):                      # small (latency-bound sums) and big (gradient buckets) communicators
+            buf = (C.c_ubyte * 128)()
+            if self.comm.rank == 0:
+                _lib.call("drs_rccl_unique_id", buf)
+            ids.append(self.comm.broadcast_object(bytes(buf), src=0))
+        torch.cuda.set_device(self.dev)
+        self._rccl = []
+        for raw in ids:
+            h = C.c_void_p()
+            _lib.call("drs_rccl_comm_create", self.comm.world, self.comm.rank, (C.c_ubyte * 128).from_buffer_copy(raw), C.byref(h))
+            self._rccl.append(h)
+        _lib.call("drs_net_set_rccl", self.h, self.comm.world, self.comm.rank, self._rccl[0], self._rccl[1], None)
+        self.collectives = "rccl"
+
+    def _install_callback(self):
+        self.collectives = "callback"
         spans = sorted((t.data_ptr(), t.data_ptr() + t.numel() * t.element_size(), t) for t in self._bufs.values())
         self._works = {}
         self._next_handle = 0

@@ -149,19 +149,35 @@ def sync_rng(comm):
     np.random.seed(seeds[1])
 
 
+def rank0_call(comm, fn, what):
+    """fn() on rank 0 only, its result on every rank.  If rank 0 raises (a bad cache file, an I/O error, a failing builder) EVERY rank
+    raises -- the others are not left waiting in the broadcast until the communicator times out."""
+    v, err = None, None
+    if comm.rank == 0:
+        try:
+            v = fn()
+        except Exception as e:
+            if comm.world == 1:
+                raise
+            err = "%s: %s" % (type(e).__name__, e)
+    ok, payload = comm.broadcast_object((err is None, v if err is None else err))
+    if not ok:
+        raise RuntimeError("rank 0 failed on %s: %s" % (what, payload))
+    return payload
+
+
 def rank0_cached(comm, path, make):
     """the reference's cwd / output .npy caches (isprs:1634-1639, 2087-2115) under data parallelism: rank 0 loads or builds and
     saves, every rank gets rank 0's array (no rank reads a half-written file, every rank takes the same branch)."""
-    v = None
-    if comm.rank == 0:
+    def load_or_make():
         if os.path.isfile(path):
-            v = np.load(path, allow_pickle=True)
-        else:
-            v = make()
-            tmp = path + ".tmp%d.npy" % os.getpid()
-            np.save(tmp, np.asarray(v, dtype=object) if isinstance(v, list) else v)
-            os.replace(tmp, path)                    # atomic: a concurrent reader sees the old state or the whole file
-    return comm.broadcast_object(v)
+            return np.load(path, allow_pickle=True)
+        v = make()
+        tmp = path + ".tmp%d.npy" % os.getpid()
+        np.save(tmp, np.asarray(v, dtype=object) if isinstance(v, list) else v)
+        os.replace(tmp, path)                    # atomic: a concurrent reader sees the old state or the whole file
+        return v
+    return rank0_call(comm, load_or_make, path)
 
 
 # ------------------------------------------------------------------------------------------------- training
@@ -340,20 +356,22 @@ def predict_tile(net, pool, map_index, crop_size, batch_size, mean_full, std_ful
         return _predict_tile_bands(net, pool, map_index, crop_size, batch_size, mean_full, std_full, comm), total
     prob = torch.zeros(h * w * K, dtype=torch.float32, device=net.dev)
     occur = torch.zeros(h * w, dtype=torch.int32, device=net.dev)
-    bs = min(batch_size, net.b_max)
-    nb = -(-total // bs)
+    # batches are the REFERENCE's: batch i starts where its `batch_size` puts it (for flavour="contest" that start depends on the
+    # batch size, contest:275), whatever this net's b_max is -- under data parallelism b_max is batch_size / world -- and is fed
+    # to the net in pieces of at most b_max windows
+    nb = -(-total // batch_size)
     st = net._stream()
     for i in range(nb):
         if i % comm.world != comm.rank:
             continue
-        pos = P.window_positions(h, w, crop_size, stride, i, bs, flavour)          # flavour: where batch i starts (patches.window_start)
-        if len(pos) == 0:
-            continue
-        inst = np.concatenate([np.full((len(pos), 1), map_index), pos], axis=1)
-        P.crop_to_net(net, pool, inst, crop_size, mean_full, std_full)
-        _, logits = net.forward(len(pos), crop_size, want_logits=True)
-        _lib.call("drs_stitch_accumulate", prob.data_ptr(), occur.data_ptr(), logits.data_ptr(), h, w, K, crop_size, stride,
-                  P.window_start(h, w, crop_size, stride, i, bs, flavour), len(pos), st)
+        pos_all = P.window_positions(h, w, crop_size, stride, i, batch_size, flavour)  # flavour: where batch i starts (patches.window_start)
+        f0 = P.window_start(h, w, crop_size, stride, i, batch_size, flavour)
+        for c0 in range(0, len(pos_all), net.b_max):
+            pos = pos_all[c0:c0 + net.b_max]
+            inst = np.concatenate([np.full((len(pos), 1), map_index), pos], axis=1)
+            P.crop_to_net(net, pool, inst, crop_size, mean_full, std_full)
+            _, logits = net.forward(len(pos), crop_size, want_logits=True)
+            _lib.call("drs_stitch_accumulate", prob.data_ptr(), occur.data_ptr(), logits.data_ptr(), h, w, K, crop_size, stride, f0 + c0, len(pos), st)
     if comm.world > 1:          # (the multi-scale caller needs the whole sums; the plain path below exchanges bands instead)
         comm.all_reduce_sum(prob)
         comm.all_reduce_sum(occur)

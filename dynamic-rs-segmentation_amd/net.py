@@ -261,6 +261,9 @@ class DilatedNet(object):
             slab = max([slab] + [_lib.query("drs_conv_wgrad_split_splits", B, S, L.k, L.cin_k, L.cout, L.halo, self.ns) * L.k * L.k * L.cin_k * L.cout
                                  for i, L in enumerate(p.layers) if self._split_fwd(i)])
         self.slab = torch.zeros(slab, **f32)
+        # partial-sum slab of the stream-K convolution launches (forward: N = cout; input gradient: N = cin)
+        self.conv_ws = torch.zeros(max(1, max(max(_lib.query("drs_conv_workspace_floats", L.cout), _lib.query("drs_conv_workspace_floats", L.cin) if i else 0)
+                                              for i, L in enumerate(p.layers))), **f32)
         # conv1's filter with the bands padded to cin_k; with cin_k < 32 its rows are padded (zeros) to a whole number of K-steps
         self.w0pad = torch.zeros(-(-L0.k * L0.k * L0.cin_k // 32) * 32 * L0.cout, **f32)
         self.wt = [None] + [torch.zeros(L.k * L.k * L.cin * L.cout, **f32) for L in p.layers[1:]]
@@ -410,9 +413,9 @@ class DilatedNet(object):
                         B, S, Pin, ldin, cin_off, _ptr(self.wf_planes[i]), self._bias_ptr(L.name),
                         L.k, L.rate, L.pad_b, L.cin_k, L.cout, _ptr(self.z[i]), L.cout, 0, 0, _ptr(stats), self.ns, st)
             else:
-                self._k("conv_fwd", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_forward", _ptr(xin), B, S, Pin, ldin, cin_off,
+                self._k("conv_fwd", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_forward_ws", _ptr(xin), B, S, Pin, ldin, cin_off,
                         self._weight_ptr(i), self._bias_ptr(L.name),
-                        L.k, L.rate, L.pad_b, L.cin_k, L.cout, _ptr(self.z[i]), L.cout, 0, 0, _ptr(stats), st)
+                        L.k, L.rate, L.pad_b, L.cin_k, L.cout, _ptr(self.z[i]), L.cout, 0, 0, _ptr(stats), _ptr(self.conv_ws), self.conv_ws.numel(), st)
             bo = p.bn_offsets[L.name]
             mm, mv = self.bn[bo:bo + L.cout], self.bn[bo + L.cout:bo + 2 * L.cout]
             if training and not self.comm.collective:
@@ -603,9 +606,9 @@ class DilatedNet(object):
                             B, S, L.halo, L.cout, 0, _ptr(self.wd_planes[i]), None, L.k, L.rate,
                             L.pad_a, L.cout, L.cin, _ptr(self.gbuf[L.src]), p.buffers[L.src][0], 0, acc, None, self.ns, st)
                 else:
-                    self._k("conv_dgrad", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_forward", _ptr(self.gz), B, S, L.halo, L.cout,
+                    self._k("conv_dgrad", 2.0 * M * L.k * L.k * L.cin * L.cout, "drs_conv_forward_ws", _ptr(self.gz), B, S, L.halo, L.cout,
                             0, _ptr(self.wt[i]), None, L.k, L.rate, L.pad_a, L.cout, L.cin, _ptr(self.gbuf[L.src]), p.buffers[L.src][0], 0,
-                            acc, None, st)
+                            acc, None, _ptr(self.conv_ws), self.conv_ws.numel(), st)
             deferred_wgrad = (lambda i=i: filter_gradient(i))
         deferred_wgrad()
         if self.comm.collective:

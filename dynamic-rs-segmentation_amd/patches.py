@@ -227,7 +227,9 @@ def crop_to_net(net, pool, instances, S, mean, std, aug=None, void_label=-1, qua
     """dynamically_create_patches + normalize_images (isprs:1742-1745 / 1579-1583) fused on the device:
     fills net's conv1 slab, net.labels and net.acc_mask for `instances` rows (map, x, y[, rot]).
     quantize_f16: the coffee script's training patches pass through float16 (coffee:293) and are normalised in place in that
-    array (coffee:1290): value, difference and quotient are each rounded to float16."""
+    array (coffee:1290): value, difference and quotient are each rounded to float16; NumPy >= 2 evaluates the difference and the
+    quotient in the type of the mean / std scalars when that is wider: float32 for coffee's own statistics (np.mean / np.std of
+    float32 patches, coffee:78-79), float64 when `mean` arrives as float64 (drs_crop_normalize modes 1 / 2)."""
     import ctypes as C
     B = len(instances)
     net._check(B, S)
@@ -251,7 +253,8 @@ def crop_to_net(net, pool, instances, S, mean, std, aug=None, void_label=-1, qua
               p_inst, p_rot if aug is not None else None, p_ron if aug is not None else None,
               None if noise is None else noise.data_ptr(), p_non if aug is not None else None,
               aug.seed if aug is not None else 0, aug.index0 if aug is not None else 0, C.cast(m3c, C.c_void_p), C.cast(s3c, C.c_void_p), B, S, P, ld,
-              slab.data_ptr(), net.labels.data_ptr(), net.acc_mask.data_ptr(), int(void_label), 1 if quantize_f16 else 0, net._stream())
+              slab.data_ptr(), net.labels.data_ptr(), net.acc_mask.data_ptr(), int(void_label),
+              (2 if getattr(mean, "dtype", None) == np.float64 else 1) if quantize_f16 else 0, net._stream())
     net._keep = noise                                            # alive until the stream has consumed it
     return inst[:, 1:3]
 

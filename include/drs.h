@@ -45,6 +45,15 @@ extern "C" {
  * The input-gradient pass is this same call on the haloed output gradient with the filter from
  * drs_filter_flip_transpose and pad_before := pad_after. */
 int drs_conv_mtile(int cout);
+/* drs_conv_forward_ws: the same with a caller-owned workspace (>= drs_conv_workspace_floats(cout) floats to enable every
+ * geometry; NULL / smaller: fewer or none).  With it, launches of fewer than 4096 tiles run "stream-K": the K-steps of all
+ * tiles are cut into equal ranges, one per workgroup and a whole number of workgroups per CU, the tiles that a cut crosses are
+ * completed from partial sums in the workspace in a fixed order (bitwise reproducible; sums associate differently from
+ * drs_conv_forward's).  This is the path of the per-rank batches of data parallelism (16 patches of 25..85 pixels a side). */
+size_t drs_conv_workspace_floats(int cout);
+int drs_conv_forward_ws(const float* in, int B, int S, int P, int ld_in, int coff_in, const float* w, const float* bias,
+                        int k, int rate, int pad_before, int cin, int cout, float* out, int ld_out, int coff_out,
+                        int accumulate, float* stats_partial, float* workspace, size_t workspace_floats, void* stream);
 int drs_conv_forward(const float* in, int B, int S, int P, int ld_in, int coff_in, const float* w, const float* bias,
                      int k, int rate, int pad_before, int cin, int cout, float* out, int ld_out, int coff_out,
                      int accumulate, float* stats_partial, void* stream);
@@ -77,7 +86,8 @@ int drs_filter_pad_cin(const float* w, float* wp, int k, int cin, int cin_pad, i
  *   drs_conv_forward_split : drs_conv_forward on terms (`in`, `w`); cout % 64 == 0.  The input-gradient pass is the same
  *                        call on the terms of the haloed output gradient with wd and pad_before := pad_after.
  *                        stats_partial rows hold drs_split_conv_mtile(cout) pixels.
- *   drs_conv_wgrad_split : drs_conv_wgrad on terms; slab = drs_conv_wgrad_split_splits(..., Pg, nterms) * k*k*cin*cout floats.
+ *   drs_conv_wgrad_split : drs_conv_wgrad on terms; slab = drs_conv_wgrad_split_splits(..., Pg, nterms) * k*k*cin*cout floats
+ *                        (an upper bound that is monotone in B and S: a slab sized for (b_max, s_max) serves every smaller call).
  *                        With Pg > 0 pixels past the end read the gradient slab's first halo pixel (zeros). */
 int drs_split_conv_mtile(int cout);
 int drs_split_terms(const float* src, size_t n, int nterms, unsigned short* terms, void* stream);
@@ -200,7 +210,10 @@ int drs_confusion(const unsigned char* labels, const unsigned char* pred, const 
  * void_label (contest_dilated_random.py:235-239; -1 = none).  Normalisation touches channels 0,1,2 only.
  * mean3 / std3 are HOST pointers to 3 doubles each (copied into the kernel arguments).
  * quantize_f16: coffee_dilated_random.py:293 casts its training patches to float16 and :67-74 normalises them in that array:
- * value, value - mean and (value - mean) / std are each rounded to float16 (float32 arithmetic, as numpy >= 2 evaluates it). */
+ * value, value - mean and (value - mean) / std are each rounded to float16.  NumPy >= 2 evaluates float16-array (op) numpy-scalar in
+ * the scalar's type: 1 = mean / std are float32 scalars (what coffee's compute_image_mean yields from its float32 patches, :78-79):
+ * float32 arithmetic; 2 = float64 scalars (e.g. statistics read from a float64 .npy): float64 arithmetic.  (NumPy 1.x cast the
+ * scalar to float16 first: not reproduced.) */
 int drs_crop_normalize(const void* tiles, int tiles_are_f64, const unsigned char* labels, const long long* tile_off,
                        const long long* lab_off, const int* tile_h, const int* tile_w, int C, const int* inst,
                        const double* rot, const unsigned char* rot_on, const double* noise,
@@ -274,6 +287,20 @@ int drs_grad_buffer(drs_net_t* net, float** dev_ptr, size_t* count);
 long long drs_net_global_step(drs_net_t* net, long long set_to);      /* set_to < 0: read only (`main_global_step`, isprs:1685) */
 float drs_net_learning_rate(const drs_net_t* net, float lr0);         /* exponential_decay(lr0, global_step, 50000, factor, staircase) */
 int drs_net_set_comm(drs_net_t* net, int world, int rank, drs_allreduce_fn allreduce, drs_wait_fn wait, void* user);
+/* Library-side collectives (SURVEY 8b `drs_allreduce(handle, comm)`): the sums above issued by the step engine itself through
+ * RCCL, bound at run time by dlopen (csrc/rccl_comm.hip) -- no host callback in the step.  comm_small / comm_big: ncclComm_t of
+ * `world` ranks on this process's GPU, made by drs_rccl_comm_create below or by the host from the same librccl; comm_big may be
+ * NULL.  comm_small carries the latency-bound sums (forward sync-BN statistics on the compute stream itself, backward ones on a
+ * side stream under the filter gradient of the block above), comm_big the gradient buckets on comm_stream (hipStream_t; NULL: the
+ * library creates one).  The communicators remain the caller's (destroy them after the net).  comm_small = NULL undoes it.
+ *   drs_rccl_available : 1 if librccl could be bound.
+ *   drs_rccl_unique_id : ncclGetUniqueId into id128 (128 bytes, host memory); rank 0 calls it, the host hands the bytes to every rank.
+ *   drs_rccl_comm_create / _destroy : ncclCommInitRank / ncclCommDestroy (collective over the ranks; the device must be current). */
+int drs_rccl_available(void);
+int drs_rccl_unique_id(unsigned char* id128);
+int drs_rccl_comm_create(int world, int rank, const unsigned char* id128, void** comm);
+int drs_rccl_comm_destroy(void* comm);
+int drs_net_set_rccl(drs_net_t* net, int world, int rank, void* comm_small, void* comm_big, void* comm_stream);
 int drs_train_step(drs_net_t* net, int B, int S, float lr0, int flags, double global_pixels, void* stream);
 int drs_forward(drs_net_t* net, int B, int S, int flags, int ignore_label, void* stream);
 int drs_apply_update(drs_net_t* net, float lr0, void* stream);        /* the update alone (after DRS_NO_UPDATE) */

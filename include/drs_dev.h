@@ -1,0 +1,36 @@
+/*
+ * drs_dev.h -- development switches of libdrs_hip_dev.so (the same sources as libdrs_hip.so compiled with -DDRS_DEV).
+ *
+ * NOT part of the drop-in boundary (include/drs.h) and not exported by the product library.  They select between kernel forms
+ * that are held bitwise equal by the tests (register-staged / LDS-DMA tiles, the cut of the filter gradient, skipping of the
+ * all-halo taps) and feed the in-process A/B tools under tools/.  Every switch is PROCESS-GLOBAL state of the dev library:
+ * all nets of a process that runs on the dev library share it.  Each setter returns the previous value; a negative argument
+ * (where noted) only reads.
+ */
+#ifndef DRS_DEV_H_
+#define DRS_DEV_H_
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int drs_debug_skip_taps(int v);          /* 0 multiply the all-halo taps / chunks too, 1 skip them where it pays (default), 2 always; < 0 reads */
+int drs_debug_conv_variant(int v);       /* forward / input gradient: 0 register-staged tiles, 1 LDS-DMA halves, -1 per tile (default) */
+int drs_debug_conv_wide192(int v);       /* Cout = 192 as one 128 x 192 tile (1, default) or three 128 x 64 tiles (0) */
+int drs_debug_conv_splitk(int v);        /* split-K of the forward / input-gradient pass: -1 by the cost model (default), 0 never, n >= 1 that many ranges */
+int drs_debug_wgrad_variant(int v);      /* filter gradient: 0 register-staged, 1 LDS-DMA halves, -1 per tile (default) */
+int drs_debug_wgrad_balance(int v);      /* 1 cut the pixel dimension by live pixels (default), 0 equal chunk ranges */
+int drs_debug_wgrad_target(int v);       /* workgroups the pixel split aims at (default 2048) */
+int drs_debug_wgrad_target_big(int v);   /* the same on launches with many tiles and pixels (0 = default rule) */
+int drs_debug_wgrad_len(int v);          /* chunks per workgroup small launches aim at (default 96) */
+int drs_debug_wgrad_minchunks(int v);    /* fewest 32-pixel chunks a split of the pixel dimension may have (default 32) */
+int drs_debug_variant(int v);            /* split-bf16 forward kernels: 0 register-staged, 1 LDS-DMA (default) */
+/* the workgroups drs_conv_wgrad would launch for a shape, worked out on the host by the kernels' own assignment code:
+   out[5 i ..] = (row tile, column tile, split, first chunk, end chunk) of workgroup i; out_tile_splits[r] = splits of row tile r.
+   Returns the number of workgroups (nothing is written past cap), negative on a rejected shape. */
+int drs_debug_wgrad_cut(int B, int S, int k, int rate, int pad_before, int cin, int cout, int* out, int cap, int* out_tile_splits,
+                        int* out_tile_rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRS_DEV_H_ */

@@ -144,6 +144,19 @@ def _sync_worker(rank, world, port, tmp):
     except RuntimeError:
         ok = True
     assert ok
+    # a failure on rank 0 (a corrupt cache file, a builder that raises) fails EVERY rank instead of stranding the others in the broadcast
+    bad = os.path.join(tmp, "corrupt.npy")
+    if rank == 0:
+        open(bad, "wb").write(b"not an npy file")
+    comm.barrier()
+    for trial in (lambda: loops.rank0_cached(comm, bad, make),
+                  lambda: loops.rank0_cached(comm, os.path.join(tmp, "never.npy"), lambda: 1 / 0)):
+        raised = False
+        try:
+            trial()
+        except RuntimeError as e:
+            raised = "rank 0 failed" in str(e)
+        assert raised
     np.save(os.path.join(tmp, "r%d.npy" % rank), np.array([a[0], a[1], b[0], b[1], float(v1.sum()), float(v2.sum())]))
     comm.barrier()
     dist.destroy_process_group()

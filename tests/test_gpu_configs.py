@@ -33,48 +33,96 @@ def _padded(x, P):
 # conv8, conv3 (4x4, asymmetric pad 4/5), conv6 (Cout 192: the 128x64 tile) of Dilated8Pooling
 SHAPES = [(3, 8, 256, 256), (4, 3, 64, 128), (3, 6, 192, 192)]
 SIZES = [(128, 65), (128, 77), (128, 85), (16, 100)]
+# DenseDilated6 (isprs:914-959): conv6 / conv5 / conv4 read channels [0, Cin) of the 448-wide concat slab, their input gradients
+# ACCUMULATE into the [M][448] gradient of that slab; conv2 (Cout 32) is the 256 x 32 register-staged tile
+DENSE_SHAPES = [(3, 6, 320, 128), (3, 5, 192, 128), (4, 4, 128, 64), (5, 2, 32, 32)]
+DENSE_SIZES = [(128, 50), (128, 75), (16, 100)]
+# Dilated6Pooling (isprs:962-993) at configs[1]'s own size
+GRSL_SHAPES = [(3, 5, 128, 256), (3, 6, 256, 256)]
 
 
-@pytest.mark.parametrize("B,S", SIZES)
-@pytest.mark.parametrize("k,rate,cin,cout", SHAPES)
-def test_conv_above_64_matches_oracle_on_sampled_patches(k, rate, cin, cout, B, S):
+def _split_planes(lib, t, ns):
+    p = torch.zeros(ns * t.numel(), dtype=torch.int16, device=DEV)
+    lib.call("drs_split_terms", t.data_ptr(), t.numel(), ns, p.data_ptr(), stream())
+    return p
+
+
+def _conv_case(k, rate, cin, cout, B, S, arith="f32", ld=None):
+    """forward, input gradient and filter gradient of one layer shape at (B, S) on the HIP path (either arithmetic), the input a
+    channel slice [0, cin) of an `ld`-wide slab whose other channels hold junk, the input gradient ACCUMULATED into an `ld`-wide
+    gradient slab when ld != cin: against the fp64 oracle on sampled patches, exactly for the filter gradient of a gradient that is
+    zero outside them, by adjointness on the dense one; skip-on / skip-off bitwise."""
     from drs_amd import _lib
+    _lib = _lib.dev()         # libdrs_hip_dev.so: the same sources + the switch that forces the halo-tap skip on / off
+    ns = {"f32": 0, "bf16x6": 3}[arith]
+    ld = ld or cin
+    dense = ld != cin
     M = B * S * S
-    g0 = torch.Generator(device=DEV).manual_seed(1000 * k + 10 * rate + S)
+    g0 = torch.Generator(device=DEV).manual_seed(1000 * k + 10 * rate + S + cin)
     pb, pa = onets.same_pad(k, rate)
     P = max(pb, pa)
     x = torch.randn(B, S, S, cin, device=DEV, generator=g0)
     g = torch.randn(B, S, S, cout, device=DEV, generator=g0)
     w = torch.randn(k, k, cin, cout, device=DEV, generator=g0) / (k * k * cin) ** 0.5
     bias = torch.randn(cout, device=DEV, generator=g0)
-    xp, gp = _padded(x, P), _padded(g, P)
+    xw = x
+    if dense:
+        xw = torch.full((B, S, S, ld), 3.0, device=DEV)        # junk in the channels this layer must not read
+        xw[..., :cin] = x
+    xp, gp = _padded(xw, P), _padded(g, P)
     st = stream()
-    raw = _lib.load()
-    wt = torch.empty(w.numel(), device=DEV)
-    _lib.call("drs_filter_flip_transpose", w.data_ptr(), wt.data_ptr(), k, cin, cout, st)
-    ns = _lib.query("drs_conv_wgrad_splits", B, S, k, cin, cout)
-    slab = torch.empty(ns * w.numel(), device=DEV)
-    mt = _lib.query("drs_conv_mtile", cout)
-    rows = (M + mt - 1) // mt
+    raw = _lib
     sample = sorted({0, B // 2, B - 1})
     gs = torch.zeros_like(g)
     gs[sample] = g[sample]
     gsp = _padded(gs, P)
+    gx0 = torch.randn(M, ld, device=DEV, generator=g0) if dense else None
+    if ns:
+        if cout % 64 or cin % 32:
+            pytest.skip("layer stays on the exact-fp32 kernels in every arithmetic")
+        xt, gt, gst = _split_planes(_lib, xp, ns), _split_planes(_lib, gp, ns), _split_planes(_lib, gsp, ns)
+        wf = torch.zeros(ns * w.numel(), dtype=torch.int16, device=DEV)
+        wd = torch.zeros(ns * w.numel(), dtype=torch.int16, device=DEV)
+        split_dgrad = cin % 64 == 0
+        _lib.call("drs_filter_split", w.data_ptr(), k, cin, cin, cout, ns, wf.data_ptr(), wd.data_ptr() if split_dgrad else None, st)
+        nsp = _lib.query("drs_conv_wgrad_split_splits", B, S, k, cin, cout, P, ns)
+        mt = _lib.query("drs_split_conv_mtile", cout)
+    else:
+        nsp = _lib.query("drs_conv_wgrad_splits", B, S, k, cin, cout)
+        mt = _lib.query("drs_conv_mtile", cout)
+    wt = torch.empty(w.numel(), device=DEV)
+    _lib.call("drs_filter_flip_transpose", w.data_ptr(), wt.data_ptr(), k, cin, cout, st)
+    slab = torch.empty(nsp * w.numel(), device=DEV)
+    rows = (M + mt - 1) // mt
 
     def run():
         y = torch.empty(M, cout, device=DEV)
         stats = torch.zeros(rows * cout * 2, device=DEV)
-        _lib.call("drs_conv_forward", xp.data_ptr(), B, S, P, cin, 0, w.data_ptr(), bias.data_ptr(), k, rate, pb, cin, cout, y.data_ptr(),
-                  cout, 0, 0, stats.data_ptr(), st)
-        gx = torch.empty(M, cin, device=DEV)
-        _lib.call("drs_conv_forward", gp.data_ptr(), B, S, P, cout, 0, wt.data_ptr(), None, k, rate, pa, cout, cin, gx.data_ptr(), cin, 0, 0,
-                  None, st)
+        gx = gx0.clone() if dense else torch.empty(M, cin, device=DEV)
         gw = torch.empty(w.numel(), device=DEV)
-        _lib.call("drs_conv_wgrad", xp.data_ptr(), B, S, P, cin, 0, gp.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout, slab.data_ptr(),
-                  gw.data_ptr(), st)
         gws = torch.empty(w.numel(), device=DEV)
-        _lib.call("drs_conv_wgrad", xp.data_ptr(), B, S, P, cin, 0, gsp.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout, slab.data_ptr(),
-                  gws.data_ptr(), st)
+        if ns:
+            _lib.call("drs_conv_forward_split", xt.data_ptr(), B, S, P, ld, 0, wf.data_ptr(), bias.data_ptr(), k, rate, pb, cin, cout,
+                      y.data_ptr(), cout, 0, 0, stats.data_ptr(), ns, st)
+            if split_dgrad:
+                _lib.call("drs_conv_forward_split", gt.data_ptr(), B, S, P, cout, 0, wd.data_ptr(), None, k, rate, pa, cout, cin, gx.data_ptr(),
+                          ld, 0, 1 if dense else 0, None, ns, st)
+            else:
+                _lib.call("drs_conv_forward", gp.data_ptr(), B, S, P, cout, 0, wt.data_ptr(), None, k, rate, pa, cout, cin, gx.data_ptr(), ld, 0,
+                          1 if dense else 0, None, st)
+            _lib.call("drs_conv_wgrad_split", xt.data_ptr(), B, S, P, ld, 0, gt.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout,
+                      slab.data_ptr(), gw.data_ptr(), ns, st)
+            _lib.call("drs_conv_wgrad_split", xt.data_ptr(), B, S, P, ld, 0, gst.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout,
+                      slab.data_ptr(), gws.data_ptr(), ns, st)
+        else:
+            _lib.call("drs_conv_forward", xp.data_ptr(), B, S, P, ld, 0, w.data_ptr(), bias.data_ptr(), k, rate, pb, cin, cout, y.data_ptr(),
+                      cout, 0, 0, stats.data_ptr(), st)
+            _lib.call("drs_conv_forward", gp.data_ptr(), B, S, P, cout, 0, wt.data_ptr(), None, k, rate, pa, cout, cin, gx.data_ptr(), ld, 0,
+                      1 if dense else 0, None, st)
+            _lib.call("drs_conv_wgrad", xp.data_ptr(), B, S, P, ld, 0, gp.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout, slab.data_ptr(),
+                      gw.data_ptr(), st)
+            _lib.call("drs_conv_wgrad", xp.data_ptr(), B, S, P, ld, 0, gsp.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout, slab.data_ptr(),
+                      gws.data_ptr(), st)
         torch.cuda.synchronize()
         return y, stats, gx, gw, gws
 
@@ -88,13 +136,17 @@ def test_conv_above_64_matches_oracle_on_sampled_patches(k, rate, cin, cout, B, 
     for a, b, c in zip(res[0], res[2], res[1]):
         assert torch.equal(a, b) and torch.equal(a, c)          # skipped products are exact zeros: bitwise neutral
     y, stats, gx, gw, gws = res[1]
+    if dense:
+        assert torch.equal(gx[:, cin:], gx0[:, cin:])           # channels beyond the slice are not touched
+        gx = gx[:, :cin] - gx0[:, :cin]                         # what was accumulated (one fp32 rounding of the sum apart)
+    tol = 1e-5 if not dense else 2e-5
     # (1) forward and input gradient on the sampled patches against the fp64 oracle
     w64, b64 = w.cpu().numpy().astype(np.float64), bias.cpu().numpy().astype(np.float64)
     xs, gsn = x[sample].cpu().numpy().astype(np.float64), g[sample].cpu().numpy().astype(np.float64)
     ref = T.conv2d_same(xs, w64, rate) + b64
     gx_ref, gw_ref = T.conv2d_same_bwd(xs, w64, rate, gsn)
     assert rel_err(y.view(B, S, S, cout)[sample].cpu().numpy(), ref) < 1e-5
-    assert rel_err(gx.view(B, S, S, cin)[sample].cpu().numpy(), gx_ref) < 1e-5
+    assert rel_err(gx.reshape(B, S, S, cin)[sample].cpu().numpy(), gx_ref) < tol
     # (2) the filter gradient of the sampled patches (same grid, splits and chunk walk as the dense one), exactly
     assert rel_err(gws.view(k, k, cin, cout).cpu().numpy(), gw_ref) < 1e-5
     # (3) dense filter gradient and dense input gradient by adjointness with the (checked) forward
@@ -103,7 +155,7 @@ def test_conv_above_64_matches_oracle_on_sampled_patches(k, rate, cin, cout, B, 
     b = (x.reshape(M, cin).double() * gx.double()).sum().item()
     c = (w.reshape(-1).double() * gw.double()).sum().item()
     scale = (yb.norm() * g.double().norm()).item()
-    assert abs(a - b) < 1e-6 * scale and abs(a - c) < 1e-6 * scale, (a, b, c)
+    assert abs(a - b) < (1e-6 if not dense else 3e-6) * scale and abs(a - c) < 1e-6 * scale, (a, b, c)
     # (4) batch-norm statistics of the epilogue: per-tile sums reduce to the moments of y (ragged last M tile included)
     sv = conv_stats_moments(_lib, stats, M, mt, cout)
     y64 = y.double()
@@ -111,6 +163,71 @@ def test_conv_above_64_matches_oracle_on_sampled_patches(k, rate, cin, cout, B, 
     var = y64.var(0, unbiased=False).cpu().numpy()
     np.testing.assert_allclose(sv[:, 0] / M, mean, rtol=0, atol=1e-6 * np.abs(mean).max() + 1e-7)
     np.testing.assert_allclose(sv[:, 1] / M - (sv[:, 0] / M) ** 2, var, rtol=2e-6)
+
+
+@pytest.mark.parametrize("arith", ["f32", "bf16x6"])
+@pytest.mark.parametrize("B,S", SIZES)
+@pytest.mark.parametrize("k,rate,cin,cout", SHAPES)
+def test_conv_above_64_matches_oracle_on_sampled_patches(k, rate, cin, cout, B, S, arith):
+    _conv_case(k, rate, cin, cout, B, S, arith)
+
+
+@pytest.mark.parametrize("arith", ["f32", "bf16x6"])
+@pytest.mark.parametrize("B,S", DENSE_SIZES)
+@pytest.mark.parametrize("k,rate,cin,cout", DENSE_SHAPES)
+def test_dense_net_conv_shapes_in_the_concat_slab_match_oracle(k, rate, cin, cout, B, S, arith):
+    """BASELINE configs[3] (DenseDilated6, sizes up to 100): the dense-specific paths at B = 128, S = 50 / 75 and B = 16, S = 100."""
+    _conv_case(k, rate, cin, cout, B, S, arith, ld=448)
+
+
+@pytest.mark.parametrize("arith", ["f32", "bf16x6"])
+@pytest.mark.parametrize("k,rate,cin,cout", GRSL_SHAPES)
+def test_dilated_grsl_conv5_conv6_at_config2_size(k, rate, cin, cout, arith):
+    """BASELINE configs[1]: Dilated6Pooling's own layers (128 -> 256 at rate 5, 256 -> 256 at rate 6) at batch 64, 64 x 64."""
+    _conv_case(k, rate, cin, cout, 64, 64, arith)
+
+
+def test_dense_classifier_448_channels_two_classes_at_size():
+    """the DenseDilated6 classifier (C = 448, K = 2; isprs:950-957) at B = 128, S = 50: logits / loss / gradients against fp64 on
+    sampled pixels and as sums."""
+    from drs_amd import _lib
+    B, S, C, K = 128, 50, 448, 2
+    M = B * S * S
+    g0 = torch.Generator(device=DEV).manual_seed(44)
+    feat = torch.randn(M, C, device=DEV, generator=g0)
+    w = torch.randn(C, K, device=DEV, generator=g0) / C ** 0.5
+    bias = torch.randn(K, device=DEV, generator=g0) * 0.1
+    y = torch.randint(0, K, (M,), device=DEV, generator=g0, dtype=torch.int32).to(torch.uint8)
+    crow = _lib.query("drs_classifier_rows", B, S)
+    logits = torch.empty(M * K, device=DEV)
+    pred = torch.empty(M, dtype=torch.uint8, device=DEV)
+    gfeat = torch.empty(M * C, device=DEV)
+    dwp, dbp = torch.empty(crow * C * K, device=DEV), torch.empty(crow * K, device=DEV)
+    lp = torch.empty(crow, dtype=torch.float64, device=DEV)
+    conf = torch.zeros(K * K, dtype=torch.int32, device=DEV)
+    st = stream()
+    _lib.call("drs_classifier_loss", feat.data_ptr(), B, S, 0, C, 0, C, K, w.data_ptr(), bias.data_ptr(), y.data_ptr(), None, None, 1.0 / M,
+              logits.data_ptr(), pred.data_ptr(), gfeat.data_ptr(), C, 0, dwp.data_ptr(), dbp.data_ptr(), lp.data_ptr(), conf.data_ptr(), st)
+    scr = torch.zeros(_lib.query("drs_colsum_scratch_doubles", C * K), dtype=torch.float64, device=DEV)
+    dw, db = torch.empty(C * K, device=DEV), torch.empty(K, device=DEV)
+    _lib.call("drs_rows_reduce_f32", dwp.data_ptr(), crow, C * K, dw.data_ptr(), scr.data_ptr(), st)
+    _lib.call("drs_rows_reduce_f32", dbp.data_ptr(), crow, K, db.data_ptr(), scr.data_ptr(), st)
+    torch.cuda.synchronize()
+    f64, w64 = feat.double(), w.double()
+    lg = f64 @ w64 + bias.double()
+    assert rel_err(logits.view(M, K).cpu().numpy(), lg.cpu().numpy()) < 1e-5
+    p = torch.softmax(lg, 1)
+    dl = (p - torch.nn.functional.one_hot(y.long(), K)) / M
+    assert rel_err(gfeat.view(M, C).cpu().numpy(), (dl @ w64.t()).cpu().numpy()) < 1e-5
+    assert rel_err(dw.view(C, K).cpu().numpy(), (f64.t() @ dl).cpu().numpy()) < 1e-5
+    assert rel_err(db.cpu().numpy(), dl.sum(0).cpu().numpy()) < 1e-5
+    lt = torch.nn.functional.cross_entropy(lg, y.long(), reduction="sum").item()
+    assert abs(lp.sum().item() - lt) < 1e-6 * lt
+    margin = (lg[:, 0] - lg[:, 1]).abs() > 1e-4
+    assert torch.equal(pred.long()[margin], lg.argmax(1)[margin])
+    want = torch.zeros(K, K, dtype=torch.int64, device=DEV)
+    want.index_put_((y.long(), pred.long()), torch.ones(M, dtype=torch.int64, device=DEV), accumulate=True)
+    assert torch.equal(conf.view(K, K).long(), want)
 
 
 def test_uniform_size_training_loop_config3(tmp_path, capsys):
@@ -149,6 +266,73 @@ def test_uniform_size_training_loop_config3(tmp_path, capsys):
     assert "Validation: Overall Accuracy=" in text
     best = int(text.split("Current patch size ")[1].split()[0])
     assert best == 25 + int(np.argmax(score / np.maximum(want, 1)))     # select_best_patch_size, isprs:549-608
+
+
+def test_dense_multinomial_loss_training_loop_config4(tmp_path, capsys):
+    """BASELINE configs[3] at its own sizes: DenseDilated6 (`dilated_icpr_rate6_densely`), `multinomial` over [25, 100] with the
+    listed sizes {25, 50, 75, 100} at twice the base probability (isprs:61-71), update_type=loss (score += loss * epoch / 10,
+    isprs:1757-1763), 4-band tiles, 2 classes, batch 32, 24 steps: every step scores its own size once, sizes above 64 are trained
+    on, the best-size rule follows the scores (`loss`: the smallest mean, unsampled sizes count as 0 and win, isprs:549-608)."""
+    from drs_amd import loops, sampling as SP
+    from drs_amd.cli import init_size_scores
+    from drs_amd.synthetic import make_tile
+    a, b = make_tile(330, 350, 4, 2, seed=41, n_seeds=50), make_tile(260, 240, 4, 2, seed=42, n_seeds=30)
+    random.seed(6)
+    np.random.seed(6)
+    dist = SP.create_distributions_over_classes([a[1]], 25, 10, num_classes=2)
+    tdist = SP.create_distributions_over_classes([b[1]], 25, 25, num_classes=2)
+    rot = SP.create_rotation_distribution(dist)
+    values = [25, 50, 75, 100]
+    acc, occ, chosen, probs = init_size_scores("multinomial", values)
+    assert len(acc) == 76 and abs(probs.sum() - 1) < 1e-12 and abs(probs[25] - 2 / 76) < 1e-12
+    steps, B = 24, 32
+    out = str(tmp_path) + "/"
+    net = loops.train([a[0]], [a[1]], dist, rot, [b[0]], [b[1]], tdist, ["b"], 0.01, B, steps, 0.001, [0.4] * 4, [0.2] * 4, "loss",
+                      "multinomial", values, acc, occ, chosen, probs, 20, out, 8, "dilated_icpr_rate6_densely", "vaihingen", "none",
+                      num_classes=2, device=DEV, val_cache_dir=str(tmp_path))
+    text = capsys.readouterr().out
+    assert net.plan.dense and net.global_step == steps and net.s_max == 100
+    sizes = [int(t) for t in text.split("\n") if t.strip().isdigit()]
+    assert len(sizes) == steps and min(sizes) >= 25 and max(sizes) <= 100 and max(sizes) > 64
+    want = np.bincount(np.asarray(sizes) - 25, minlength=76)
+    np.testing.assert_array_equal(np.load(out + "patch_occur_step_%d.npy" % steps), want)
+    score = np.load(out + "patch_acc_loss_step_%d.npy" % steps)
+    assert np.all(score[want == 0] == 0) and np.all(score[want > 0] > 0)          # loss * epoch_counter / 10 per drawn size
+    losses = [float(t.split("Loss= ")[1].split()[0]) for t in text.split("\n") if "Training Minibatch" in t]
+    assert len(losses) == 3 and all(np.isfinite(losses)) and losses[-1] < 1.5 * losses[0]
+    # epoch_counter is 1 throughout (the super-batch of 3200 instances is not exhausted): score = sum of batch losses / 10
+    assert 0.01 * steps < score.sum() < 1.0 * steps
+    assert np.all(np.isfinite(net.params.cpu().numpy()))
+    assert "Validation: Overall Accuracy=" in text
+    best = int(text.split("Current patch size ")[1].split()[0])
+    mean = score / np.maximum(want, 1)
+    assert mean[best - 25] == mean.min() == 0.0          # the smallest mean wins, and a size never drawn has mean 0 (isprs:552)
+
+
+def test_dilated_grsl_config2_steps_are_reproducible_and_learn():
+    """BASELINE configs[1]: `dilated_grsl` (Dilated6Pooling, isprs:962-993), single_fixed 64 x 64, 5 bands, batch 64, patches of a
+    2048 x 2048 tile: three steps, twice -- bitwise equal (no float atomics anywhere), the loss falls, the confusion matrix counts
+    every pixel."""
+    from drs_amd import patches as P
+    from drs_amd.net import DilatedNet
+    from drs_amd.synthetic import make_tile, grid_instances
+    B, S = 64, 64
+    tile, lab = make_tile(2048, 2048, 5, 6, seed=1234)
+    pool = P.TilePool([tile], [lab], DEV)
+    inst = grid_instances(2048, 2048, S, 25, B, seed=3)
+    runs = []
+    for rep in range(2):
+        net = DilatedNet("dilated_grsl", 5, 6, 0.005, b_max=B, s_max=S, device=DEV, seed=42)
+        assert len(net.plan.layers) == 6 and net.plan.layers[5].cout == 256 and net.plan.layers[4].rate == 5
+        losses = []
+        for i in range(3):
+            P.crop_to_net(net, pool, inst, S, [0.5] * 3, [0.1] * 3)
+            out = net.train_step(B, S, 0.01)
+            losses.append(net.loss_value(out["loss_parts"]))
+        runs.append((losses, net.params.clone()))
+        assert int(out["conf"].sum().item()) == B * S * S
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
+    assert runs[0][0][2] < runs[0][0][0]
 
 
 def _oracle_tile(o, tile, lab, S, bs, mean, std, K):
@@ -239,11 +423,17 @@ def test_config5_full_6000x6000_mosaic_properties():
     avg = prob.view(n * n, K) / occ.view(-1, 1).float()
     assert torch.equal(out.long(), avg.argmax(1))
     assert bool(torch.isfinite(prob).all())
-    # the corner window is exactly the forward pass of that window alone
+    # the corner window is the forward pass of that window alone (a batch of one runs the stream-K cut of the convolutions, a batch
+    # of 256 one workgroup per tile: the same products, summed in a different order)
     P.crop_to_net(net, pool, np.array([[0, 0, 0]]), S, mean, std)
     _, lg = net.forward(1, S)
     torch.cuda.synchronize()
-    assert torch.equal(prob.view(n, n, K)[:32, :32], lg[0, :32, :32])       # pixels covered by the first window only
+    corner = prob.view(n, n, K)[:32, :32]                                   # pixels covered by the first window only
+    assert float((corner - lg[0, :32, :32]).abs().max()) <= 2e-5 * float(lg.abs().max())
+    P.crop_to_net(net, pool, np.concatenate([np.zeros((Bw, 1), dtype=np.int64), P.window_positions(n, n, S, 32, 0, Bw)], axis=1), S, mean, std)
+    _, lgb = net.forward(Bw, S)
+    torch.cuda.synchronize()
+    assert torch.equal(corner, lgb[0, :32, :32])                            # ... and bit for bit the first batch's forward pass
     del avg
     prob2, occ2, _ = loops.predict_tile(net, pool, 0, S, Bw, mean, std, return_sums=True)
     torch.cuda.synchronize()

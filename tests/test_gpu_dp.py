@@ -60,10 +60,12 @@ def test_two_rank_step_equals_single_rank(tmp_path):
     np.testing.assert_array_equal(r["conf"], res["conf"].cpu().numpy())
 
 
-def _rccl_worker(rank, world, port, out, engine):
+def _rccl_worker(rank, world, port, out, mode):
     """ONE rank on the real backend ('nccl' = RCCL) with every collective of the step forced on (sums over one rank are identities):
     communicator bound to the device, asynchronous gradient buckets, sync-BN sums, stream waits -- the code an 8-GPU run executes."""
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", DRS_FORCE_COLLECTIVES="1")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", DRS_FORCE_COLLECTIVES="1",
+                      DRS_COMM={"rccl": "rccl", "callback": "torch", "op": "torch"}[mode])
+    engine = mode != "op"
     import torch.distributed as dist
     from drs_amd.dist import TorchComm
     from drs_amd.net import DilatedNet
@@ -81,18 +83,22 @@ def _rccl_worker(rank, world, port, out, engine):
         res = d.train_step(B, S, 0.01)
         losses.append(d.loss_value(res["loss_parts"]))
     torch.cuda.synchronize()
-    assert len(calls) >= 3 * 3, calls                       # gradient buckets and backward BN sums went through the communicator
+    if mode == "rccl":       # the library issued every sum itself (drs_net_set_rccl): nothing came back into Python
+        assert d.collectives == "rccl" and not calls
+    else:
+        assert len(calls) >= 3 * 3, calls                   # gradient buckets and backward BN sums went through the communicator
     np.savez(out, grads=d.grads.cpu().numpy(), params=d.params.cpu().numpy(), bn=d.bn.cpu().numpy(), losses=np.asarray(losses),
              conf=res["conf"].cpu().numpy())
     comm.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("engine", [True, False], ids=["step-level", "op-level"])
-def test_rccl_collectives_at_world_one_leave_the_step_unchanged(tmp_path, engine):
+@pytest.mark.parametrize("mode", ["rccl", "callback", "op"], ids=["step-level-library-rccl", "step-level-callback", "op-level"])
+def test_rccl_collectives_at_world_one_leave_the_step_unchanged(tmp_path, mode):
     from drs_amd.net import DilatedNet
+    engine = mode != "op"
     out = str(tmp_path / "rccl.npz")
-    mp.spawn(_rccl_worker, args=(1, 29700 + os.getpid() % 1000, out, engine), nprocs=1, join=True)
+    mp.spawn(_rccl_worker, args=(1, 29700 + os.getpid() % 1000, out, mode), nprocs=1, join=True)
     x, y = _inputs()
     d = DilatedNet(NET, CH, K, 0.005, b_max=B, s_max=S, device="cuda:0", seed=3, engine=engine)
     losses = []

@@ -88,6 +88,7 @@ def test_halo_tap_skipping_is_bitwise_neutral(lib, k, rate, cin, cout, B, S):
     """Filter taps / pixel chunks that meet only the zero halo are not executed on large grids (drs_common.hpp); forcing the
     skip on (2) and off (0) at small sizes must give bitwise identical forward, input-gradient and filter-gradient results, in
     the exact-fp32 and in the split-bf16 kernels (tiles crossing image boundaries, ragged chunks, odd S included)."""
+    lib = lib.dev()          # libdrs_hip_dev.so: the same sources + the A/B switches of include/drs_dev.h
     rng = np.random.default_rng(S * 7 + cout)
     x = rng.normal(size=(B, S, S, cin)).astype(np.float32)
     w = (rng.normal(size=(k, k, cin, cout)) * 0.05).astype(np.float32)
@@ -107,7 +108,7 @@ def test_halo_tap_skipping_is_bitwise_neutral(lib, k, rate, cin, cout, B, S):
     wg = torch.zeros(ns * w.size, dtype=torch.int16, device=DEV)
     lib.call("drs_filter_split", wd.data_ptr(), k, cin, cin, cout, ns, wf.data_ptr(), wg.data_ptr() if cin % 64 == 0 else None, stream())
     res = {}
-    raw = lib.load()
+    raw = lib
     try:
         for mode in (0, 2):
             raw.drs_debug_skip_taps(mode)
@@ -437,6 +438,7 @@ def test_register_staged_and_lds_dma_kernel_forms_are_bitwise_equal(lib, k, rate
     library picks per tile by measured speed.  K order, chunk walk and summation order are the same, so the two forms must agree
     bit for bit -- also on patch sides that are not multiples of 32 (table walk), ragged M tiles and a last chunk with pixels past
     the end (the DMA form zeroes those rows in LDS)."""
+    lib = lib.dev()          # libdrs_hip_dev.so: the same sources + the A/B switches of include/drs_dev.h
     rng = np.random.default_rng(S * 13 + cout + k)
     x = rng.normal(size=(B, S, S, cin)).astype(np.float32)
     w = (rng.normal(size=(k, k, cin, cout)) * 0.05).astype(np.float32)
@@ -447,7 +449,7 @@ def test_register_staged_and_lds_dma_kernel_forms_are_bitwise_equal(lib, k, rate
     M = B * S * S
     xd, gd, wd, bd = padded(x, P), padded(g, P), dev(w), dev(bias)
     mt = lib.query("drs_conv_mtile", cout)
-    raw = lib.load()
+    raw = lib
     res = {}
     try:
         for v in (0, 1):
@@ -480,6 +482,7 @@ def test_filter_gradient_chunk_walk_over_patch_sides(lib, S, B):
     multiple of 32, per-pixel offset tables that each thread advances incrementally (below 11 pixels a side: by division).  Every
     regime -- sides below 11, not / exactly a multiple of 32, chunks spanning several rows or images, a ragged last chunk -- against
     the fp64 oracle, in both kernel forms and with the all-halo chunks skipped or not, which must also agree bit for bit."""
+    lib = lib.dev()          # libdrs_hip_dev.so: the same sources + the A/B switches of include/drs_dev.h
     k, rate, cin, cout = 3, 2, 64, 128
     rng = np.random.default_rng(S * 31 + B)
     x = rng.normal(size=(B, S, S, cin)).astype(np.float32)
@@ -489,7 +492,7 @@ def test_filter_gradient_chunk_walk_over_patch_sides(lib, S, B):
     P = max(pb, pa)
     xd, gd = padded(x, P), padded(g, P)
     _, gw_ref = T.conv2d_same_bwd(x.astype(np.float64), w.astype(np.float64), rate, g.astype(np.float64))
-    raw = lib.load()
+    raw = lib
     outs = []
     try:
         for variant in (0, 1):

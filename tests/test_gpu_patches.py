@@ -145,6 +145,15 @@ def test_coffee_sampler_flip_by_index_and_float16_on_device(S):
     np.testing.assert_array_equal(xq, g["patches16_%d" % S].astype(np.float32))       # coffee:293
     xn, _, _ = _indexed_on_device(g, S, 3, 2, dist, tiles, labs, quantize=True, mean=g["mean"], std=g["std"])
     np.testing.assert_array_equal(xn, g["normalized16_%d" % S].astype(np.float32))    # coffee:67-74 on the float16 array, bit for bit
+    # statistics that arrive as float64 (e.g. read back from a float64 .npy): NumPy >= 2 then evaluates float16 (op) float64 in float64
+    m64, s64 = g["mean"].astype(np.float64) * 1.0000001, g["std"].astype(np.float64) * 0.9999999
+    want = g["patches16_%d" % S].copy()
+    for c in range(3):                                                                # coffee:67-74 with float64 scalars, by NumPy itself
+        want[..., c] = np.subtract(want[..., c], m64[c])
+        want[..., c] = np.divide(want[..., c], s64[c])
+    assert want.dtype == np.float16
+    xn64, _, _ = _indexed_on_device(g, S, 3, 2, dist, tiles, labs, quantize=True, mean=m64, std=s64)
+    np.testing.assert_array_equal(xn64, want.astype(np.float32))
 
 
 def _ref_patches(g, S):

@@ -19,10 +19,23 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hdr = open(os.path.join(root, "include", "drs.h")).read()
-    declared = set(re.findall(r"^(?:int|void|float|long long)\s+(drs_[a-z0-9_]+)\s*\(", hdr, flags=re.M))      # every function of the header
+    pat = r"^(?:int|void|float|long long|size_t)\s+(drs_[a-z0-9_]+)\s*\("
+    declared = set(re.findall(pat, hdr, flags=re.M))      # every function of the header
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)
+    # the product library exports the drop-in boundary and nothing else; the development switches (include/drs_dev.h) exist in
+    # libdrs_hip_dev.so only, which the package's product path never loads
+    import subprocess
+    exported = set(re.findall(r" T (drs_[a-z0-9_]+)$", subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True,
+                                                                        check=True).stdout, flags=re.M))
+    assert exported == declared, exported ^ declared
+    dev_hdr = open(os.path.join(root, "include", "drs_dev.h")).read()
+    dev_declared = set(re.findall(pat, dev_hdr, flags=re.M))
+    assert dev_declared == set(_lib.DEV_SIGNATURES) and all(n.startswith("drs_debug_") for n in dev_declared)
+    dev = _lib.dev()
+    for name in declared | dev_declared:
+        assert hasattr(dev, name)
     # pure size queries are host code and callable without a GPU
     assert _lib.query("drs_conv_mtile", 256) == 128 and _lib.query("drs_conv_mtile", 64) == 128 and _lib.query("drs_conv_mtile", 32) == 256
     assert _lib.query("drs_bn_backward_rows", 2, 16, 64, 0) == 16 and _lib.query("drs_bn_backward_rows", 128, 64, 64, 0) == 2048

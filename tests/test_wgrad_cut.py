@@ -25,9 +25,7 @@ def _live_range(row_first, row_last, cin, k, rate, pad, S):
 
 
 def _cut(B, S, k, rate, pad, cin, cout):
-    lib = _lib.load()
-    lib.drs_debug_wgrad_cut.restype = C.c_int
-    lib.drs_debug_wgrad_cut.argtypes = [C.c_int] * 7 + [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib = _lib.dev()          # libdrs_hip_dev.so: the product library does not export the development entry points
     cap = 1 << 16
     out = np.zeros((cap, 5), dtype=np.int32)
     nt = np.zeros(256, dtype=np.int32)
@@ -99,7 +97,7 @@ def test_cut_is_a_partition_and_balanced(B, S):
 
 
 def test_equal_cut_still_available():
-    lib = _lib.load()
+    lib = _lib.dev()
     old = lib.drs_debug_wgrad_balance(0)
     try:
         wg, nt, tr = _cut(128, 64, 3, 8, 8, 256, 256)
@@ -112,3 +110,23 @@ def test_equal_cut_still_available():
             assert v[0][1] == 0 and v[-1][2] == 128 * 64 * 64 // 32 and all(v[i][2] == v[i + 1][1] for i in range(len(v) - 1))
     finally:
         lib.drs_debug_wgrad_balance(old)
+
+
+def test_split_path_slab_bound_is_monotone_in_batch_and_size():
+    """the split-bf16 filter-gradient workspace is sized once, at (b_max, s_max), while the patch side changes every step
+    (isprs:1727-1737) and the exact split count is not monotone in S.  drs_conv_wgrad_split_splits therefore returns a bound that
+    is: every (b <= b_max, s <= s_max) needs no more than the allocation.  Swept over the nets / sizes the advisor found overflowing."""
+    from drs_amd import _lib
+    from drs_amd.nets import Plan
+    _lib.load()
+    for net_type in ("dilated_icpr_rate6_small", "dilated_icpr_rate6_squeeze", "dilated_grsl_rate8", "dilated_icpr_rate6_densely"):
+        plan = Plan(net_type, 5, 6, first_cin_pad=8)
+        for ns in (2, 3):
+            for b_max, s_max in ((32, 85), (32, 100), (64, 65), (128, 45)):
+                for L in plan.layers:
+                    if L.cout % 64 or L.cin_k % 32:
+                        continue
+                    alloc = _lib.query("drs_conv_wgrad_split_splits", b_max, s_max, L.k, L.cin_k, L.cout, L.halo, ns)
+                    for b in (1, b_max // 2, b_max):
+                        for s in range(1, s_max + 1):
+                            assert _lib.query("drs_conv_wgrad_split_splits", b, s, L.k, L.cin_k, L.cout, L.halo, ns) <= alloc, (net_type, L.name, b, s)

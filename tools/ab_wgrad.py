@@ -2,23 +2,26 @@
 """In-process A/B of the filter-gradient launch policy on the Dilated8Pooling shapes (development aid): interleaved repetitions on
 one device, best-of per arm.  An arm is a string of development-switch settings: b<0|1> cut by live pixels off / on
 (drs_debug_wgrad_balance), t<N> workgroup target (drs_debug_wgrad_target), g<N> target of the many-tiles-and-pixels launches under
-the live cut (drs_debug_wgrad_target_big), v<0|1> kernel form (drs_debug_wgrad_variant; default per tile), l<N> chunks per workgroup that small launches aim at.
+the live cut (drs_debug_wgrad_target_big), v<0|1> kernel form (drs_debug_wgrad_variant; default per tile), l<N> chunks per workgroup that small launches aim at,
+m<N> fewest chunks a split may have (drs_debug_wgrad_minchunks).
     python tools/ab_wgrad.py [B=128] [S=64] [arms=b0,b1,b1g2048] [layers=1,2,...] [rounds=4]"""
 import os, re, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from drs_amd import _lib
+_lib = _lib.dev()      # libdrs_hip_dev.so: the library with the A/B switches of include/drs_dev.h
 from drs_amd.nets import Plan
 DEV = "cuda:0"
 
 
 def apply(lib, arm):
-    kv = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"([btgvl])(\d+)", arm))
+    kv = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"([btgvlm])(\d+)", arm))
     lib.drs_debug_wgrad_balance(kv.get("b", 1))
     lib.drs_debug_wgrad_target(kv.get("t", 2048))
     lib.drs_debug_wgrad_target_big(kv.get("g", 0))
     lib.drs_debug_wgrad_variant(kv.get("v", -1))
     lib.drs_debug_wgrad_len(kv.get("l", 96))
+    lib.drs_debug_wgrad_minchunks(kv.get("m", 32))
 
 
 def main(B=128, S=64, arms="b0,b1", rounds=4, layers=""):

@@ -8,6 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from drs_amd import _lib  # noqa: E402
+_lib = _lib.dev()      # libdrs_hip_dev.so: the library with the A/B switches of include/drs_dev.h
 from drs_amd.nets import Plan  # noqa: E402
 
 DEV = "cuda:0"

@@ -4,6 +4,7 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from drs_amd import _lib
+_lib = _lib.dev()      # libdrs_hip_dev.so: the library with the A/B switches of include/drs_dev.h
 from drs_amd.nets import Plan
 DEV = "cuda:0"
 def main(B=128, S=64, layers="4,8", reps=3, skip=1, target=0, fwd=0, variant=-1):
