@@ -1164,11 +1164,14 @@ int pick_wgrad_cols(int tr, int cout) { return (tr == 128 && cout % 192 == 0 && 
 
 int g_wgrad_balance = 1;     // development switch (drs_debug_wgrad_balance): 0 = equal chunk ranges (and the old rule for skipping), 1 = cut by live pixels
 int g_wgrad_len = 96;       // development switch (drs_debug_wgrad_len): chunks per workgroup small launches aim at
-int g_wgrad_minchunks = 32; // development switch (drs_debug_wgrad_minchunks): fewest 32-pixel chunks a split may have
+int g_wgrad_minchunks = 8;  // development switch (drs_debug_wgrad_minchunks): fewest 32-pixel chunks a split may have
 int g_wgrad_target_big = 0;  // development switch: workgroups aimed at on launches with many tiles and pixels under the live cut (0 = default)
 
-// workgroups a filter-gradient launch of `work` chunk-tiles (32-pixel chunks x tiles) aims at
-int wgrad_target(long long work, int ntile, int nchunks, bool balanced) {
+int g_wgrad_model = 1;       // development switch (drs_debug_wgrad_model): 1 = per-CU cost model for launches below the `big` class, 0 = the r02 table
+
+// workgroups a filter-gradient launch of `work` chunk-tiles (32-pixel chunks x tiles) aims at; occ = workgroups of this tile
+// shape a CU holds (4; the 128 x 192 tile: 3)
+int wgrad_target(long long work, int ntile, int nchunks, bool balanced, int occ) {
   // fill the 256 CUs evenly.  Small launches (the per-rank batches of data parallelism) want long workgroups more than many:
   // >= 96 chunks each, down to one round of 512 (sweeps at B = 16 / 32 in profiles/r02/wgrad_ablation.txt).  Launches with many
   // tiles and pixels: with equal chunk ranges and the dead chunks skipped the workgroups differ in length by up to a quarter and
@@ -1177,10 +1180,28 @@ int wgrad_target(long long work, int ntile, int nchunks, bool balanced) {
   fit = fit < 512 ? 512 : (fit > g_wgrad_target ? g_wgrad_target : fit);
   const bool big = ntile >= 24 && nchunks >= 8192;
   if (!balanced) return big ? 2 * g_wgrad_target : (int)fit;
-  // equal-length workgroups: the chip holds 4 x 256 of them, and one workgroup over a whole number of rounds costs a round
+  // equal-length workgroups: the chip holds occ x 256 of them, and one workgroup over a whole number of rounds costs a round
   // (measured: 513 workgroups instead of 507 +27 %, 2049 instead of 2030 +7 %), so aim AT a whole number of workgroups per CU
   // (one round) or of rounds, and never above it (wgrad_live_plan rounds the splits down)
   if (big) return g_wgrad_target_big ? g_wgrad_target_big : 3 * 1024;
+  if (g_wgrad_model) {
+    // n workgroups per CU, all resident: a CU's time ~ (its chunks + n * o) / eff(n), o = what a workgroup costs besides its
+    // chunks (assignment, pipeline fill, the 64 KB slab tile: ~6 chunks' worth), eff(n) = share of the MFMA rate n co-resident
+    // workgroups reach (1: 0.75, 2: 0.88, 3: 0.93, 4: 0.95: the barrier bubbles of one are filled by the others).  Sweeps at
+    // B = 16, S = 25 .. 85: profiles/r03/ab_wgrad_small.log.  Longer than g_wgrad_len chunks per workgroup: whole further rounds.
+    static const double eff[5] = {1.0, 0.75, 0.88, 0.93, 0.95};
+    const double W0 = (double)work / 256.0, o = 6.0;
+    int n = 1;
+    double bt = 1e30;
+    for (int i = 1; i <= occ && i <= 4; ++i) {
+      const double t = (W0 + i * o) / eff[i];
+      if (t < bt) { bt = t; n = i; }
+    }
+    int r = (int)(W0 / n / (double)g_wgrad_len + 0.5);
+    r = r < 1 ? 1 : r;
+    const long long t = 256LL * n * r;
+    return (int)(t > 4096 ? 4096 : t);
+  }
   static const int steps[] = {512, 768, 1024, 2048, 3072, 4096};
   int best = steps[0];
   for (int s : steps)
@@ -1188,13 +1209,13 @@ int wgrad_target(long long work, int ntile, int nchunks, bool balanced) {
   return best;
 }
 
-// equal chunk ranges: the number of splits.  Never less than 32 chunks (1024 pixels) per split.
+// equal chunk ranges: the number of splits.  Never less than g_wgrad_minchunks chunks per split.
 int wgrad_uniform_splits(int B, int S, int k, int cin, int cout) {
   const long long M = (long long)B * S * S;
   const int tr = pick_wgrad_rows(k * k * cin), to = pick_wgrad_cols(tr, cout);
   const int ntile = ((k * k * cin + tr - 1) / tr) * (cout / to);
   const int nchunks = (int)((M + 31) / 32);
-  int want = wgrad_target((long long)nchunks * ntile, ntile, nchunks, false) / ntile;
+  int want = wgrad_target((long long)nchunks * ntile, ntile, nchunks, false, 4) / ntile;
   int maxs = (nchunks + g_wgrad_minchunks - 1) / g_wgrad_minchunks;
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
@@ -1232,7 +1253,7 @@ bool wgrad_live_plan(int B, int S, int k, int rate, int pad, int cin, int cout, 
   const int nchunks = (int)((M + 31) / 32);
   double work = 0;                                          // live chunk-tiles of the launch
   for (int c = 0; c < nv; ++c) work += (double)cnt[c] * nto * B * vals[c] / 32.0;
-  const int target = wgrad_target((long long)work, ntr * nto, nchunks, true);
+  const int target = wgrad_target((long long)work, ntr * nto, nchunks, true, (tr == 128 && to == 192) ? 3 : 4);
   const double len = work / target;                          // chunks per workgroup
   int maxs = (nchunks + g_wgrad_minchunks - 1) / g_wgrad_minchunks;
   if (maxs > cap) maxs = cap;
@@ -1325,6 +1346,8 @@ int drs_debug_wgrad_balance(int v) { const int old = g_wgrad_balance; if (v >= 0
 int drs_debug_wgrad_len(int v) { const int old = g_wgrad_len; if (v > 0) g_wgrad_len = v; return old; }
 
 int drs_debug_wgrad_minchunks(int v) { const int old = g_wgrad_minchunks; if (v > 0) g_wgrad_minchunks = v; return old; }
+
+int drs_debug_wgrad_model(int v) { const int old = g_wgrad_model; if (v >= 0) g_wgrad_model = v; return old; }
 
 int drs_debug_wgrad_target_big(int v) { const int old = g_wgrad_target_big; if (v >= 0) g_wgrad_target_big = v; return old; }
 

@@ -278,6 +278,9 @@ static SlideCfg slide_cfg(int B, int S, int C) {
   c.ncol = (S + c.TX - 1) / c.TX;
   c.nstrips = 1;
   while ((long long)B * c.ncol * c.nstrips < 2048 && S / (c.nstrips * 2) >= 8) c.nstrips *= 2;
+  // the per-rank batches of data parallelism (16 patches of 25 .. 85 pixels): few workgroups, each a chain of dependent row loads
+  // -- the launch is latency-bound, so shorter strips (down to 2-3 rows: 2 extra rows loaded per strip, out of L2) and more of them
+  while ((long long)B * c.ncol * c.nstrips < 768 && S / (c.nstrips * 2) >= 2) c.nstrips *= 2;
   c.rps = (S + c.nstrips - 1) / c.nstrips;
   return c;
 }
@@ -816,6 +819,198 @@ __global__ __launch_bounds__(256) void classifier_loss_kernel(const ClsArgs a) {
   }
 }
 
+// The same classifier block on the matrix cores (isprs:1024-1031 is a true dense contraction: [M x C] . [C x K]): three
+// products per tile of 16 pixels, all on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains), the class dimension padded to 16 / 8:
+//   logits^T [class][px] = W^T [class][c] . feat^T [c][px]            (k = channel;  C / 4 MFMAs)
+//   gfeat^T  [c][px]     = W [c][class]   . dlogits^T [class][px]     (k = class;    C / 8 MFMAs)
+//   dW^T     [class][c] += dlogits^T [class][px] . feat [px][c]       (k = pixel;    C / 4 MFMAs)
+// The orientations are chosen so that what one product leaves in a lane is what the next one wants there.  The rows of the first
+// product are the classes in the order 0, 4, 8, 12, 1, 5, ...: lane l then holds, for pixel l & 15, class (l >> 4) + 4 r in
+// accumulator register r -- the real classes (< 8) of a pixel sit in registers 0 and 1 of its four lanes, softmax / arg-max /
+// loss need the exchanges with lanes l ^ 16 and l ^ 32, and the logit gradients are already the B operand of the second
+// product (k slot l >> 4 <-> class (l >> 4) + 4 s at step s = 0, 1).  Only the third product needs them transposed: through a
+// 1-KiB LDS tile per wave.  The features are read twice, in the lane arrangement each product wants -- 16 pixels x 64 B per
+// instruction for the first (k = channel on l >> 4), 4 pixels x 256 B for the third (k = pixel on l >> 4) -- the second time
+// out of L2.  One workgroup = 4 waves, each walking its own 16-pixel tiles of the workgroup's pixel range; the filter sits in
+// LDS in the two operand arrangements.  Sums over pixels (dW, db, the loss) stay per workgroup and are added in wave order.
+template <int CQ, bool TRAIN>
+__global__ __launch_bounds__(256) void classifier_mfma_kernel(const ClsArgs a) {
+  constexpr int C = CQ * 64, NJ = C / 16, KP = 16;
+  __shared__ __attribute__((aligned(16))) float W1[C * KP];      // [c / 16][(c % 16) / 4][row i <-> class (i >> 2) + 4 (i & 3)][c % 4]: A operand of the first product
+  __shared__ __attribute__((aligned(16))) float W2[C * 8];       // [c][2 G + s <-> class G + 4 s]: A operand of the second
+  __shared__ __attribute__((aligned(16))) float DL[4][16 * KP];  // per wave: logit gradients [px][class] of the current tile (classes 8 .. 15 stay zero)
+  __shared__ float redb[4][8];
+  __shared__ double redl[4];
+  __shared__ unsigned int confs[64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int p = lane & 15, G = lane >> 4;
+  const int K = a.K;
+  for (int i = t; i < C * KP; i += 256) {
+    const int c = i >> 4, row = i & 15;
+    const int cls = (row >> 2) + 4 * (row & 3);
+    W1[(((c >> 4) * 4 + ((c & 15) >> 2)) * KP + row) * 4 + (c & 3)] = cls < K ? a.w[(size_t)c * K + cls] : 0.f;
+  }
+  for (int i = t; i < C * 8; i += 256) {
+    const int c = i >> 3, slot = i & 7;
+    const int cls = (slot >> 1) + 4 * (slot & 1);
+    W2[i] = cls < K ? a.w[(size_t)c * K + cls] : 0.f;
+  }
+  for (int i = t; i < 4 * 16 * KP; i += 256) (&DL[0][0])[i] = 0.f;
+  if (t < 64) confs[t] = 0u;
+  const int cls0 = G, cls1 = G + 4;                 // this lane's two real class slots
+  const float bk0 = cls0 < K ? a.bias[cls0] : 0.f, bk1 = cls1 < K ? a.bias[cls1] : 0.f;
+  __syncthreads();
+
+  f32x4 dw[CQ][4];
+#pragma unroll
+  for (int q = 0; q < CQ; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dw[q][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float db0 = 0.f, db1 = 0.f;
+  double lsum = 0.0;
+
+  const int p0 = blockIdx.x * a.rows_per_block;
+  int pend = p0 + a.rows_per_block;
+  pend = pend < a.M ? pend : a.M;
+  const float* fb = a.feat.base + a.feat.coff;
+  for (int tb = p0 + 16 * wave; tb < pend; tb += 64) {
+    const int pix = tb + p;
+    const bool valid = pix < pend;
+    const int pixc = valid ? pix : pend - 1;
+    const uint32_t off1 = padded_pixel_off(pixc, a.feat.S, a.feat.P, a.feat.ld, a.rcpS, a.rcpSS, 0, 0);
+    // ---- logits: k = channel 16 jj + 4 G + e
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int JC = NJ < 8 ? NJ : 8;          // feature loads in flight per lane (NJ is a multiple of 4)
+#pragma unroll
+    for (int j0 = 0; j0 < NJ; j0 += JC) {
+      f32x4 fr[JC];
+#pragma unroll
+      for (int j = 0; j < JC; ++j)
+        if (j0 + j < NJ) fr[j] = *reinterpret_cast<const f32x4*>(fb + off1 + 16 * (j0 + j) + 4 * G);
+#pragma unroll
+      for (int j = 0; j < JC; ++j) {
+        if (j0 + j >= NJ) continue;
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(&W1[(((j0 + j) * 4 + G) * KP + p) * 4]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e], fr[j][e], acc, 0, 0, 0);
+      }
+    }
+    // this lane: pixel p, classes G (register 0) and G + 4 (register 1); registers 2, 3 are padding
+    const float lg0 = acc[0] + bk0, lg1 = acc[1] + bk1;
+    float mv = -INFINITY;
+    int mc = 0;
+    if (cls0 < K) { mv = lg0; mc = cls0; }
+    if (cls1 < K && lg1 > mv) { mv = lg1; mc = cls1; }
+    // maximum and its FIRST class over the four lanes of the pixel: the larger value, the lower class on a tie
+#pragma unroll
+    for (int d = 16; d <= 32; d <<= 1) {
+      const float ov = __shfl_xor(mv, d);
+      const int oc = __shfl_xor(mc, d);
+      if (ov > mv || (ov == mv && oc < mc)) { mv = ov; mc = oc; }
+    }
+    const float mx = mv;
+    const int am = mc;
+    if (valid) {
+      if (a.logits) {
+        if (cls0 < K) a.logits[(size_t)pix * K + cls0] = lg0;
+        if (cls1 < K) a.logits[(size_t)pix * K + cls1] = lg1;
+      }
+      if (a.pred && G == 0) a.pred[pix] = (unsigned char)am;
+    }
+    if (!TRAIN) continue;
+    const int y = a.labels[pixc];
+    if (G == 0 && valid && a.conf && (!a.acc_mask || a.acc_mask[pix]) && y < K) atomicAdd(&confs[y * 8 + am], 1u);
+    const bool in_loss = valid && (!a.loss_mask || a.loss_mask[pixc]) && y < K;     // a label outside [0, K) never trains the net
+    const float ex0 = cls0 < K ? __expf(lg0 - mx) : 0.f, ex1 = cls1 < K ? __expf(lg1 - mx) : 0.f;
+    float se = ex0 + ex1;
+    se += __shfl_xor(se, 16);                       // (a + b == b + a bit for bit: every lane of the pixel gets the same sum)
+    se += __shfl_xor(se, 32);
+    const float inv = 1.0f / se;
+    const float dl0 = (in_loss && cls0 < K) ? (ex0 * inv - (cls0 == y ? 1.f : 0.f)) * a.inv_n : 0.f;
+    const float dl1 = (in_loss && cls1 < K) ? (ex1 * inv - (cls1 == y ? 1.f : 0.f)) * a.inv_n : 0.f;
+    if (in_loss && cls0 == y) lsum += (double)(__logf(se) + mx - lg0);
+    if (in_loss && cls1 == y) lsum += (double)(__logf(se) + mx - lg1);
+    db0 += dl0;
+    db1 += dl1;
+    if (!a.gfeat) continue;
+    // ---- gradient wrt the features: k slot G <-> class G + 4 s (the lane's own registers), rows = 16 channels per product
+    float* gdst = a.gfeat + (size_t)pixc * a.ld_g + a.coff_g + 4 * G;
+#pragma unroll
+    for (int tt = 0; tt < NJ; ++tt) {
+      const float2 wv = *reinterpret_cast<const float2*>(&W2[(16 * tt + p) * 8 + 2 * G]);
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+      g = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, dl0, g, 0, 0, 0);
+      g = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, dl1, g, 0, 0, 0);
+      if (valid) *reinterpret_cast<f32x4*>(gdst + 16 * tt) = g;
+    }
+    // ---- filter gradient: k = pixel; the logit gradients transposed through this wave's LDS tile
+    DL[wave][p * KP + cls0] = dl0;
+    DL[wave][p * KP + cls1] = dl1;
+    __builtin_amdgcn_wave_barrier();
+    float aop[4];
+    uint32_t off2[4];
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      aop[t4] = DL[wave][(4 * t4 + G) * KP + p];          // class p of pixel 4 t4 + G
+      off2[t4] = __shfl(off1, 4 * t4 + G);                // that pixel's (clamped) feature row
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+      f32x4 fv[CQ];
+#pragma unroll
+      for (int q = 0; q < CQ; ++q) fv[q] = *reinterpret_cast<const f32x4*>(fb + off2[t4] + 64 * q + 4 * p);
+#pragma unroll
+      for (int q = 0; q < CQ; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dw[q][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[t4], fv[q][e], dw[q][e], 0, 0, 0);
+    }
+  }
+  if (!TRAIN) return;
+  // ---- workgroup sums in wave order, one slab row per workgroup.  dw[q][e][r] = dW[c = 64 q + 4 p + e][class 4 G + r]
+  __syncthreads();                       // every wave is done with W1: it becomes the [C][8] accumulator
+  float* red = W1;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w && G < 2) {
+#pragma unroll
+      for (int q = 0; q < CQ; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int idx = (64 * q + 4 * p + e) * 8 + 4 * G + r;
+            red[idx] = (w ? red[idx] : 0.f) + dw[q][e][r];
+          }
+    }
+    __syncthreads();
+  }
+  // db: over the 16 pixels of a lane row (fixed butterfly), then over the waves
+  {
+    float v0 = db0, v1 = db1;
+    for (int d = 1; d < 16; d <<= 1) { v0 += __shfl_xor(v0, d); v1 += __shfl_xor(v1, d); }
+    if (p == 0) { redb[wave][cls0] = v0; redb[wave][cls1] = v1; }
+  }
+  {
+    double v = lsum;
+    for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+    if (lane == 0) redl[wave] = v;
+  }
+  __syncthreads();
+  if (a.dw_partial) {
+    for (int e = t; e < C * K; e += 256) {
+      const int c = e / K, k = e - c * K;
+      a.dw_partial[(size_t)blockIdx.x * C * K + e] = red[c * 8 + k];
+    }
+    if (t < K) a.db_partial[(size_t)blockIdx.x * K + t] = ((redb[0][t] + redb[1][t]) + redb[2][t]) + redb[3][t];
+  }
+  if (t == 0) a.loss_partial[blockIdx.x] = ((redl[0] + redl[1]) + redl[2]) + redl[3];
+  if (a.conf && t < K * K) {
+    const int r = t / K, c = t - r * K;
+    const unsigned v = confs[r * 8 + c];
+    if (v) atomicAdd(&a.conf[t], v);
+  }
+}
+
 __global__ void sum_f64_kernel(const double* __restrict__ in, int n, double* __restrict__ out) {
   __shared__ double sh[256];
   double s = 0.0;
@@ -1037,7 +1232,19 @@ int drs_bn_backward_apply_terms(const float* gxhat, const float* z, int B, int S
   return bn_backward_apply_impl(gxhat, z, B, S, C, mean_rstd, sums, count, gz, P_out, ld_out, coff_out, terms, nterms, stream);
 }
 
-int drs_classifier_rows(int B, int S) { return (B * S * S + 255) / 256; }
+// slab rows = workgroups of a classifier launch: 64 .. pixels per workgroup, at most 1024 workgroups (monotone in B * S * S: a
+// slab sized for (b_max, s_max) serves every smaller call)
+int drs_classifier_rows(int B, int S) {
+  const long long M = (long long)B * S * S;
+  const long long n = (M + 63) / 64;
+  return (int)(n < 1 ? 1 : (n > 1024 ? 1024 : n));
+}
+
+int g_cls_variant = 1;       // development switch (drs_debug_cls_variant): 1 = by the class count (below), 2 = MFMA form always, 0 = vector-ALU form always
+
+#ifdef DRS_DEV
+int drs_debug_cls_variant(int v) { const int old = g_cls_variant; if (v >= 0) g_cls_variant = v; return old; }
+#endif
 
 int drs_classifier_loss(const float* feat, int B, int S, int P, int ld, int coff, int C, int K, const float* w,
                         const float* bias, const unsigned char* labels, const unsigned char* loss_mask,
@@ -1049,14 +1256,28 @@ int drs_classifier_loss(const float* feat, int B, int S, int P, int ld, int coff
   if (M <= 0 || M >= (1 << 24)) return DRS_ERR_ARG;
   if (labels && !loss_partial) return DRS_ERR_ARG;
   if (gfeat && (!dw_partial || !db_partial || !labels)) return DRS_ERR_ARG;
+  if (ld % 4 || coff % 4 || (gfeat && (ld_g % 4 || coff_g % 4))) return DRS_ERR_ARG;       // 16-byte feature / gradient accesses
   ClsArgs a;
   a.feat = mkview(const_cast<float*>(feat), S, P, ld, coff); a.C = C; a.K = K; a.M = (int)M; a.w = w; a.bias = bias;
   a.labels = labels; a.loss_mask = loss_mask; a.acc_mask = acc_mask; a.inv_n = inv_n; a.logits = logits; a.pred = pred;
   a.gfeat = gfeat; a.ld_g = ld_g; a.coff_g = coff_g; a.dw_partial = dw_partial; a.db_partial = db_partial;
-  a.loss_partial = loss_partial; a.conf = conf; a.rows_per_block = 256;
+  a.loss_partial = loss_partial; a.conf = conf;
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
   const int nblk = drs_classifier_rows(B, S);
+  a.rows_per_block = (int)(((M + nblk - 1) / nblk + 63) / 64 * 64);      // whole 16-pixel tiles per wave; trailing workgroups may be empty
   hipStream_t st = (hipStream_t)stream;
+  // the MFMA form pads the class dimension to 16 / 8, the vector-ALU form multiplies exactly K classes: in-process A/B
+  // (tools/bench_classifier.py, profiles/r03/bench_classifier.log) K = 6, C = 256: MFMA 0.31 against 0.40 ms training and 0.11
+  // against 0.19 ms inference at B = 128; K = 2, C = 448: vector-ALU 0.24 against 0.47 ms.  So: MFMA from four classes up.
+  const bool mfma = g_cls_variant == 1 ? K >= 4 : g_cls_variant == 2;
+  if (mfma) {
+#define DRS_CLS_M(cq) do { if (labels) DRS_LAUNCH((classifier_mfma_kernel<cq, true>), dim3(nblk), dim3(256), 0, st, a); \
+                           else DRS_LAUNCH((classifier_mfma_kernel<cq, false>), dim3(nblk), dim3(256), 0, st, a); } while (0)
+    switch (C / 64) { case 1: DRS_CLS_M(1); break; case 2: DRS_CLS_M(2); break; case 3: DRS_CLS_M(3); break; case 4: DRS_CLS_M(4); break;
+                      case 5: DRS_CLS_M(5); break; case 6: DRS_CLS_M(6); break; default: DRS_CLS_M(7); break; }
+#undef DRS_CLS_M
+    return DRS_LAUNCH_CHECK();
+  }
 #define DRS_CLS_CASE(ci, km) DRS_LAUNCH((classifier_loss_kernel<ci, km>), dim3(nblk), dim3(256), 0, st, a)
 #define DRS_CLS_KM(km) switch (C / 64) { case 1: DRS_CLS_CASE(1, km); break; case 2: DRS_CLS_CASE(2, km); break; case 3: DRS_CLS_CASE(3, km); break; \
     case 4: DRS_CLS_CASE(4, km); break; case 5: DRS_CLS_CASE(5, km); break; case 6: DRS_CLS_CASE(6, km); break; default: DRS_CLS_CASE(7, km); break; }

@@ -302,7 +302,8 @@ def test_bn_eval_coeffs(lib):
 
 
 @pytest.mark.parametrize("C,K,B,S,P,masked", [(256, 6, 2, 9, 0, False), (448, 2, 1, 12, 6, False), (256, 7, 2, 8, 0, True),
-                                             (64, 6, 1, 31, 1, False)])
+                                             (64, 6, 1, 31, 1, False), (448, 6, 2, 13, 6, True), (128, 4, 3, 10, 0, False), (128, 3, 1, 17, 2, False),
+                                             (256, 8, 5, 21, 0, True), (192, 5, 1, 40, 1, False)])
 def test_classifier_loss(lib, C, K, B, S, P, masked):
     rng = np.random.default_rng(C + K)
     M = B * S * S

@@ -92,9 +92,9 @@ def test_cut_is_a_partition_and_balanced(B, S):
         lens = np.asarray(lens)
         # workgroup lengths in live chunks: equal up to the rounding of n per class and the chunks that straddle a boundary
         if len(set(int(x) for x in nt[:ntr])) > 1 or S % 32 == 0:
-            spread = (lens.max() - lens.min()) / max(1.0, lens.mean())
-            assert spread <= 0.2 or lens.max() - lens.min() <= 3, (B, S, k, rate, cin, cout, lens.min(), lens.mean(), lens.max())
-
+            # what delays a launch is its LONGEST workgroup (a tile's last split may be short: the remainder of its live pixels)
+            over = (lens.max() - lens.mean()) / max(1.0, lens.mean())
+            assert over <= 0.2 or lens.max() - lens.mean() <= 3, (B, S, k, rate, cin, cout, lens.min(), lens.mean(), lens.max())
 
 def test_equal_cut_still_available():
     lib = _lib.dev()
@@ -130,3 +130,22 @@ def test_split_path_slab_bound_is_monotone_in_batch_and_size():
                     for b in (1, b_max // 2, b_max):
                         for s in range(1, s_max + 1):
                             assert _lib.query("drs_conv_wgrad_split_splits", b, s, L.k, L.cin_k, L.cout, L.halo, ns) <= alloc, (net_type, L.name, b, s)
+
+
+def test_slab_sized_at_the_largest_step_serves_every_smaller_one():
+    """The step engine sizes the filter-gradient slab once, at (b_max, s_max) (engine.hip list_buffers), while the patch side changes
+    every step (isprs:1727-1737) and the last batch of a validation pass is short: no (b <= b_max, s <= s_max) may cut a row tile
+    into more splits than drs_conv_wgrad_splits(b_max, s_max) allows for.  (The exact count is not monotone in S.)"""
+    from drs_amd.nets import Plan
+    lib = _lib.dev()
+    for net_type, ch, K in (("dilated_grsl_rate8", 5, 6), ("dilated_icpr_rate6_densely", 4, 2), ("dilated_grsl", 5, 6), ("dilated_icpr_original", 3, 6)):
+        plan = Plan(net_type, ch, K, first_cin_pad=8)
+        for b_max, s_max in ((16, 85), (32, 100), (128, 64), (64, 65), (4, 25)):
+            for L in plan.layers:
+                alloc = _lib.query("drs_conv_wgrad_splits", b_max, s_max, L.k, L.cin_k, L.cout)
+                nt = np.zeros(256, dtype=np.int32)
+                for b in sorted(v for v in {1, 2, 3, 5, 8, 13, b_max // 2, b_max - 1, b_max} if 1 <= v <= b_max):
+                    for s in range(1, s_max + 1):
+                        n = lib.drs_debug_wgrad_cut(b, s, L.k, L.rate, L.pad_b, L.cin_k, L.cout, None, 0, nt.ctypes.data, None)
+                        assert n > 0 and int(nt.max()) <= alloc, (net_type, L.name, b, s, int(nt.max()), alloc, b_max, s_max)
+                        nt[:] = 0

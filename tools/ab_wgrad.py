@@ -3,7 +3,7 @@
 one device, best-of per arm.  An arm is a string of development-switch settings: b<0|1> cut by live pixels off / on
 (drs_debug_wgrad_balance), t<N> workgroup target (drs_debug_wgrad_target), g<N> target of the many-tiles-and-pixels launches under
 the live cut (drs_debug_wgrad_target_big), v<0|1> kernel form (drs_debug_wgrad_variant; default per tile), l<N> chunks per workgroup that small launches aim at,
-m<N> fewest chunks a split may have (drs_debug_wgrad_minchunks).
+m<N> fewest chunks a split may have (drs_debug_wgrad_minchunks), o<0|1> workgroup count by the r02 table / the per-CU cost model.
     python tools/ab_wgrad.py [B=128] [S=64] [arms=b0,b1,b1g2048] [layers=1,2,...] [rounds=4]"""
 import os, re, sys
 import torch
@@ -15,13 +15,14 @@ DEV = "cuda:0"
 
 
 def apply(lib, arm):
-    kv = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"([btgvlm])(\d+)", arm))
+    kv = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"([btgvlmo])(\d+)", arm))
     lib.drs_debug_wgrad_balance(kv.get("b", 1))
     lib.drs_debug_wgrad_target(kv.get("t", 2048))
     lib.drs_debug_wgrad_target_big(kv.get("g", 0))
     lib.drs_debug_wgrad_variant(kv.get("v", -1))
     lib.drs_debug_wgrad_len(kv.get("l", 96))
-    lib.drs_debug_wgrad_minchunks(kv.get("m", 32))
+    lib.drs_debug_wgrad_minchunks(kv.get("m", 8))
+    lib.drs_debug_wgrad_model(kv.get("o", 1))
 
 
 def main(B=128, S=64, arms="b0,b1", rounds=4, layers=""):
