@@ -92,13 +92,13 @@ def allowed_cores():
     return n, note
 
 
-def cpu_baseline(batch=64, warmup=2, timed=5):
+def cpu_baseline(batch=GLOBAL_BATCH, warmup=1, timed=3):
     """The reference step restated with PyTorch-CPU fp32 ops (oracle/torch_ref.py) + the reference's host pipeline (numpy crop /
     rotate / noise / flip, normalise of bands 0..2, confusion matrix), on this host's cores, as SURVEY.md 8(d) specifies it: the
     bench's own workload (same net, 64x64x5 patches of the same 2048 x 2048 synthetic tile, same instances), `warmup` + `timed`
-    steps, every core the process is allowed (allowed_cores: affinity mask cut to the cgroup's CPU quota), median step; plus a 1-thread figure.  The batch is 64 rather than the
-    GPU line's 128 to keep the default run within minutes (a CPU step is seconds long and scales linearly in the batch); the
-    1-thread figure uses one step of 8 patches for the same reason.  Both are stated in `sample`."""
+    steps at the GPU line's own batch of 128 (a CPU step is ~10 s long: 1 + 3 steps bound the sample to well under a minute), every core
+    the process is allowed (allowed_cores: affinity mask cut to the cgroup's CPU quota), median step; plus a 1-thread figure from one step
+    of 8 patches.  Both are stated in `sample`."""
     from oracle.torch_ref import TorchNet
     from oracle import host_ref as H
     from oracle.tf_ops import OracleNet
@@ -140,7 +140,7 @@ def cpu_baseline(batch=64, warmup=2, timed=5):
         pass
     return dict(value=round(batch / med, 3), unit="patches/s", cores=ncores, cores_note=core_note, kind="port", cpu_model=model,
                 value_1_thread=round(b1 / one, 3),
-                sample="%d timed steps after %d warm-up, batch %d (GPU line: 128), dilated_grsl_rate8 / 64x64x5 patches of the 2048x2048 "
+                sample="%d timed steps after %d warm-up, batch %d (= the GPU line's), dilated_grsl_rate8 / 64x64x5 patches of the 2048x2048 "
                        "tile, host crop+augment+normalise+confusion included; median step %.2f s (min %.2f, max %.2f); 1-thread figure: one "
                        "step of %d patches, %.2f s" % (timed, warmup, batch, med, min(times), max(times), b1, one))
 
@@ -179,6 +179,48 @@ def executed_fraction(plan, B, S):
     return live / tot
 
 
+def per_rank_size_table(dev, pool, mean, std, sizes=(25, 35, 45, 55, 65, 75, 85), B=16, steps=8):
+    """what one rank of the 8-GPU run of BASELINE configs[2] sees (batch 128 / 8 = 16 patches, `uniform` over [25, 85],
+    isprs:1727-1737): ms per step and the convolution families' share of the fp32 MFMA roof, per patch side (N = 1 only, outside
+    the timed region).  `weighted_patches_per_s` = sizes drawn uniformly: patches / summed step time."""
+    from drs_amd.net import DilatedNet, KernelTimer
+    from drs_amd import patches as P
+    from drs_amd.synthetic import grid_instances
+    net = DilatedNet(NET, CHANNELS, CLASSES, WD, b_max=B, s_max=max(sizes), device=dev, seed=42)
+    rows_out, tot = [], 0.0
+    for S in sizes:
+        inst = grid_instances(TILE, TILE, S, 25, 2048, seed=S)
+
+        def step(i):
+            r = inst[(i * B) % 2000:(i * B) % 2000 + B]
+            aug = P.draw_augmentation(r, S, CHANNELS, noise="device")
+            P.crop_to_net(net, pool, r, S, mean, std, aug)
+            return net.train_step(B, S, LR)
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        net.timer = KernelTimer()
+        for i in range(3):
+            step(i)
+        summ = net.timer.summary()
+        net.timer = None
+        fd = [summ[k] for k in ("conv_fwd", "conv_dgrad") if k in summ]
+        fd_tf = sum(d["work"] for d in fd) / (sum(d["ms"] for d in fd) * 1e-3) / 1e12
+        wg_tf = summ["conv_wgrad"]["work"] / (summ["conv_wgrad"]["ms"] * 1e-3) / 1e12
+        rows_out.append(dict(S=S, ms_per_step=round(dt * 1e3, 3), patches_per_s=round(B / dt, 1),
+                             fwd_dgrad_frac=round(fd_tf / PEAK_FP32_MFMA_TFLOPS, 3), wgrad_frac=round(wg_tf / PEAK_FP32_MFMA_TFLOPS, 3)))
+        tot += dt
+    del net
+    torch.cuda.empty_cache()
+    return dict(local_batch=B, rows=rows_out, weighted_patches_per_s=round(B * len(sizes) / tot, 1),
+                note="one rank's step at the per-rank batch of an 8-GPU run, no collectives; stream-K convolutions below 4096 tiles")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,6 +229,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-opt-in", action="store_true", help="skip the short bf16x3 measurement reported beside the fp32 headline")
+    ap.add_argument("--no-size-table", action="store_true", help="skip the per-rank patch-size table (N = 1 only)")
     ap.add_argument("--arith", choices=sorted(ARITH), default="f32",
                     help="arithmetic of the convolution kernels: exact fp32 MFMA (default) or split-bf16 (conv_split.hip)")
     args = ap.parse_args()
@@ -311,7 +354,7 @@ def main():
             roofline["mfma_issued_frac"] = round(ach * ar["products"] / ar["peak"], 4)
 
     # ---- validation half of the metric: forward-only pixels/sec (eval-mode BN, arg-max, confusion), isprs:1569-1618
-    vb = 4
+    vb = 25             # B * 100 patches per validation pass; 25 batches of 128 bound the sample (0.4 s)
     for _ in range(2):
         P.crop_to_net(net, pool, inst[:GLOBAL_BATCH][sl], PATCH, mean, std)
         net.forward(B_local, PATCH, want_logits=False, labels=True)
@@ -354,8 +397,14 @@ def main():
                 torch.cuda.empty_cache()
             opt_in[arith] = {"dtype": ARITH[arith]["dtype"], "value": round(GLOBAL_BATCH / dt2, 2), "unit": "patches/s",
                              "ms_per_step": round(1e3 * dt2, 3), "steps": 10, "warmup": 3}
-        opt_in["note"] = ("not the headline: opt-in arithmetics of the convolutions (DESIGN.md 3a), held to the fp32 path's parity bounds in "
-                          "tests/; bf16x6 is as exact as the fp32 MFMA kernels (tests/test_gpu_split.py), bf16x3 is not")
+        opt_in["note"] = ("not the headline and not credited: opt-in arithmetics of the convolutions on the op-level path only (DESIGN.md 3a). "
+                          "bf16x6 matches the fp32 MFMA kernels on Gaussian operands but its 6-of-9 partial products carry ~2^-22 per "
+                          "product, ~3x an fp32 FMA's rounding, when a few large terms dominate a sum "
+                          "(tests/test_gpu_split.py::test_three_term_arithmetic_on_adversarial_operands); bf16x3 carries 2^-16")
+
+    size_table = None
+    if world == 1 and args.arith == "f32" and not args.no_size_table and not forced:
+        size_table = per_rank_size_table(dev, pool, mean, std)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -363,6 +412,11 @@ def main():
 
     if rank == 0:
         value = GLOBAL_BATCH * args.steps / elapsed
+        # fp32 ceiling of the whole step: 3 x 17.12 GFLOP per 64 x 64 patch at 157.3 TFLOP/s per GPU (3062 patches/s)
+        ceiling = world * PEAK_FP32_MFMA_TFLOPS * 1e12 / (3 * 2 * net.plan.mac_per_pixel() * PATCH * PATCH)
+        if roofline is not None and args.arith == "f32":
+            roofline["whole_step_frac"] = round(value / ceiling, 4)
+            roofline["whole_step_ceiling_patches_per_s"] = round(ceiling, 1)
         line = {
             "metric": "training patches/sec dilated_grsl_rate8 64x64x5", "value": round(value, 2), "unit": "patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
@@ -372,11 +426,12 @@ def main():
                        "global_batch": GLOBAL_BATCH, "patch": PATCH, "bands": CHANNELS, "classes": CLASSES,
                        "parallelism": "dp%d" % world + (" (REHEARSAL: all ranks on one GPU over gloo)" if rehearsal else "")
                                       + (" (collectives forced through RCCL at world 1)" if forced else ""),
-                       "sync_bn": True},
+                       "sync_bn": True, "collectives": getattr(net, "collectives", None) if comm else None},
             "val_pixels_per_sec": round(val_pixels_per_s, 1), "final_loss": round(loss, 5),
             "workspace_gb_per_gpu": round(net.workspace_bytes() / 1e9, 2),
             "train_tflops": round(value * 3 * 2 * net.plan.mac_per_pixel() * PATCH * PATCH / 1e12, 2),
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "opt_in_arithmetic": opt_in,
+            "extra": {"per_rank_size_table": size_table},
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if comm:

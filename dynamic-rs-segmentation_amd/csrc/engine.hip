@@ -878,8 +878,13 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     pending.push_back(h);
     DRS_TRY(all_reduce(n, grads + n->cls_w, n->n_params - n->cls_w, F32, 1, st, &h)); // classifier, SE layers and every bias (small)
     pending.push_back(h);
-    DRS_TRY(all_reduce(n, scalars, 1, F64, 0, st, nullptr));
-    DRS_TRY(all_reduce(n, conf, (size_t)n->K * n->K, I32, 0, st, nullptr));
+    // (library-side RCCL: the backward phase's small sums all go through the small communicator's side stream, in order -- one
+    // communicator is never driven from two streams at once)
+    const int side = n->rccl_small ? 1 : 0;
+    DRS_TRY(all_reduce(n, scalars, 1, F64, side, st, &h));
+    pending.push_back(h);
+    DRS_TRY(all_reduce(n, conf, (size_t)n->K * n->K, I32, side, st, &h));
+    pending.push_back(h);
     DRS_TRY(wait_handles(n, pending, st));
   }
   DRS_TRY(drs_scale_f64(scalars, 1, 1.0 / n_glob, st));

@@ -222,5 +222,64 @@ def test_three_term_arithmetic_is_as_exact_as_the_fp32_mfma_kernels(lib, k, rate
     e6 = (_rms_err(out2.cpu().numpy().reshape(ref.shape), ref), _rms_err(gx2.cpu().numpy().reshape(gx_ref.shape), gx_ref) if cin % 64 == 0 else 0.0,
           _rms_err(gw2.cpu().numpy().reshape(gw_ref.shape), gw_ref))
     print("k%d r%d %3d->%3d  fp32 MFMA: fwd %.2e dgrad %.2e wgrad %.2e | bf16x6: fwd %.2e dgrad %.2e wgrad %.2e" % ((k, rate, cin, cout) + e32 + e6))
-    for a, b in zip(e6, e32):
-        assert a <= 1.10 * b + 1e-9, (e6, e32)
+    # forward / input gradient: within 10 %.  Filter gradient: the exact-fp32 kernel cuts the pixel dimension into more, shorter splits
+    # since r03 (workgroup count by a per-CU cost model, splits down to 8 chunks), i.e. shorter fp32 accumulation chains
+    # and a smaller error of its own (2.1e-7 against the split kernel's 2.7e-7 on conv2's shape at this size): within 50 %.
+    for a, b, lim in zip(e6, e32, (1.10, 1.10, 1.50)):
+        assert a <= lim * b + 1e-9, (e6, e32)
+
+
+ADVERSARIAL = ["gaussian", "large_channel_means", "wide_dynamic_range", "cancelling_pairs", "near_denormal"]
+
+
+@pytest.mark.parametrize("case", ADVERSARIAL)
+def test_three_term_arithmetic_on_adversarial_operands(lib, case):
+    """Where `bf16x6` stands against the exact-fp32 MFMA kernels OUTSIDE Gaussian operands -- the reason it stays an opt-in
+    arithmetic of the op-level path and earns no headline.  A product of 3-term operands keeps 6 of the 9 partial products: the
+    three dropped ones are ~2^-24 .. 2^-32 of the product each, so a product carries ~2^-22.5 relative error where an fp32 FMA
+    carries none (its only rounding is the accumulation's).  On sums of many comparable terms the accumulation rounding dominates
+    both arithmetics (Gaussian operands: ratio ~0.85-1); when a few large terms dominate a sum, or the operands sit on a large
+    common offset, the product error shows.  The forward product of conv8's shape, errors against the fp64 oracle relative to the
+    largest sum |a| |b|; asserted: the bound the path is held to everywhere (1e-5), and the measured ratio to fp32 per case
+    (profiles/r03/bf16x6_adversarial.log: RMS ratio 0.86 Gaussian / large means, 1.14 wide range (max 1.97), 2.36 cancelling pairs).
+    VERDICT r02 asked for <= 1.1 x the fp32 kernels' RMS and MAX on such operands before the arithmetic may carry the headline: it
+    does not meet that, by construction, so it is not promoted into the step engine."""
+    k, rate, cin, cout, B, S, ns = 3, 8, 256, 256, 2, 14, 3
+    rng = np.random.default_rng(17)
+    x = rng.normal(size=(B, S, S, cin))
+    w = rng.normal(size=(k, k, cin, cout)) / np.sqrt(k * k * cin)
+    if case == "large_channel_means":             # activations on a per-channel offset 10^3 x their spread (what forced the two-pass BN statistics)
+        x = x + 1000.0 * rng.normal(size=(1, 1, 1, cin))
+    elif case == "wide_dynamic_range":            # magnitudes spanning 2^-20 .. 2^20 inside every dot product
+        x = x * np.exp2(rng.uniform(-20, 20, size=x.shape))
+        w = w * np.exp2(rng.uniform(-20, 20, size=w.shape))
+    elif case == "cancelling_pairs":              # neighbouring channels carry +a, -a against the same filter value: the sum is rounding only
+        x[..., 1::2] = -x[..., 0::2]
+        w[:, :, 1::2, :] = w[:, :, 0::2, :]
+        x = x + 1e-3 * rng.normal(size=x.shape)   # (plus a small signal, so that the reference is not identically zero)
+    elif case == "near_denormal":                 # products around 2^-126: the low bf16 terms fall into the denormal range
+        x = x * 2.0 ** -100
+        w = w * 2.0 ** -20
+    x, w = x.astype(np.float32), w.astype(np.float32)
+    pb, pa = onets.same_pad(k, rate)
+    P = max(pb, pa)
+    M = B * S * S
+    xd, wd = padded(x, P), dev(w)
+    ref = T.conv2d_same(x.astype(np.float64), w.astype(np.float64), rate)
+    out = torch.zeros(M * cout, dtype=torch.float32, device=DEV)
+    lib.call("drs_conv_forward", xd.data_ptr(), B, S, P, cin, 0, wd.data_ptr(), None, k, rate, pb, cin, cout, out.data_ptr(), cout, 0, 0, None, stream())
+    xt, _ = planes(lib, xd, ns)
+    wf = torch.zeros(ns * w.size, dtype=torch.int16, device=DEV)
+    lib.call("drs_filter_split", wd.data_ptr(), k, cin, cin, cout, ns, wf.data_ptr(), None, stream())
+    out2 = torch.zeros(M * cout, dtype=torch.float32, device=DEV)
+    lib.call("drs_conv_forward_split", xt.data_ptr(), B, S, P, cin, 0, wf.data_ptr(), None, k, rate, pb, cin, cout, out2.data_ptr(), cout, 0, 0, None, ns, stream())
+    torch.cuda.synchronize()
+    scale = T.conv2d_same(np.abs(x).astype(np.float64), np.abs(w).astype(np.float64), rate).max()     # sum |a| |b|: the error scale of a dot product
+    a32, a6 = out.cpu().numpy().reshape(ref.shape).astype(np.float64), out2.cpu().numpy().reshape(ref.shape).astype(np.float64)
+    rms32, rms6 = np.sqrt(np.mean((a32 - ref) ** 2)) / scale, np.sqrt(np.mean((a6 - ref) ** 2)) / scale
+    max32, max6 = np.abs(a32 - ref).max() / scale, np.abs(a6 - ref).max() / scale
+    print("%-20s fp32 MFMA rms %.2e max %.2e | bf16x6 rms %.2e max %.2e | ratio rms %.2f max %.2f" % (case, rms32, max32, rms6, max6, rms6 / rms32, max6 / max32))
+    assert max32 < 1e-5 and max6 < 1e-5                     # the parity bound both arithmetics are held to
+    LIMIT = {"gaussian": (1.1, 1.1), "large_channel_means": (1.1, 1.1), "wide_dynamic_range": (1.5, 3.0), "cancelling_pairs": (3.5, 3.5),
+             "near_denormal": (1.1, 1.1)}
+    assert rms6 <= LIMIT[case][0] * rms32 + 1e-12 and max6 <= LIMIT[case][1] * max32 + 1e-12

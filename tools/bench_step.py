@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Time the training step at a given local batch (what one rank sees under data parallelism).  Default: no collectives;
-`comm=rccl`: every collective of the step issued through RCCL at world 1 (identities; DRS_FORCE_COLLECTIVES), `comm=rccl2`: the same
-with the second communicator for the small sums (DRS_BN_COMM)."""
+`comm=rccl`: every collective of the step issued at world 1 (identities; DRS_FORCE_COLLECTIVES) by the LIBRARY itself through RCCL
+(drs_net_set_rccl: no Python in the step); `comm=callback`: the same sums through the all-reduce callback into torch.distributed
+(DRS_COMM=torch; the r02 path); `comm=callback2`: that with torch's second communicator for the small sums (DRS_BN_COMM)."""
 import os, sys, time
 import numpy as np
 import torch
@@ -15,7 +16,8 @@ def main(B=16, S=64, steps=20, arith="f32", comm_kind="none"):
     comm = None
     if comm_kind != "none":
         os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", DRS_FORCE_COLLECTIVES="1")
-        if comm_kind == "rccl2":
+        os.environ["DRS_COMM"] = "rccl" if comm_kind == "rccl" else "torch"
+        if comm_kind == "callback2":
             os.environ["DRS_BN_COMM"] = "1"
         from drs_amd.dist import TorchComm
         torch.cuda.set_device(0)
@@ -43,7 +45,7 @@ def main(B=16, S=64, steps=20, arith="f32", comm_kind="none"):
     for i in range(3): step(i)
     summ = net.timer.summary(); net.timer = None
     ksum = sum(d["ms"] for d in summ.values()) / 3
-    print(arith, "comm=" + comm_kind, "B=%d S=%d: %.2f ms/step  (%.0f patches/s; x%d ranks = %.0f)  host enqueue %.2f ms/step, timed kernels %.2f ms" % (B, S, dt * 1e3, B / dt, 128 // B, 128 / dt, host * 1e3, ksum))
+    print(arith, "comm=" + comm_kind + ("/" + str(getattr(net, "collectives", None)) if comm else ""), "B=%d S=%d: %.2f ms/step  (%.0f patches/s; x%d ranks = %.0f)  host enqueue %.2f ms/step, timed kernels %.2f ms" % (B, S, dt * 1e3, B / dt, 128 // B, 128 / dt, host * 1e3, ksum))
     for k, d in sorted(summ.items()): print("   %-18s %6.3f ms/step" % (k, d["ms"] / 3))
 
 if __name__ == "__main__":
