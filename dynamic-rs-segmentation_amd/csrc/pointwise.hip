@@ -644,6 +644,7 @@ struct ClsArgs {
   double* loss_partial;      // [nblk]
   unsigned int* conf;        // [K][K] counts (integer atomics) or null
   int rows_per_block;
+  int dma_span, nrows;       // classifier_dma_kernel: slab rows' worth of pixels per workgroup; slab rows in all
   float rcpS, rcpSS;
 };
 
@@ -879,7 +880,9 @@ __global__ __launch_bounds__(256) void classifier_mfma_kernel(const ClsArgs a) {
     const int pixc = valid ? pix : pend - 1;
     const uint32_t off1 = padded_pixel_off(pixc, a.feat.S, a.feat.P, a.feat.ld, a.rcpS, a.rcpSS, 0, 0);
     // ---- logits: k = channel 16 jj + 4 G + e
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // (two accumulation chains, even / odd 16-channel groups: a single chain of this MFMA is paced by its 40-cycle dependent
+    // latency, not its 32-cycle issue rate)
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
     constexpr int JC = NJ < 8 ? NJ : 8;          // feature loads in flight per lane (NJ is a multiple of 4)
 #pragma unroll
     for (int j0 = 0; j0 < NJ; j0 += JC) {
@@ -892,9 +895,14 @@ __global__ __launch_bounds__(256) void classifier_mfma_kernel(const ClsArgs a) {
         if (j0 + j >= NJ) continue;
         const f32x4 wv = *reinterpret_cast<const f32x4*>(&W1[(((j0 + j) * 4 + G) * KP + p) * 4]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e], fr[j][e], acc, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) {
+          if ((j0 + j) & 1) acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e], fr[j][e], acc_b, 0, 0, 0);
+          else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e], fr[j][e], acc, 0, 0, 0);
+        }
       }
     }
+    acc[0] += acc_b[0];
+    acc[1] += acc_b[1];
     // this lane: pixel p, classes G (register 0) and G + 4 (register 1); registers 2, 3 are padding
     const float lg0 = acc[0] + bk0, lg1 = acc[1] + bk1;
     float mv = -INFINITY;
@@ -1009,6 +1017,234 @@ __global__ __launch_bounds__(256) void classifier_mfma_kernel(const ClsArgs a) {
     const unsigned v = confs[r * 8 + c];
     if (v) atomicAdd(&a.conf[t], v);
   }
+}
+
+// The MFMA classifier with its features brought in ONCE, by LDS-DMA, one tile ahead: a wave owns two 16-pixel feature tiles in LDS
+// (16 x C floats each), the DMA of tile i+1 (global_load_lds_dwordx4, no registers) lands while tile i is multiplied, and both
+// feature operands -- k = channel for the logits, k = pixel for the filter gradient -- are ds_read_b128 fragments of that one
+// image (16-byte piece c of pixel p sits in slot c ^ (p & 15), realised on the SOURCE address: both read patterns are
+// conflict-free).  One workgroup of 4 waves per CU (C = 256: 128 KiB of tiles + 28 KiB of filter images); the latency that
+// classifier_mfma_kernel pays per tile at two waves per SIMD (HBM round trip, then four L2 round trips for the second read) is
+// hidden behind a whole tile of arithmetic.  Every vector-memory operation inside the loop is counted by hand: the label / mask
+// bytes are inline-asm loads waited for with vmcnt(#DMA instructions), the DMA itself with vmcnt(#feature-gradient stores).
+// Products, orientations, class permutation and every sum are those of classifier_mfma_kernel: results are bitwise the same.
+template <int CQ, bool TRAIN>
+__global__ __launch_bounds__(256, 1) void classifier_dma_kernel(const ClsArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int C = CQ * 64, NJ = C / 16, KP = 16, NI = 4 * CQ;      // NI: 1-KiB DMA instructions per tile
+  __shared__ __attribute__((aligned(1024))) float FT[4][2][16 * C];
+  __shared__ __attribute__((aligned(16))) float W1[C * KP];
+  __shared__ __attribute__((aligned(16))) float W2[C * 8];
+  __shared__ __attribute__((aligned(16))) float DL[4][16 * KP];
+  __shared__ float redb[4][8];
+  __shared__ double redl[4];
+  __shared__ unsigned int confs[64];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int p = lane & 15, G = lane >> 4;
+  const int K = a.K;
+  for (int i = t; i < C * KP; i += 256) {
+    const int c = i >> 4, row = i & 15;
+    const int cls = (row >> 2) + 4 * (row & 3);
+    W1[(((c >> 4) * 4 + ((c & 15) >> 2)) * KP + row) * 4 + (c & 3)] = cls < K ? a.w[(size_t)c * K + cls] : 0.f;
+  }
+  for (int i = t; i < C * 8; i += 256) {
+    const int c = i >> 3, slot = i & 7;
+    const int cls = (slot >> 1) + 4 * (slot & 1);
+    W2[i] = cls < K ? a.w[(size_t)c * K + cls] : 0.f;
+  }
+  for (int i = t; i < 4 * 16 * KP; i += 256) (&DL[0][0])[i] = 0.f;
+  if (t < 64) confs[t] = 0u;
+  const int cls0 = G, cls1 = G + 4;
+  const float bk0 = cls0 < K ? a.bias[cls0] : 0.f, bk1 = cls1 < K ? a.bias[cls1] : 0.f;
+  __syncthreads();
+
+  f32x4 dw[CQ][4];
+#pragma unroll
+  for (int q = 0; q < CQ; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dw[q][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float db0 = 0.f, db1 = 0.f;
+  double lsum = 0.0;
+
+  // this form wants long pixel ranges (one workgroup per CU, a DMA pipeline to fill): the launch has at most 256 workgroups, each
+  // covering the pixels of a.dma_span slab rows; it writes its sums to row blockIdx.x and zeroes the rows nobody writes
+  const int p0 = blockIdx.x * a.rows_per_block * a.dma_span;
+  int pend = p0 + a.rows_per_block * a.dma_span;
+  pend = pend < a.M ? pend : a.M;
+  const float* fb = a.feat.base + a.feat.coff;
+  const unsigned char* lm = a.loss_mask ? a.loss_mask : a.labels;      // (absent masks: any readable bytes keep the load count fixed)
+  const unsigned char* am_ = a.acc_mask ? a.acc_mask : a.labels;
+  // DMA of the tile that starts at pixel `tb` into buffer `buf`: instruction i moves bytes [1024 i, 1024 (i + 1)) of the image
+  auto dma = [&](int tb, int buf) {
+    int px = tb + p;
+    px = px < pend ? px : pend - 1;
+    const uint32_t off = padded_pixel_off(px, a.feat.S, a.feat.P, a.feat.ld, a.rcpS, a.rcpSS, 0, 0);
+    float* dst = &FT[wave][buf][0];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int X = 1024 * i + 16 * lane;                 // byte of the image this lane fills
+      const int pixel = X / (4 * C), slot = (X % (4 * C)) / 16;
+      const uint32_t po = (C == 256) ? (uint32_t)__builtin_amdgcn_readlane((int)off, i)      // one pixel per instruction: scalar
+                                     : (uint32_t)__shfl(off, pixel);                       // that pixel's feature row (lane `pixel` computed it)
+      __builtin_amdgcn_global_load_lds(fb + po + 4 * (slot ^ pixel), (lds_ptr)(dst + 256 * i), 16, 0, 0);
+    }
+  };
+  int tb = p0 + 16 * wave;
+  int cur = 0;
+  if (tb < pend) dma(tb, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (; tb < pend; tb += 64, cur ^= 1) {
+    const int pix = tb + p;
+    const bool valid = pix < pend;
+    const int pixc = valid ? pix : pend - 1;
+    __builtin_amdgcn_wave_barrier();
+    // label / mask bytes of this tile: hidden from the compiler's wait bookkeeping (it would drain the DMA below at their first use)
+    unsigned ylab = 0, vlm = 1, vam = 1;
+    if (TRAIN) {
+      asm volatile("global_load_ubyte %0, %1, off" : "=v"(ylab) : "v"(a.labels + pixc) : "memory");
+      asm volatile("global_load_ubyte %0, %1, off" : "=v"(vlm) : "v"(lm + pixc) : "memory");
+      asm volatile("global_load_ubyte %0, %1, off" : "=v"(vam) : "v"(am_ + pixc) : "memory");
+    }
+    if (tb + 64 < pend) dma(tb + 64, cur ^ 1);           // the next tile lands while this one is multiplied
+    const float* F = &FT[wave][cur][0];
+    // ---- logits: k = channel 16 jj + 4 G + e
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};          // two chains, as in classifier_mfma_kernel
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      const f32x4 fr = *reinterpret_cast<const f32x4*>(&F[p * C + 4 * ((4 * jj + G) ^ p)]);
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(&W1[((jj * 4 + G) * KP + p) * 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (jj & 1) acc_b = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e], fr[e], acc_b, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[e], fr[e], acc, 0, 0, 0);
+      }
+    }
+    acc[0] += acc_b[0];
+    acc[1] += acc_b[1];
+    const float lg0 = acc[0] + bk0, lg1 = acc[1] + bk1;
+    float mv = -INFINITY;
+    int mc = 0;
+    if (cls0 < K) { mv = lg0; mc = cls0; }
+    if (cls1 < K && lg1 > mv) { mv = lg1; mc = cls1; }
+#pragma unroll
+    for (int d = 16; d <= 32; d <<= 1) {
+      const float ov = __shfl_xor(mv, d);
+      const int oc = __shfl_xor(mc, d);
+      if (ov > mv || (ov == mv && oc < mc)) { mv = ov; mc = oc; }
+    }
+    const float mx = mv;
+    const int am = mc;
+    if (valid) {
+      if (a.logits) {
+        if (cls0 < K) a.logits[(size_t)pix * K + cls0] = lg0;
+        if (cls1 < K) a.logits[(size_t)pix * K + cls1] = lg1;
+      }
+      if (a.pred && G == 0) a.pred[pix] = (unsigned char)am;
+    }
+    if (TRAIN) {
+      // the three byte loads are older than the NI DMA instructions (or nothing, on the last tile) issued after them
+      if (tb + 64 < pend) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(ylab), "+v"(vlm), "+v"(vam) : "n"(NI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ylab), "+v"(vlm), "+v"(vam) :: "memory");
+      const int y = (int)ylab;
+      if (G == 0 && valid && a.conf && (!a.acc_mask || vam) && y < K) atomicAdd(&confs[y * 8 + am], 1u);
+      const bool in_loss = valid && (!a.loss_mask || vlm) && y < K;
+      const float ex0 = cls0 < K ? __expf(lg0 - mx) : 0.f, ex1 = cls1 < K ? __expf(lg1 - mx) : 0.f;
+      float se = ex0 + ex1;
+      se += __shfl_xor(se, 16);
+      se += __shfl_xor(se, 32);
+      const float inv = 1.0f / se;
+      const float dl0 = (in_loss && cls0 < K) ? (ex0 * inv - (cls0 == y ? 1.f : 0.f)) * a.inv_n : 0.f;
+      const float dl1 = (in_loss && cls1 < K) ? (ex1 * inv - (cls1 == y ? 1.f : 0.f)) * a.inv_n : 0.f;
+      if (in_loss && cls0 == y) lsum += (double)(__logf(se) + mx - lg0);
+      if (in_loss && cls1 == y) lsum += (double)(__logf(se) + mx - lg1);
+      db0 += dl0;
+      db1 += dl1;
+      if (a.gfeat) {
+        // ---- filter gradient first (k = pixel; the logit gradients transposed through this wave's LDS tile) ...
+        DL[wave][p * KP + cls0] = dl0;
+        DL[wave][p * KP + cls1] = dl1;
+        __builtin_amdgcn_wave_barrier();
+        float aop[4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) aop[t4] = DL[wave][(4 * t4 + G) * KP + p];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+          const int px = 4 * t4 + G;
+#pragma unroll
+          for (int q = 0; q < CQ; ++q) {
+            const f32x4 fv = *reinterpret_cast<const f32x4*>(&F[px * C + 4 * ((16 * q + p) ^ px)]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dw[q][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[t4], fv[e], dw[q][e], 0, 0, 0);
+          }
+        }
+        // ---- ... then the gradient wrt the features: its NJ stores are the youngest vector-memory operations of the tile
+        float* gdst = a.gfeat + (size_t)pixc * a.ld_g + a.coff_g + 4 * G;
+#pragma unroll
+        for (int tt = 0; tt < NJ; ++tt) {
+          const float2 wv = *reinterpret_cast<const float2*>(&W2[(16 * tt + p) * 8 + 2 * G]);
+          f32x4 g = {0.f, 0.f, 0.f, 0.f};
+          g = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, dl0, g, 0, 0, 0);
+          g = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, dl1, g, 0, 0, 0);
+          if (valid) *reinterpret_cast<f32x4*>(gdst + 16 * tt) = g;
+        }
+        // the next tile's DMA is older than those NJ stores (every tile has a valid lane, so all NJ are issued)
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NJ) : "memory");
+        continue;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (!TRAIN) return;
+  __syncthreads();
+  float* red = W1;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w && G < 2) {
+#pragma unroll
+      for (int q = 0; q < CQ; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int idx = (64 * q + 4 * p + e) * 8 + 4 * G + r;
+            red[idx] = (w ? red[idx] : 0.f) + dw[q][e][r];
+          }
+    }
+    __syncthreads();
+  }
+  {
+    float v0 = db0, v1 = db1;
+    for (int d = 1; d < 16; d <<= 1) { v0 += __shfl_xor(v0, d); v1 += __shfl_xor(v1, d); }
+    if (p == 0) { redb[wave][cls0] = v0; redb[wave][cls1] = v1; }
+  }
+  {
+    double v = lsum;
+    for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+    if (lane == 0) redl[wave] = v;
+  }
+  __syncthreads();
+  if (a.dw_partial) {
+    for (int e = t; e < C * K; e += 256) {
+      const int c = e / K, k = e - c * K;
+      a.dw_partial[(size_t)blockIdx.x * C * K + e] = red[c * 8 + k];
+    }
+    if (t < K) a.db_partial[(size_t)blockIdx.x * K + t] = ((redb[0][t] + redb[1][t]) + redb[2][t]) + redb[3][t];
+  }
+  if (t == 0) a.loss_partial[blockIdx.x] = ((redl[0] + redl[1]) + redl[2]) + redl[3];
+  for (int r = gridDim.x + blockIdx.x; r < a.nrows; r += gridDim.x) {        // slab rows beyond the launch: zero (the caller sums a.nrows rows)
+    if (a.dw_partial) {
+      for (int e = t; e < C * K; e += 256) a.dw_partial[(size_t)r * C * K + e] = 0.f;
+      if (t < K) a.db_partial[(size_t)r * K + t] = 0.f;
+    }
+    if (t == 0) a.loss_partial[r] = 0.0;
+  }
+  if (a.conf && t < K * K) {
+    const int r = t / K, c = t - r * K;
+    const unsigned v = confs[r * 8 + c];
+    if (v) atomicAdd(&a.conf[t], v);
+  }
+#endif
 }
 
 __global__ void sum_f64_kernel(const double* __restrict__ in, int n, double* __restrict__ out) {
@@ -1240,7 +1476,7 @@ int drs_classifier_rows(int B, int S) {
   return (int)(n < 1 ? 1 : (n > 1024 ? 1024 : n));
 }
 
-int g_cls_variant = 1;       // development switch (drs_debug_cls_variant): 1 = by the class count (below), 2 = MFMA form always, 0 = vector-ALU form always
+int g_cls_variant = 1;       // development switch (drs_debug_cls_variant): 1 = by the class count and width (below), 2 = register MFMA form always, 3 = LDS-DMA MFMA form where it fits, 0 = vector-ALU form always
 
 #ifdef DRS_DEV
 int drs_debug_cls_variant(int v) { const int old = g_cls_variant; if (v >= 0) g_cls_variant = v; return old; }
@@ -1269,7 +1505,19 @@ int drs_classifier_loss(const float* feat, int B, int S, int P, int ld, int coff
   // the MFMA form pads the class dimension to 16 / 8, the vector-ALU form multiplies exactly K classes: in-process A/B
   // (tools/bench_classifier.py, profiles/r03/bench_classifier.log) K = 6, C = 256: MFMA 0.31 against 0.40 ms training and 0.11
   // against 0.19 ms inference at B = 128; K = 2, C = 448: vector-ALU 0.24 against 0.47 ms.  So: MFMA from four classes up.
-  const bool mfma = g_cls_variant == 1 ? K >= 4 : g_cls_variant == 2;
+  const bool mfma = g_cls_variant == 1 ? K >= 4 : g_cls_variant >= 2;
+  a.dma_span = 1; a.nrows = nblk;
+  // the LDS-DMA form (two feature tiles per wave fit the 160 KiB up to C = 256) is one workgroup per CU with a pipeline to fill: it
+  // pays from 2^18 pixels (tools/bench_classifier.py: B = 128, S = 64 training 0.31 -> 0.26 ms; B = 16, S = 64: 0.059 -> 0.077 ms)
+  if (mfma && C / 64 <= 4 && g_cls_variant != 2 && (g_cls_variant == 3 || M >= (1 << 18))) {
+    a.dma_span = (nblk + 255) / 256;
+    const int ndma = (nblk + a.dma_span - 1) / a.dma_span;
+#define DRS_CLS_D(cq) do { if (labels) DRS_LAUNCH((classifier_dma_kernel<cq, true>), dim3(ndma), dim3(256), 0, st, a); \
+                           else DRS_LAUNCH((classifier_dma_kernel<cq, false>), dim3(ndma), dim3(256), 0, st, a); } while (0)
+    switch (C / 64) { case 1: DRS_CLS_D(1); break; case 2: DRS_CLS_D(2); break; case 3: DRS_CLS_D(3); break; default: DRS_CLS_D(4); break; }
+#undef DRS_CLS_D
+    return DRS_LAUNCH_CHECK();
+  }
   if (mfma) {
 #define DRS_CLS_M(cq) do { if (labels) DRS_LAUNCH((classifier_mfma_kernel<cq, true>), dim3(nblk), dim3(256), 0, st, a); \
                            else DRS_LAUNCH((classifier_mfma_kernel<cq, false>), dim3(nblk), dim3(256), 0, st, a); } while (0)

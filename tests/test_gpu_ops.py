@@ -526,3 +526,50 @@ def test_filter_gradient_chunk_walk_over_patch_sides(lib, S, B):
         assert torch.equal(outs[0], o)
     assert rel_err(gw_eq.cpu().numpy().reshape(gw_ref.shape), gw_ref) < 1e-5
     assert float((gw_eq - outs[0]).abs().max() / outs[0].abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("C,K,B,S,P", [(256, 6, 3, 21, 0), (128, 4, 2, 17, 2), (64, 7, 1, 40, 1), (192, 8, 5, 9, 0), (256, 6, 16, 25, 0)])
+def test_classifier_forms_agree(lib, C, K, B, S, P):
+    """The classifier block exists in a vector-ALU form (2-3 classes), a register-staged MFMA form and an LDS-DMA MFMA form (features
+    brought in once, one tile ahead; up to C = 256).  The two MFMA forms run the same products in the same order: bitwise equal,
+    ragged last tiles, haloed feature slabs and masks included; the vector-ALU form agrees to rounding."""
+    lib = lib.dev()
+    rng = np.random.default_rng(C * 3 + K + S)
+    M = B * S * S
+    feat = rng.normal(size=(B, S, S, C)).astype(np.float32)
+    w = (rng.normal(size=(C, K)) / np.sqrt(C)).astype(np.float32)
+    bias = rng.normal(size=K).astype(np.float32) * 0.1
+    y = rng.integers(0, K, size=M).astype(np.uint8)
+    lm = rng.integers(0, 2, size=M).astype(np.uint8)
+    am = rng.integers(0, 2, size=M).astype(np.uint8)
+    fd = padded(feat, P, fill=3.0) if P else dev(feat)
+    rows = lib.query("drs_classifier_rows", B, S)
+    wdev, bdev, yd, lmd, amd = dev(w), dev(bias), dev(y), dev(lm), dev(am)
+    res = {}
+    try:
+        for v in (0, 2, 3):
+            lib.drs_debug_cls_variant(v)
+            logits = torch.zeros(M * K, dtype=torch.float32, device=DEV)
+            pred = torch.zeros(M, dtype=torch.uint8, device=DEV)
+            gfeat = torch.zeros(M * C, dtype=torch.float32, device=DEV)
+            dwp = torch.zeros(rows * C * K, dtype=torch.float32, device=DEV)
+            dbp = torch.zeros(rows * K, dtype=torch.float32, device=DEV)
+            lp = torch.zeros(rows, dtype=torch.float64, device=DEV)
+            conf = torch.zeros(K * K, dtype=torch.int32, device=DEV)
+            lib.call("drs_classifier_loss", fd.data_ptr(), B, S, P, C, 0, C, K, wdev.data_ptr(), bdev.data_ptr(), yd.data_ptr(), lmd.data_ptr(),
+                     amd.data_ptr(), 1.0 / max(1, int(lm.sum())), logits.data_ptr(), pred.data_ptr(), gfeat.data_ptr(), C, 0, dwp.data_ptr(), dbp.data_ptr(),
+                     lp.data_ptr(), conf.data_ptr(), stream())
+            pred2 = torch.zeros(M, dtype=torch.uint8, device=DEV)
+            lib.call("drs_classifier_loss", fd.data_ptr(), B, S, P, C, 0, C, K, wdev.data_ptr(), bdev.data_ptr(), None, None, None, 0.0, None,
+                     pred2.data_ptr(), None, 0, 0, None, None, None, None, stream())
+            torch.cuda.synchronize()
+            res[v] = (logits, pred, gfeat, dwp, dbp, lp, conf, pred2)
+    finally:
+        lib.drs_debug_cls_variant(1)
+    for a, b in zip(res[2], res[3]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[0][1], res[2][1]) or float((res[0][1] != res[2][1]).float().mean()) < 1e-3
+    assert torch.equal(res[0][6], res[2][6]) or float((res[0][6] - res[2][6]).abs().sum()) <= 2e-3 * M
+    for i in (0, 2):
+        assert float((res[0][i] - res[2][i]).abs().max()) <= 1e-5 * float(res[2][i].abs().max())
+    assert abs(float(res[0][5].sum()) - float(res[2][5].sum())) <= 1e-6 * abs(float(res[2][5].sum()))

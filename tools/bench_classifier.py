@@ -50,16 +50,16 @@ def main(Bs, Ss, C, K):
                           db.data_ptr() if train else None, lp.data_ptr() if train else None, conf.data_ptr() if train else None, st)
             res = {}
             for rep in range(3):
-                for v in (0, 2):
+                for v in (0, 2, 3):
                     _lib.drs_debug_cls_variant(v)
                     for train in (True, False):
                         res[(v, train)] = min(res.get((v, train), 1e9), t(lambda: run(train)))
             _lib.drs_debug_cls_variant(1)
             for train in (True, False):
                 byt = M * C * 4 * (2 if train else 1)
-                print("B=%3d S=%3d C=%d K=%d %-9s vector-ALU %.4f ms (%.2f TB/s = %.3f of 8)   MFMA %.4f ms (%.2f TB/s = %.3f of 8)" % (
-                    B, S, C, K, "training" if train else "inference", res[(0, train)], byt / res[(0, train)] / 1e9, byt / res[(0, train)] / 8e9,
-                    res[(2, train)], byt / res[(2, train)] / 1e9, byt / res[(2, train)] / 8e9), flush=True)
+                print("B=%3d S=%3d C=%d K=%d %-9s " % (B, S, C, K, "training" if train else "inference") +
+                      "   ".join("%s %.4f ms (%.2f TB/s = %.3f of 8)" % (n, res[(v, train)], byt / res[(v, train)] / 1e9, byt / res[(v, train)] / 8e9)
+                                 for v, n in ((0, "vector-ALU"), (2, "MFMA reg"), (3, "MFMA LDS-DMA"))), flush=True)
 
 
 if __name__ == "__main__":
