@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -154,6 +155,11 @@ struct drs_net {
   bool own_comm_stream;
   std::vector<hipEvent_t> comm_events;      // ring: [2 h] = data ready on the compute stream, [2 h + 1] = sum done on the side stream
   int comm_next;
+  // backward pass of small steps: the filter gradients on a stream of their own beside the batch-norm-backward -> input-gradient
+  // chain (two alternating gz slabs); created at first use
+  hipStream_t wg_stream;
+  hipEvent_t ev_gz[2], ev_wg[2];
+  int two_stream_mode;                      // -1 by the rule in train_step_impl, 0 never, 1 always (DRS_TWO_STREAMS)
   // per-slab (B, S) of the pooling call that last zeroed its halo (the halo of a slab one block owns stays zero)
   std::vector<long long> halo_ok;
   bool timing;
@@ -332,6 +338,7 @@ void list_buffers(drs_net* n) {
   n->add_buf("partial", std::max(rows_fwd * cmax * 2, part), F32);
   n->add_buf("gxh", M * cmax, F32);
   n->add_buf("gz", B * (S + 2 * hmax) * (S + 2 * hmax) * cmax, F32);
+  n->add_buf("gz2", B * (S + 2 * hmax) * (S + 2 * hmax) * cmax, F32);       // the second haloed output-gradient slab of the two-stream backward pass
   n->add_buf("slab", slab, F32);
   const Layer& L0 = n->layers[0];
   n->add_buf("w0pad", (size_t)round_up(L0.k * L0.k * L0.cin_k, 32) * L0.cout, F32);
@@ -529,6 +536,8 @@ int drs_net_create(const char* net_type, int channels, int num_classes, float we
     n->bessel = bessel_moving_var ? 1 : 0; n->lr_decay = lr_decay_factor; n->global_step = 0;
     n->world = 1; n->rank = 0; n->allreduce = nullptr; n->wait = nullptr; n->comm_user = nullptr; n->timing = false;
     n->rccl_small = n->rccl_big = nullptr; n->comm_stream = n->small_stream = nullptr; n->own_comm_stream = false; n->comm_next = 0;
+    n->wg_stream = nullptr;
+    { const char* e = std::getenv("DRS_TWO_STREAMS"); n->two_stream_mode = e ? std::atoi(e) : -1; }
     build_plan(n);
     list_buffers(n);
     n->halo_ok.assign(n->slabs.size(), -1);
@@ -553,6 +562,10 @@ static void release_rccl(drs_net* n) {
 void drs_net_destroy(drs_net_t* n) {
   if (!n) return;
   release_rccl(n);
+  if (n->wg_stream) {
+    for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(n->ev_gz[i]); (void)hipEventDestroy(n->ev_wg[i]); }
+    (void)hipStreamDestroy(n->wg_stream);
+  }
   for (auto& r : n->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto e : n->pool_events) (void)hipEventDestroy(e);
   delete n;
@@ -798,25 +811,43 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
   size_t bucket_hi = n->cls_w;
   std::vector<char> written(n->slabs.size(), 0);
   written[n->feat] = 1;
-  float* gz = n->p<float>("gz");
+  float* gzb[2] = {n->p<float>("gz"), n->p<float>("gz2")};
   float* gxh = n->p<float>("gxh");
   float* partial = n->p<float>("partial");
   double* sums = n->p<double>("sums");
 
+  // Small steps (the per-rank batches of data parallelism) run every convolution launch as one round: the chip drains and refills
+  // between two dependent kernels.  The filter gradient of block i+1 depends only on that block's gz, so it goes to a stream of its
+  // own and runs beside the batch-norm backward / input gradient of block i (two gz slabs in turn): its workgroups fill the CUs the
+  // other chain's tails leave idle.  Same kernels, same operands: results are bitwise those of the one-stream order.  Not with the
+  // host-callback collectives (the host's communicator is ordered against ITS stream, not this one), not while launches are timed
+  // (per-kernel figures want kernels alone on the chip), and not from 2^18 pixels (measured: nothing to gain at B >= 64).
+  bool two = n->two_stream_mode > 0 || (n->two_stream_mode < 0 && M < (1 << 18));
+  if (n->allreduce || n->timing) two = false;
+  if (two && !n->wg_stream) {
+    bool ok = hipStreamCreateWithFlags(&n->wg_stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < 2; ++i)
+      ok = hipEventCreateWithFlags(&n->ev_gz[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&n->ev_wg[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) return DRS_ERR_HIP;
+  }
+  hipStream_t ws = two ? n->wg_stream : st;       // the stream the filter gradients run on
+
   auto filter_gradient = [&](int i) -> int {
     const Layer& L = n->layers[i];
     const Slab& in = n->slabs[L.src];
+    if (two && hipStreamWaitEvent(ws, n->ev_gz[i & 1], 0) != hipSuccess) return DRS_ERR_HIP;      // block i's gz is written
     {
-      Timed t(n, st, K_CONV_WGRAD, 2.0 * M * L.k * L.k * L.cin * L.cout);
-      DRS_TRY(drs_conv_wgrad(n->p<float>("act:" + in.name), B, S, in.P, in.C, 0, gz, L.halo, L.cout, 0, L.k, L.rate, L.pad_b, L.cin_k, L.cin, L.cout,
-                             n->p<float>("slab"), grads + L.w_off, st));
+      Timed t(n, ws, K_CONV_WGRAD, 2.0 * M * L.k * L.k * L.cin * L.cout);
+      DRS_TRY(drs_conv_wgrad(n->p<float>("act:" + in.name), B, S, in.P, in.C, 0, gzb[two ? (i & 1) : 0], L.halo, L.cout, 0, L.k, L.rate, L.pad_b, L.cin_k,
+                             L.cin, L.cout, n->p<float>("slab"), grads + L.w_off, ws));
     }
     if (collectives(n) && i > 0 && (nL - i) % 2 == 0) {      // every second layer: one bucket
       int h;
-      DRS_TRY(all_reduce(n, grads + L.w_off, bucket_hi - L.w_off, F32, 1, st, &h));
+      DRS_TRY(all_reduce(n, grads + L.w_off, bucket_hi - L.w_off, F32, 1, ws, &h));
       pending.push_back(h);
       bucket_hi = L.w_off;
     }
+    if (two && hipEventRecord(n->ev_wg[i & 1], ws) != hipSuccess) return DRS_ERR_HIP;             // this gz slab may be rewritten
     return DRS_OK;
   };
 
@@ -852,14 +883,19 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     DRS_TRY(drs_stats_reduce(partial, drs_bn_backward_rows(B, S, L.cout, mx ? 1 : 0), L.cout, sums, nullptr, st));
     // sync batch norm: the all-reduce of (sum g, sum g*xhat) runs on the collective's stream while this stream computes the
     // filter gradient of the block above
+    // (two streams: the filter gradient runs beside this chain anyway, so the sum goes on this stream itself -- no event hand-over
+    // on the critical path, and the small communicator is then driven from this stream only, forward and backward)
     int h_bn;
-    DRS_TRY(all_reduce(n, sums, 2 * (size_t)L.cout, F64, 1, st, &h_bn));
+    DRS_TRY(all_reduce(n, sums, 2 * (size_t)L.cout, F64, two ? 0 : 1, st, &h_bn));
     if (deferred >= 0) DRS_TRY(filter_gradient(deferred));
     DRS_TRY(wait_handles(n, {h_bn}, st));
+    float* gz = gzb[two ? (i & 1) : 0];
+    if (two && i + 2 < nL && hipStreamWaitEvent(st, n->ev_wg[i & 1], 0) != hipSuccess) return DRS_ERR_HIP;   // block i+2's filter gradient has read this slab
     {
       Timed t(n, st, K_BN_BWD_APPLY, M * L.cout * 12.0);
       DRS_TRY(drs_bn_backward_apply(gxh, z, B, S, L.cout, mr, sums, n_bn, gz, L.halo, L.cout, 0, st));
     }
+    if (two && hipEventRecord(n->ev_gz[i & 1], st) != hipSuccess) return DRS_ERR_HIP;
     if (L.src != 0) {
       const Slab& in = n->slabs[L.src];
       const int acc = written[L.src] ? 1 : 0;
@@ -872,6 +908,10 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     deferred = i;
   }
   DRS_TRY(filter_gradient(deferred));
+  if (two) {      // every filter gradient is in place before the rest of the step reads the gradient buffer
+    if (hipStreamWaitEvent(st, n->ev_wg[0], 0) != hipSuccess) return DRS_ERR_HIP;
+    if (nL > 1 && hipStreamWaitEvent(st, n->ev_wg[1], 0) != hipSuccess) return DRS_ERR_HIP;
+  }
   if (collectives(n)) {
     int h;
     DRS_TRY(all_reduce(n, grads, bucket_hi, F32, 1, st, &h));                         // the remaining (earliest) layers
@@ -880,7 +920,7 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     pending.push_back(h);
     // (library-side RCCL: the backward phase's small sums all go through the small communicator's side stream, in order -- one
     // communicator is never driven from two streams at once)
-    const int side = n->rccl_small ? 1 : 0;
+    const int side = (n->rccl_small && !two) ? 1 : 0;
     DRS_TRY(all_reduce(n, scalars, 1, F64, side, st, &h));
     pending.push_back(h);
     DRS_TRY(all_reduce(n, conf, (size_t)n->K * n->K, I32, side, st, &h));
