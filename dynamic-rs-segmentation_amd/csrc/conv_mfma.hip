@@ -495,6 +495,7 @@ struct WgradArgs {
   int ntr, nto;
   int skip_halo;             // the walk jumps over the dead chunks (0: it multiplies their zeros -- same sums, bitwise)
   int live_cut;              // the live ranges shape the cut (plan) whether or not the walk skips
+  int ablate;                // timing experiments only (libdrs_hip_dev.so): 1 = every tap reads the un-shifted pixels (wrong sums)
   float rcpS, rcpSS;
   WgradPlan plan;
 };
@@ -832,7 +833,7 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   const int myRc = myR < rows_all ? myR : 0;
   const int tap = myRc / a.Cin, c0 = myRc % a.Cin;
   const int u = tap / a.k, v = tap % a.k;
-  const uint32_t xconst = (uint32_t)((u * a.rate * Sxp + v * a.rate) * a.ld_x + a.coff_x + c0) * 4u;
+  const uint32_t xconst = (uint32_t)((a.ablate == 1 ? 0 : (u * a.rate * Sxp + v * a.rate)) * a.ld_x + a.coff_x + c0) * 4u;
   uint32_t xoff[IX], goff[IG];
   int xpix[IX], gpix[IG];
 #pragma unroll
@@ -1167,6 +1168,7 @@ int g_wgrad_len = 96;       // development switch (drs_debug_wgrad_len): chunks 
 int g_wgrad_minchunks = 8;  // development switch (drs_debug_wgrad_minchunks): fewest 32-pixel chunks a split may have
 int g_wgrad_target_big = 0;  // development switch: workgroups aimed at on launches with many tiles and pixels under the live cut (0 = default)
 
+int g_wgrad_ablate = 0;      // development switch (drs_debug_wgrad_ablate): timing experiments with wrong sums
 int g_wgrad_model = 1;       // development switch (drs_debug_wgrad_model): 1 = per-CU cost model for launches below the `big` class, 0 = the r02 table
 
 // workgroups a filter-gradient launch of `work` chunk-tiles (32-pixel chunks x tiles) aims at; occ = workgroups of this tile
@@ -1315,6 +1317,7 @@ int wgrad_setup(int B, int S, int k, int rate, int pad_before, int cin, int cout
   const int nchunks = (int)((M + 31) / 32);
   a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
+  a.ablate = g_wgrad_ablate;
   // the cut: by live pixels (every workgroup of the launch the same length, the dead chunks skipped at any size), or equal chunk
   // ranges where that does not apply; development switches: drs_debug_wgrad_balance(0) = the equal cut with the dead chunks
   // skipped from 2^19 pixels only, drs_debug_skip_taps(0) = same cut, the dead chunks multiplied (same sums: bitwise)
@@ -1348,6 +1351,8 @@ int drs_debug_wgrad_len(int v) { const int old = g_wgrad_len; if (v > 0) g_wgrad
 int drs_debug_wgrad_minchunks(int v) { const int old = g_wgrad_minchunks; if (v > 0) g_wgrad_minchunks = v; return old; }
 
 int drs_debug_wgrad_model(int v) { const int old = g_wgrad_model; if (v >= 0) g_wgrad_model = v; return old; }
+
+int drs_debug_wgrad_ablate(int v) { const int old = g_wgrad_ablate; if (v >= 0) g_wgrad_ablate = v; return old; }
 
 int drs_debug_wgrad_target_big(int v) { const int old = g_wgrad_target_big; if (v >= 0) g_wgrad_target_big = v; return old; }
 

@@ -3,7 +3,8 @@
 one device, best-of per arm.  An arm is a string of development-switch settings: b<0|1> cut by live pixels off / on
 (drs_debug_wgrad_balance), t<N> workgroup target (drs_debug_wgrad_target), g<N> target of the many-tiles-and-pixels launches under
 the live cut (drs_debug_wgrad_target_big), v<0|1> kernel form (drs_debug_wgrad_variant; default per tile), l<N> chunks per workgroup that small launches aim at,
-m<N> fewest chunks a split may have (drs_debug_wgrad_minchunks), o<0|1> workgroup count by the r02 table / the per-CU cost model.
+m<N> fewest chunks a split may have (drs_debug_wgrad_minchunks), o<0|1> workgroup count by the r02 table / the per-CU cost model,
+a<0|1> timing experiment with WRONG sums: every tap reads the un-shifted pixels (what perfect re-use of X across tap rows would buy).
     python tools/ab_wgrad.py [B=128] [S=64] [arms=b0,b1,b1g2048] [layers=1,2,...] [rounds=4]"""
 import os, re, sys
 import torch
@@ -15,7 +16,7 @@ DEV = "cuda:0"
 
 
 def apply(lib, arm):
-    kv = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"([btgvlmo])(\d+)", arm))
+    kv = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"([btgvlmoa])(\d+)", arm))
     lib.drs_debug_wgrad_balance(kv.get("b", 1))
     lib.drs_debug_wgrad_target(kv.get("t", 2048))
     lib.drs_debug_wgrad_target_big(kv.get("g", 0))
@@ -23,6 +24,7 @@ def apply(lib, arm):
     lib.drs_debug_wgrad_len(kv.get("l", 96))
     lib.drs_debug_wgrad_minchunks(kv.get("m", 8))
     lib.drs_debug_wgrad_model(kv.get("o", 1))
+    lib.drs_debug_wgrad_ablate(kv.get("a", 0))
 
 
 def main(B=128, S=64, arms="b0,b1", rounds=4, layers=""):
