@@ -620,6 +620,20 @@ int drs_net_variable_info(const drs_net_t* n, int index, char* name, int name_ca
   return DRS_OK;
 }
 
+int drs_net_layer_info(const drs_net_t* n, int index, char* name, int name_cap, int* geom8, char* src_slab, char* dst_slab, int slab_cap,
+                       int* dst_coff, int* pool) {
+  if (!n || index < 0 || index >= (int)n->layers.size()) return DRS_ERR_ARG;
+  const Layer& L = n->layers[index];
+  auto put = [](char* dst, int cap, const std::string& v) { if (dst && cap > 0) { std::strncpy(dst, v.c_str(), cap - 1); dst[cap - 1] = 0; } };
+  put(name, name_cap, L.name);
+  put(src_slab, slab_cap, n->slabs[L.src].name);
+  put(dst_slab, slab_cap, n->slabs[L.dst].name);
+  if (geom8) { const int g[8] = {L.k, L.rate, L.cin, L.cin_k, L.cout, L.pad_b, L.pad_a, L.halo}; for (int i = 0; i < 8; ++i) geom8[i] = g[i]; }
+  if (dst_coff) *dst_coff = L.dst_coff;
+  if (pool) *pool = L.pool == 2 ? 2 + 256 * L.avg_k : L.pool;
+  return DRS_OK;
+}
+
 int drs_net_layout(const drs_net_t* n, size_t* n_params, size_t* n_decay, size_t* n_bn, int* n_layers, int* x0_channels, int* x0_halo) {
   if (!n) return DRS_ERR_ARG;
   if (n_params) *n_params = n->n_params;

@@ -599,6 +599,17 @@ __global__ void se_fc_wgrad_kernel(const float* __restrict__ u, const float* __r
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ gxh, const float* __restrict__ z, int B, int S, int C,
                                     const float* __restrict__ mean_rstd, const double* __restrict__ sums, double count,
                                     ActView out) {
+  // per-channel coefficients once per workgroup (they used to be 8 fp64 divisions and 96 bytes of loads per THREAD, for 48 bytes of
+  // payload: the kernel was bound by that arithmetic, not by memory): [mu | rstd | sum g / N | sum g xhat / N][C], so that a
+  // thread's four channels are one 16-byte LDS read per coefficient.  Same expressions, same rounding as before.
+  __shared__ __attribute__((aligned(16))) float coef[4 * 448];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    coef[c] = mean_rstd[2 * c];
+    coef[C + c] = mean_rstd[2 * c + 1];
+    coef[2 * C + c] = (float)(sums[2 * c] / count);
+    coef[3 * C + c] = (float)(sums[2 * c + 1] / count);
+  }
+  __syncthreads();
   const int CQ = C >> 2;
   const int Sp = S + 2 * out.P;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -614,14 +625,15 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ gxh, const float* 
   const size_t pix = ((size_t)b * S + y) * S + x;
   const f32x4 gv = *reinterpret_cast<const f32x4*>(gxh + pix * C + cq * 4);
   const f32x4 zv = *reinterpret_cast<const f32x4*>(z + pix * C + cq * 4);
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(&coef[cq * 4]);
+  const f32x4 rs = *reinterpret_cast<const f32x4*>(&coef[C + cq * 4]);
+  const f32x4 m1 = *reinterpret_cast<const f32x4*>(&coef[2 * C + cq * 4]);
+  const f32x4 m2 = *reinterpret_cast<const f32x4*>(&coef[3 * C + cq * 4]);
   f32x4 o;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int c = cq * 4 + j;
-    const float mu = mean_rstd[2 * c], rs = mean_rstd[2 * c + 1];
-    const float m1 = (float)(sums[2 * c] / count), m2 = (float)(sums[2 * c + 1] / count);
-    const float xh = (zv[j] - mu) * rs;
-    o[j] = rs * (gv[j] - m1 - xh * m2);
+    const float xh = (zv[j] - mu[j]) * rs[j];
+    o[j] = rs[j] * (gv[j] - m1[j] - xh * m2[j]);
   }
   view_store4(out, dst, o);
 }
@@ -1443,7 +1455,7 @@ int drs_bn_backward_reduce(const float* ga, int ld_ga, int coff_ga, const float*
 static int bn_backward_apply_impl(const float* gxhat, const float* z, int B, int S, int C, const float* mean_rstd,
                                   const double* sums, double count, float* gz, int P_out, int ld_out, int coff_out,
                                   unsigned short* terms, int nterms, void* stream) {
-  if (!gxhat || !z || !mean_rstd || !sums || (!gz && !terms) || C % 4) return DRS_ERR_ARG;
+  if (!gxhat || !z || !mean_rstd || !sums || (!gz && !terms) || C % 4 || C > 448) return DRS_ERR_ARG;
   if (terms && ((nterms != 2 && nterms != 3) || (ld_out & 31) || (coff_out & 31))) return DRS_ERR_ARG;
   const int Sp = S + 2 * P_out;
   if ((long long)B * Sp > 65535) return DRS_ERR_ARG;

@@ -274,6 +274,13 @@ int drs_net_buffer_info(const drs_net_t* net, int index, char* name, int name_ca
 int drs_net_bind(drs_net_t* net, const char* name, void* dev_ptr, size_t bytes);
 int drs_net_buffer(drs_net_t* net, const char* name, void** dev_ptr, size_t* bytes);
 int drs_net_layout(const drs_net_t* net, size_t* n_params, size_t* n_decay, size_t* n_bn, int* n_layers, int* x0_channels, int* x0_halo);
+/* block `index` of the net as the library runs it (the `_conv_layer` calls of the reference's builder, isprs:761-1086, in order):
+ * geom8 = (k, rate, cin, cin_k = input channels the kernel multiplies (conv1: the bands padded to 8), cout, pad_before, pad_after,
+ * halo of its input slab); the slabs it reads / writes by name ("x0", "x1", ..., "feat", "concat": buffers "act:<name>"), the
+ * channel offset of its output slice (dense / squeeze nets write slices of a shared slab, isprs:921-948), and the pooling after
+ * its activation: 0 none, 1 max 3x3 / stride 1, 2 + 256 k = k x k average */
+int drs_net_layer_info(const drs_net_t* net, int index, char* name, int name_cap, int* geom8, char* src_slab, char* dst_slab, int slab_cap,
+                       int* dst_coff, int* pool);
 /* variables under their TensorFlow scope names (`conv1/weights`, `conv1/biases`, `conv1/moving_mean`, `conv1/moving_variance`,
  * `conv_classifier/weights`, ...: what tf.train.Saver stores, isprs:1693-1695): offset / count in floats inside "params" (and
  * "grads", "momentum") or, with *in_bn = 1, inside "bn"; shape4 = HWIO for kernels */

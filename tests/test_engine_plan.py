@@ -41,6 +41,18 @@ def test_library_layout_equals_plan(net_type, ch, K):
     _lib.call("drs_net_layout", h, C.byref(npar), C.byref(ndec), C.byref(nbn), C.byref(nl), C.byref(c0), C.byref(p0))
     assert (npar.value, ndec.value, nbn.value, nl.value) == (p.n_params, p.n_decay, p.n_bn, len(p.layers))
     assert (c0.value, p0.value) == p.buffers["x0"]
+    # the blocks themselves: geometry, wiring and pooling of every `_conv_layer` call, in execution order
+    geom = (C.c_int * 8)()
+    src, dst = C.create_string_buffer(32), C.create_string_buffer(32)
+    coff, pool = C.c_int(), C.c_int()
+    for i, L in enumerate(p.layers):
+        _lib.call("drs_net_layer_info", h, i, name, 96, geom, src, dst, 32, C.byref(coff), C.byref(pool))
+        assert name.value.decode() == L.name
+        assert tuple(geom) == (L.k, L.rate, L.cin, L.cin_k, L.cout, L.pad_b, L.pad_a, L.halo), (L.name, tuple(geom))
+        assert (src.value.decode(), dst.value.decode(), coff.value) == (L.src, L.dst, L.dst_coff)
+        q = p.pools[i]
+        assert pool.value == (0 if q is None else (1 if q[0] == "max" else 2 + 256 * q[1])), (L.name, pool.value, q)
+    assert _lib.load().drs_net_layer_info(h, len(p.layers), name, 96, geom, src, dst, 32, None, None) == 1
     # buffers: every activation slab of the plan with its halo, sized for (b_max, s_max)
     nb, dt = C.c_size_t(), C.c_int()
     bufs = {}
