@@ -77,6 +77,7 @@ SIGNATURES = {
     "drs_rccl_unique_id": (_i, [_p]),
     "drs_rccl_comm_create": (_i, [_i, _i, _p, C.POINTER(_p)]),
     "drs_rccl_comm_destroy": (_i, [_p]),
+    "drs_rccl_all_reduce": (_i, [_p, _p, C.c_size_t, _i, _p]),
     "drs_net_set_rccl": (_i, [_p, _i, _i, _p, _p, _p]),
     "drs_train_step": (_i, [_p, _i, _i, _f, _i, _d, _p]),
     "drs_forward": (_i, [_p, _i, _i, _i, _i, _p]),
@@ -96,7 +97,7 @@ DEV_SIGNATURES = {
     "drs_debug_skip_taps": (_i, [_i]), "drs_debug_conv_variant": (_i, [_i]), "drs_debug_conv_wide192": (_i, [_i]),
     "drs_debug_conv_splitk": (_i, [_i]),
     "drs_debug_wgrad_variant": (_i, [_i]), "drs_debug_wgrad_balance": (_i, [_i]), "drs_debug_wgrad_target": (_i, [_i]),
-    "drs_debug_wgrad_target_big": (_i, [_i]), "drs_debug_wgrad_len": (_i, [_i]), "drs_debug_wgrad_minchunks": (_i, [_i]), "drs_debug_wgrad_model": (_i, [_i]), "drs_debug_wgrad_ablate": (_i, [_i]), "drs_debug_cls_variant": (_i, [_i]), "drs_debug_variant": (_i, [_i]),
+    "drs_debug_wgrad_target_big": (_i, [_i]), "drs_debug_wgrad_len": (_i, [_i]), "drs_debug_wgrad_minchunks": (_i, [_i]), "drs_debug_wgrad_model": (_i, [_i]), "drs_debug_wgrad_ablate": (_i, [_i]), "drs_debug_cls_variant": (_i, [_i]), "drs_debug_slide_blocks": (_i, [_i]), "drs_debug_slide_minrows": (_i, [_i]), "drs_debug_variant": (_i, [_i]),
     "drs_debug_wgrad_cut": (_i, [_i] * 7 + [_p, _i, _p, _p]),
 }
 

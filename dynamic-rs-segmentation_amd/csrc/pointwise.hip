@@ -271,13 +271,15 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ ga, int ld_ga, in
 // registers: 3 loads per output forward (one row of 3 neighbours), 3 (code, gradient) pairs backward.
 // block = TX columns x (C/4) channel quads; grid.x = column blocks, grid.y = (image, row strip).
 struct SlideCfg { int TX, ncol, nstrips, rps; };
+static int g_slide_blocks = 2048, g_slide_minrows = 8;     // (development switches: drs_debug_slide_*)
+static bool slide_ok(int C) { return C / 4 <= 128; }        // two columns or more per workgroup (the neighbours go through LDS)
 static SlideCfg slide_cfg(int B, int S, int C) {
   SlideCfg c;
   const int CQ = C / 4;
   c.TX = 256 / CQ;
   c.ncol = (S + c.TX - 1) / c.TX;
   c.nstrips = 1;
-  while ((long long)B * c.ncol * c.nstrips < 2048 && S / (c.nstrips * 2) >= 8) c.nstrips *= 2;
+  while ((long long)B * c.ncol * c.nstrips < g_slide_blocks && S / (c.nstrips * 2) >= g_slide_minrows) c.nstrips *= 2;
   // the per-rank batches of data parallelism (16 patches of 25 .. 85 pixels): few workgroups, each a chain of dependent row loads
   // -- the launch is latency-bound, so shorter strips (down to 2-3 rows: 2 extra rows loaded per strip, out of L2) and more of them
   while ((long long)B * c.ncol * c.nstrips < 768 && S / (c.nstrips * 2) >= 2) c.nstrips *= 2;
@@ -298,12 +300,32 @@ __global__ void zero_halo_kernel(ActView out, int B, int C) {
   view_store4(out, ((size_t)(b * Sp + yy) * Sp + xx) * out.ld + out.coff + cq * 4, f32x4{0.f, 0.f, 0.f, 0.f});
 }
 
-__global__ void bn_act_pool_fwd_slide_kernel(const float* __restrict__ z, int B, int S, int C, const float* __restrict__ mean_rstd,
-                                             float alpha, ActView out, unsigned char* __restrict__ idx, int nstrips, int rps) {
-  const int CQ = C >> 2;
+// Both sliding kernels, r03: a thread is a chain of dependent rows, and what bounded the launches was the data it keeps in flight
+// (one 16-byte load per wave at first: 0.56 of HBM with nothing else to wait for), not the arithmetic.  So each thread loads ONLY its
+// own column, three rows ahead of the row it works on, and the horizontal neighbours come through LDS: every thread publishes what
+// it derived from its own load (the activation forward; the (position word, gradient) pair backward), one barrier per row, two
+// cells in turn.  The first / last column thread of a workgroup also loads and publishes the column beyond its edge.  Columns
+// outside the image are read from the nearest column inside (clamped): forward such a duplicate cannot change a maximum and is
+// never chosen as its position; backward its position word is replaced by one that matches no window position.  Addresses are a
+// per-row base every lane shares plus a per-thread byte offset fixed for the strip; the row registers rotate by renaming (the loops
+// are unrolled over their rings of three).
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load and store in flight, which is
+// exactly the prefetch these kernels live on
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__global__ __launch_bounds__(256) void bn_act_pool_fwd_slide_kernel(const float* __restrict__ z, int B, int S, int C,
+                                                                    const float* __restrict__ mean_rstd, float alpha, ActView out,
+                                                                    unsigned char* __restrict__ idx, int nstrips, int rps) {
+  extern __shared__ __attribute__((aligned(16))) float xch[];                // [2][TX + 2][C]: the activations of a row
+  const int CQ = C >> 2, TX = blockDim.x / CQ;                               // TX >= 2
   const int tx = threadIdx.x / CQ, cq = threadIdx.x - tx * CQ;
-  const int x = blockIdx.x * (blockDim.x / CQ) + tx;
-  if (x >= S) return;
+  const int xr = blockIdx.x * TX + tx;
+  const bool live = xr < S;                                                  // (the last column block may overhang: such threads take part, store nothing)
+  const int x = live ? xr : S - 1;
   const int b = blockIdx.y / nstrips, strip = blockIdx.y - b * nstrips;
   const int y0 = strip * rps;
   int y1 = y0 + rps;
@@ -313,114 +335,192 @@ __global__ void bn_act_pool_fwd_slide_kernel(const float* __restrict__ z, int B,
   const float mu[4] = {mr0[0], mr0[2], mr1[0], mr1[2]};
   const float rs[4] = {mr0[1], mr0[3], mr1[1], mr1[3]};
   const float NEG = -__builtin_inff();
-  // (max, position 0..2) over the three horizontal neighbours of row r, first maximum in scan order
-  auto row_max = [&](int r, f32x4& m, unsigned (&cd)[4]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { m[j] = NEG; cd[j] = 0u; }
-    if (r < 0 || r >= S) return;
-    const float* zr = z + (((size_t)b * S + r) * S) * C + cq * 4;
-#pragma unroll
-    for (int dx = -1; dx <= 1; ++dx) {
-      const int nx = x + dx;
-      if (nx < 0 || nx >= S) continue;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(zr + (size_t)nx * C);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float a = act((v[j] - mu[j]) * rs[j], alpha);
-        if (a > m[j]) { m[j] = a; cd[j] = (unsigned)(dx + 1); }
-      }
-    }
-  };
-  f32x4 m0, m1, m2;
-  unsigned c0[4], c1[4], c2[4];
-  row_max(y0 - 1, m0, c0);
-  row_max(y0, m1, c1);
+  const bool vl = x > 0;
+  const bool edge_l = tx == 0, edge = edge_l || tx == TX - 1;
+  const int xh = edge_l ? (x > 0 ? x - 1 : 0) : (x + 1 < S ? x + 1 : S - 1);
+  const unsigned oc = (unsigned)((x * C + cq * 4) * 4), oh = edge ? (unsigned)((xh * C + cq * 4) * 4) : oc;   // (inner threads: their own column again, out of L1)
+  const size_t zrow = (size_t)S * C * 4;                                     // bytes per image row of z
+  const char* zimg = reinterpret_cast<const char*>(z) + (size_t)b * S * zrow;
+  f32x4* cells = reinterpret_cast<f32x4*>(xch);
+  const int lc = (tx + 1) * CQ + cq, lh = (edge_l ? 0 : TX + 1) * CQ + cq, lslot = (TX + 2) * CQ;
+  auto load_row = [&](int r, f32x4& vc, f32x4& vh) {
+    const int rc = r < 0 ? 0 : (r >= S ? S - 1 : r);
+    const char* zr = zimg + (size_t)rc * zrow;
+    vc = *reinterpret_cast<const f32x4*>(zr + oc);
+    vh = *reinterpret_cast<const f32x4*>(zr + oh);                           // (every thread: a load under a divergent branch makes the
+  };                                                                         //  compiler drain the loads in flight at the join)
   const int Sp = S + 2 * out.P;
-  for (int y = y0; y < y1; ++y) {
-    row_max(y + 1, m2, c2);
+  const size_t orow = (size_t)Sp * out.ld * 4;                               // bytes per padded row of the output view
+  char* oimg = reinterpret_cast<char*>(out.base) + ((size_t)b * Sp + out.P) * orow;
+  const unsigned oo = (unsigned)(((x + out.P) * out.ld + out.coff + cq * 4) * 4);
+  unsigned char* iimg = idx + (size_t)b * S * S * C;
+  // row r: (max, position 0..2 of the first maximum in scan order) over its three horizontal neighbours into (mC, cC), the registers
+  // of row r refilled with row r + 3; then output row r - 1 from rows r - 2, r - 1 (mA, mB) and r.  ONE path for every row -- a row
+  // outside the image is computed from the clamped row and then overridden -- because the compiler answers a second path through
+  // the loads with a full drain of the loads in flight.
+  const int lhx = edge ? lh : lc;
+  auto iter = [&](int r, f32x4& vc, f32x4& vh, const f32x4& mA, const unsigned (&cA)[4], const f32x4& mB, const unsigned (&cB)[4], f32x4& mC,
+                  unsigned (&cC)[4]) {
+    f32x4 a1, ah;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a1[j] = act((vc[j] - mu[j]) * rs[j], alpha);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ah[j] = act((vh[j] - mu[j]) * rs[j], alpha);
+    load_row(r + 3, vc, vh);
+    f32x4* cell = cells + (r & 1) * lslot;
+    cell[lc] = a1;
+    cell[lhx] = ah;                                              // (inner threads: their own cell again, the same value)
+    lds_barrier();
+    const f32x4 a0 = cell[lc - CQ], a2 = cell[lc + CQ];
+    const bool rv = r >= 0 && r < S;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float mm = fmaxf(fmaxf(a0[j], a1[j]), a2[j]);
+      mC[j] = rv ? mm : NEG;
+      cC[j] = (vl && a0[j] == mm) ? 0u : (a1[j] == mm ? 1u : 2u);
+    }
+    const int y = r - 1;
     f32x4 best;
     unsigned code[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      best[j] = m0[j]; code[j] = c0[j];                       // row y-1 (or -inf)
-      if (m1[j] > best[j]) { best[j] = m1[j]; code[j] = 3u + c1[j]; }
-      if (m2[j] > best[j]) { best[j] = m2[j]; code[j] = 6u + c2[j]; }
+      const float bb = fmaxf(fmaxf(mA[j], mB[j]), mC[j]);
+      best[j] = bb;
+      const unsigned kB = 3u + cB[j], kC = 6u + cC[j];          // (both formed before the selects: keeps them selects, not branches)
+      unsigned k = mB[j] == bb ? kB : kC;
+      k = mA[j] == bb ? cA[j] : k;
+      code[j] = k;
     }
-    view_store4(out, ((size_t)(b * Sp + y + out.P) * Sp + x + out.P) * out.ld + out.coff + cq * 4, best);
-    if (idx) {
-      const size_t pix = ((size_t)b * S + y) * S + x;
-      *reinterpret_cast<unsigned*>(idx + pix * C + cq * 4) = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
+    if (y >= y0 && live) {
+      *reinterpret_cast<f32x4*>(oimg + (size_t)y * orow + oo) = best;
+      if (idx) *reinterpret_cast<unsigned*>(iimg + (size_t)y * S * C + (oc >> 2)) = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
     }
-    m0 = m1; m1 = m2;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { c0[j] = c1[j]; c1[j] = c2[j]; }
+  };
+  f32x4 m0 = {NEG, NEG, NEG, NEG}, m1 = m0, m2 = m0;
+  unsigned c0[4] = {0u, 0u, 0u, 0u}, c1[4] = {0u, 0u, 0u, 0u}, c2[4] = {0u, 0u, 0u, 0u};
+  f32x4 v0c, v0h = {0.f, 0.f, 0.f, 0.f}, v1c, v1h = v0h, v2c, v2h = v0h;
+  load_row(y0 - 1, v0c, v0h);
+  load_row(y0, v1c, v1h);
+  load_row(y0 + 1, v2c, v2h);
+  for (int r = y0 - 1; r <= y1; r += 3) {                       // rows y0-1 .. y1; row r's maxima live in m[(r - y0 + 1) % 3]
+    iter(r, v0c, v0h, m1, c1, m2, c2, m0, c0);
+    if (r + 1 > y1) break;
+    iter(r + 1, v1c, v1h, m2, c2, m0, c0, m1, c1);
+    if (r + 2 > y1) break;
+    iter(r + 2, v2c, v2h, m0, c0, m1, c1, m2, c2);
   }
 }
 
-__global__ void bn_bwd_reduce_slide_kernel(const float* __restrict__ ga, int ld_ga, int coff_ga, const float* __restrict__ z,
-                                           const unsigned char* __restrict__ idx, int B, int S, int C,
-                                           const float* __restrict__ mean_rstd, float alpha, float* __restrict__ gxh,
-                                           float* __restrict__ partial, int nstrips, int rps) {
-  extern __shared__ __attribute__((aligned(16))) float red[];   // [TX][C][2]
+__global__ __launch_bounds__(256) void bn_bwd_reduce_slide_kernel(const float* __restrict__ ga, int ld_ga, int coff_ga,
+                                                                  const float* __restrict__ z, const unsigned char* __restrict__ idx, int B,
+                                                                  int S, int C, const float* __restrict__ mean_rstd, float alpha,
+                                                                  float* __restrict__ gxh, float* __restrict__ partial, int nstrips, int rps) {
+  // the exchange cells [2][TX + 2][CQ] x (gradient f32x4, position word), then (after the rows) the reduction image [TX][C][2]
+  extern __shared__ __attribute__((aligned(16))) float red[];
   const int CQ = C >> 2;
-  const int TX = blockDim.x / CQ;
+  const int TX = blockDim.x / CQ;                                            // TX >= 2
   const int tx = threadIdx.x / CQ, cq = threadIdx.x - tx * CQ;
-  const int x = blockIdx.x * TX + tx;
+  const int xr = blockIdx.x * TX + tx;
+  const bool live = xr < S;
+  const int x = live ? xr : S - 1;
   const int b = blockIdx.y / nstrips, strip = blockIdx.y - b * nstrips;
   const int y0 = strip * rps;
   int y1 = y0 + rps;
   y1 = y1 < S ? y1 : S;
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-  if (x < S) {
+  {
     const f32x4 mr0 = *reinterpret_cast<const f32x4*>(mean_rstd + cq * 8);
     const f32x4 mr1 = *reinterpret_cast<const f32x4*>(mean_rstd + cq * 8 + 4);
     const float mu[4] = {mr0[0], mr0[2], mr1[0], mr1[2]};
     const float rs[4] = {mr0[1], mr0[3], mr1[1], mr1[3]};
-    // one row of the window: arg-max codes and incoming gradients of the pooled outputs (r, x-1..x+1)
-    auto load_row = [&](int r, unsigned (&wi)[3], f32x4 (&wg)[3]) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int qx = x + k - 1;
-        if (r < 0 || r >= S || qx < 0 || qx >= S) { wi[k] = 0xffffffffu; wg[k] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
-        const size_t q = ((size_t)b * S + r) * S + qx;
-        wi[k] = *reinterpret_cast<const unsigned*>(idx + q * C + cq * 4);
-        wg[k] = *reinterpret_cast<const f32x4*>(ga + q * ld_ga + coff_ga + cq * 4);
-      }
+    const bool edge_l = tx == 0, edge = edge_l || tx == TX - 1;
+    const int xh = edge_l ? x - 1 : x + 1;
+    const bool vh_ok = xh >= 0 && xh < S;                                    // the column beyond the workgroup's edge exists
+    const int xhc = xh < 0 ? 0 : (xh >= S ? S - 1 : xh);
+    const unsigned oi = (unsigned)(x * C + cq * 4), oih = edge ? (unsigned)(xhc * C + cq * 4) : oi;      // bytes into a row of positions
+    const unsigned og = (unsigned)((x * ld_ga + coff_ga + cq * 4) * 4), ogh = edge ? (unsigned)((xhc * ld_ga + coff_ga + cq * 4) * 4) : og;
+    const size_t irow = (size_t)S * C, grow = (size_t)S * ld_ga * 4, zrow = (size_t)S * C * 4;
+    const unsigned char* iimg = idx + (size_t)b * S * irow;
+    const char* gimg = reinterpret_cast<const char*>(ga) + (size_t)b * S * grow;
+    const char* zimg = reinterpret_cast<const char*>(z) + (size_t)b * S * zrow;
+    char* ximg = reinterpret_cast<char*>(gxh) + (size_t)b * S * zrow;
+    f32x4* gcells = reinterpret_cast<f32x4*>(red);
+    const int lslot = (TX + 2) * CQ;
+    unsigned* icells = reinterpret_cast<unsigned*>(red) + 2 * lslot * 4;
+    const int lc = (tx + 1) * CQ + cq, lh = (edge_l ? 0 : TX + 1) * CQ + cq;
+    // the loads of window row r (own column; the column beyond the edge) and z of output row r - 1
+    auto load_row = [&](int r, unsigned& iw, f32x4& gw, unsigned& ih, f32x4& gh, f32x4& zv) {
+      const int rc = r < 0 ? 0 : (r >= S ? S - 1 : r);
+      iw = *reinterpret_cast<const unsigned*>(iimg + (size_t)rc * irow + oi);
+      gw = *reinterpret_cast<const f32x4*>(gimg + (size_t)rc * grow + og);
+      ih = *reinterpret_cast<const unsigned*>(iimg + (size_t)rc * irow + oih);     // (every thread, as in the forward kernel)
+      gh = *reinterpret_cast<const f32x4*>(gimg + (size_t)rc * grow + ogh);
+      const int ry = r - 1 < 0 ? 0 : (r - 1 >= S ? S - 1 : r - 1);
+      zv = *reinterpret_cast<const f32x4*>(zimg + (size_t)ry * zrow + (oi << 2));
     };
-    unsigned i0[3], i1[3], i2[3];
-    f32x4 g0[3], g1[3], g2[3];
-    load_row(y0 - 1, i0, g0);
-    load_row(y0, i1, g1);
-    for (int y = y0; y < y1; ++y) {
-      load_row(y + 1, i2, g2);
-      f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
-      // output q = p + (dy, dx) routed its gradient to p iff its winner sits at (-dy, -dx): code (1-dy)*3 + (1-dx)
+    // window row r arrives: pooled output (r, x + k - 1) with position c = 3 cy + cx routed its gradient to input
+    // (r + cy - 1, x + k - 1 + cx - 1) -- to this thread's column iff cx == 2 - k, and then to row r - 1 / r / r + 1 for cy = 0 / 1 / 2,
+    // whose sums are aP / aC / aN.  After row r the sum of row r - 1 is complete: gradient wrt the normalised activation, its sums.
+    const int lhx = edge ? lh : lc;
+    auto iter = [&](int r, unsigned& iw, f32x4& gw, unsigned& ih, f32x4& gh, f32x4& zv, f32x4& aP, f32x4& aC, f32x4& aN) {
+      const f32x4 zy = zv;
+      const bool rv = r >= 0 && r < S;                                       // (one path for every row, as in the forward kernel)
+      const unsigned mi = (rv && live) ? iw : 0xffffffffu, mh = (rv && vh_ok) ? ih : 0xffffffffu;
+      const f32x4 mg = gw, mgh = gh;
+      load_row(r + 3, iw, gw, ih, gh, zv);
+      f32x4* gcell = gcells + (r & 1) * lslot;
+      unsigned* icell = icells + (r & 1) * lslot;
+      gcell[lc] = mg;
+      icell[lc] = mi;
+      gcell[lhx] = edge ? mgh : mg;                                          // (inner threads: their own cell again, the same values)
+      icell[lhx] = edge ? mh : mi;
+      lds_barrier();
+      const unsigned wi[3] = {icell[lc - CQ], mi, icell[lc + CQ]};
+      const f32x4 wg[3] = {gcell[lc - CQ], mg, gcell[lc + CQ]};
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const unsigned w0 = (unsigned)(2 * 3 + (2 - k)), w1 = (unsigned)(1 * 3 + (2 - k)), w2 = (unsigned)(0 * 3 + (2 - k));
+        const unsigned wP = (unsigned)(2 - k), wC = (unsigned)(3 + 2 - k), wN = (unsigned)(6 + 2 - k);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (((i0[k] >> (8 * j)) & 0xffu) == w0) g[j] += g0[k][j];
-          if (((i1[k] >> (8 * j)) & 0xffu) == w1) g[j] += g1[k][j];
-          if (((i2[k] >> (8 * j)) & 0xffu) == w2) g[j] += g2[k][j];
+          const unsigned c = (wi[k] >> (8 * j)) & 0xffu;
+          aP[j] += c == wP ? wg[k][j] : 0.f;
+          aC[j] += c == wC ? wg[k][j] : 0.f;
+          aN[j] += c == wN ? wg[k][j] : 0.f;
         }
       }
-      const size_t p = ((size_t)b * S + y) * S + x;
-      const f32x4 zv = *reinterpret_cast<const f32x4*>(z + p * C + cq * 4);
+      const int y = r - 1;
       f32x4 o;
+      float t1[4], t2[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float xh = (zv[j] - mu[j]) * rs[j];
-        const float gx = xh > 0.f ? g[j] : g[j] * alpha;
+        const float xhat = (zy[j] - mu[j]) * rs[j];
+        const float gx = xhat > 0.f ? aP[j] : aP[j] * alpha;
         o[j] = gx;
-        s1[j] += gx;
-        s2[j] += gx * xh;
+        t1[j] = gx;
+        t2[j] = gx * xhat;
       }
-      *reinterpret_cast<f32x4*>(gxh + p * C + cq * 4) = o;
+      if (y >= y0 && live) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { i0[k] = i1[k]; i1[k] = i2[k]; g0[k] = g1[k]; g1[k] = g2[k]; }
+        for (int j = 0; j < 4; ++j) { s1[j] += t1[j]; s2[j] += t2[j]; }
+        *reinterpret_cast<f32x4*>(ximg + (size_t)y * zrow + (oi << 2)) = o;
+      }
+      aP = f32x4{0.f, 0.f, 0.f, 0.f};                                        // becomes the sum of row r + 2
+    };
+    unsigned i0, i1, i2, h0 = 0u, h1 = 0u, h2 = 0u;
+    f32x4 g0, g1, g2, q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0, z0, z1, z2;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+    load_row(y0 - 1, i0, g0, h0, q0, z0);
+    load_row(y0, i1, g1, h1, q1, z1);
+    load_row(y0 + 1, i2, g2, h2, q2, z2);
+    for (int r = y0 - 1; r <= y1; r += 3) {
+      iter(r, i0, g0, h0, q0, z0, a0, a1, a2);
+      if (r + 1 > y1) break;
+      iter(r + 1, i1, g1, h1, q1, z1, a1, a2, a0);
+      if (r + 2 > y1) break;
+      iter(r + 2, i2, g2, h2, q2, z2, a2, a0, a1);
     }
   }
+  __syncthreads();                                                           // the exchange cells are done with
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     red[((size_t)tx * C + cq * 4 + j) * 2] = s1[j];
@@ -1388,10 +1488,11 @@ static int bn_act_pool_forward_impl(const float* z, int B, int S, int C, const f
   v.terms = terms; v.nt = terms ? nterms : 0;
   const bool halo_is_zero = (pool & 2) != 0;     // the caller vouches for the halo (same B, S, P as the call that last zeroed it)
   pool &= 1;
-  if (pool && C / 4 <= 256) {
+  if (pool && slide_ok(C) && !terms) {             // (the split-bf16 images of the opt-in arithmetic: the gathering form below)
     const SlideCfg c = slide_cfg(B, S, C);
     if (P_out > 0 && !halo_is_zero) DRS_LAUNCH(zero_halo_kernel, grid, dim3(256), 0, (hipStream_t)stream, v, B, C);
-    DRS_LAUNCH(bn_act_pool_fwd_slide_kernel, dim3(c.ncol, B * c.nstrips), dim3(c.TX * (C / 4)), 0, (hipStream_t)stream, z, B, S, C,
+    const size_t shm = (size_t)2 * (c.TX + 2) * C * sizeof(float);
+    DRS_LAUNCH(bn_act_pool_fwd_slide_kernel, dim3(c.ncol, B * c.nstrips), dim3(c.TX * (C / 4)), shm, (hipStream_t)stream, z, B, S, C,
                mean_rstd, alpha, v, argmax, c.nstrips, c.rps);
   } else if (pool)
     DRS_LAUNCH(bn_act_pool_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, z, B, S, C, mean_rstd, alpha, v, argmax);
@@ -1422,7 +1523,7 @@ static int bn_bwd_rows_per_block(long long M) {
   return r;
 }
 int drs_bn_backward_rows(int B, int S, int C, int pool) {
-  if (pool) {
+  if (pool && slide_ok(C)) {
     const SlideCfg c = slide_cfg(B, S, C);
     return c.ncol * B * c.nstrips;
   }
@@ -1436,9 +1537,10 @@ int drs_bn_backward_reduce(const float* ga, int ld_ga, int coff_ga, const float*
   if (!ga || !z || !mean_rstd || !gxhat || !partial || C % 4 || (pool && !argmax)) return DRS_ERR_ARG;
   const int CQ = C / 4;
   if (CQ > 256) return DRS_ERR_ARG;
-  if (pool) {
+  if (pool && slide_ok(C)) {
     const SlideCfg c = slide_cfg(B, S, C);
-    const size_t shm = (size_t)c.TX * C * 2 * sizeof(float);
+    const size_t xchg = (size_t)2 * (c.TX + 2) * CQ * 20, redu = (size_t)c.TX * C * 2 * sizeof(float);
+    const size_t shm = xchg > redu ? xchg : redu;
     DRS_LAUNCH(bn_bwd_reduce_slide_kernel, dim3(c.ncol, B * c.nstrips), dim3(c.TX * CQ), shm, (hipStream_t)stream, ga, ld_ga, coff_ga, z,
                argmax, B, S, C, mean_rstd, alpha, gxhat, partial, c.nstrips, c.rps);
     return DRS_LAUNCH_CHECK();
@@ -1447,8 +1549,12 @@ int drs_bn_backward_reduce(const float* ga, int ld_ga, int coff_ga, const float*
   const int nblk = drs_bn_backward_rows(B, S, C, 0);
   const int rpb = bn_bwd_rows_per_block((long long)B * S * S);
   const size_t shm = (size_t)PT * C * 2 * sizeof(float);
-  DRS_LAUNCH(bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(CQ * PT), shm, (hipStream_t)stream, ga, ld_ga, coff_ga, z,
-             argmax, B, S, C, mean_rstd, alpha, gxhat, partial, rpb);
+  if (pool)       // wider than 512 channels: one column per workgroup, no neighbour to exchange with -- the gathering form
+    DRS_LAUNCH(bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(CQ * PT), shm, (hipStream_t)stream, ga, ld_ga, coff_ga, z,
+               argmax, B, S, C, mean_rstd, alpha, gxhat, partial, rpb);
+  else
+    DRS_LAUNCH(bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(CQ * PT), shm, (hipStream_t)stream, ga, ld_ga, coff_ga, z,
+               argmax, B, S, C, mean_rstd, alpha, gxhat, partial, rpb);
   return DRS_LAUNCH_CHECK();
 }
 
@@ -1491,6 +1597,8 @@ int drs_classifier_rows(int B, int S) {
 int g_cls_variant = 1;       // development switch (drs_debug_cls_variant): 1 = by the class count and width (below), 2 = register MFMA form always, 3 = LDS-DMA MFMA form where it fits, 0 = vector-ALU form always
 
 #ifdef DRS_DEV
+int drs_debug_slide_blocks(int v) { const int old = g_slide_blocks; if (v >= 0) g_slide_blocks = v; return old; }
+int drs_debug_slide_minrows(int v) { const int old = g_slide_minrows; if (v >= 1) g_slide_minrows = v; return old; }
 int drs_debug_cls_variant(int v) { const int old = g_cls_variant; if (v >= 0) g_cls_variant = v; return old; }
 #endif
 

@@ -103,4 +103,8 @@ int drs_rccl_comm_destroy(void* comm) {
   return report(r, "ncclCommDestroy", r->comm_destroy(comm));
 }
 
+int drs_rccl_all_reduce(void* comm, void* dev_ptr, size_t count, int dtype, void* stream) {
+  return drs_rccl_all_reduce_sum(comm, dev_ptr, count, dtype, (hipStream_t)stream);
+}
+
 }  // extern "C"

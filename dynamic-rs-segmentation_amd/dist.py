@@ -95,6 +95,16 @@ class TorchComm(object):
         if not torch.equal(lo, hi):
             raise RuntimeError("ranks disagree on %s: min %s max %s (rank %d has %s)" % (what, lo.tolist(), hi.tolist(), self.rank, t.tolist()))
 
+    def all_true(self, flag):
+        """True on every rank iff `flag` is true on every rank (collective decisions: which collectives path a net takes)"""
+        if self.world == 1:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
     def max_float(self, v, device):
         t = torch.tensor([float(v)], dtype=torch.float64, device=device)
         if self.world > 1:

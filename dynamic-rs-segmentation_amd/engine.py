@@ -107,18 +107,27 @@ class EngineNet(DilatedNet):
         rehearsals and CPU tests, DRS_COMM=torch, or RCCL not bindable) through the all-reduce callback into torch.distributed."""
         import os
         if getattr(self.comm, "backend", None) == "nccl" and os.environ.get("DRS_COMM", "rccl") != "torch":
-            try:
-                self._install_rccl()
+            err = None
+            if self.comm.all_true(bool(_lib.query("drs_rccl_available"))):
+                try:
+                    self._install_rccl()
+                except Exception as e:
+                    err = e
+            else:
+                err = _lib.DrsError("librccl could not be bound on every rank")
+            # the choice of path is itself collective: every rank takes the callback unless every rank holds two working communicators
+            ok = self.comm.all_true(err is None)
+            if ok:
+                _lib.call("drs_net_set_rccl", self.h, self.comm.world, self.comm.rank, self._rccl[0], self._rccl[1], None)
+                self.collectives = "rccl"
                 return
-            except Exception as e:
-                if os.environ.get("DRS_COMM") == "rccl":
-                    raise
-                print("drs: library-side RCCL collectives unavailable (%r); using the torch.distributed callback" % (e,))
+            if os.environ.get("DRS_COMM") == "rccl":
+                raise err or _lib.DrsError("library-side RCCL collectives failed on another rank")
+            if self.comm.rank == 0 or err is not None:
+                print("drs: library-side RCCL collectives unavailable (%r on rank %d); using the torch.distributed callback" % (err, self.comm.rank))
         self._install_callback()
 
     def _install_rccl(self):
-        if not _lib.query("drs_rccl_available"):
-            raise _lib.DrsError("librccl could not be bound")
         ids = []
         for _ in range(2):                      # small (latency-bound sums) and big (gradient buckets) communicators
             buf = (C.c_ubyte * 128)()
@@ -131,8 +140,18 @@ class EngineNet(DilatedNet):
             h = C.c_void_p()
             _lib.call("drs_rccl_comm_create", self.comm.world, self.comm.rank, (C.c_ubyte * 128).from_buffer_copy(raw), C.byref(h))
             self._rccl.append(h)
-        _lib.call("drs_net_set_rccl", self.h, self.comm.world, self.comm.rank, self._rccl[0], self._rccl[1], None)
-        self.collectives = "rccl"
+        # known-answer check of both communicators through the call the step engine issues, in each of its three types
+        W, r = self.comm.world, self.comm.rank
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        bad = []
+        for h in self._rccl:                   # (every rank issues all six, whatever it finds: the calls are collective)
+            for dt, code in ((torch.float32, 0), (torch.float64, 1), (torch.int32, 3)):
+                t = torch.tensor([r + 1, 1, -(r + 1) * 3], dtype=dt, device=self.dev)
+                _lib.call("drs_rccl_all_reduce", h, t.data_ptr(), 3, code, st)
+                if t.cpu().tolist() != [W * (W + 1) // 2, W, -3 * (W * (W + 1) // 2)]:
+                    bad.append((str(dt), t.cpu().tolist()))
+        if bad:
+            raise _lib.DrsError("library-side RCCL all-reduce at world %d returned %s" % (W, bad))
 
     def _install_callback(self):
         self.collectives = "callback"

@@ -83,6 +83,10 @@ class NoComm(object):
         pass
 
     @staticmethod
+    def all_true(flag):
+        return bool(flag)
+
+    @staticmethod
     def barrier():
         pass
 

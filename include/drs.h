@@ -302,11 +302,14 @@ int drs_net_set_comm(drs_net_t* net, int world, int rank, drs_allreduce_fn allre
  * library creates one).  The communicators remain the caller's (destroy them after the net).  comm_small = NULL undoes it.
  *   drs_rccl_available : 1 if librccl could be bound.
  *   drs_rccl_unique_id : ncclGetUniqueId into id128 (128 bytes, host memory); rank 0 calls it, the host hands the bytes to every rank.
- *   drs_rccl_comm_create / _destroy : ncclCommInitRank / ncclCommDestroy (collective over the ranks; the device must be current). */
+ *   drs_rccl_comm_create / _destroy : ncclCommInitRank / ncclCommDestroy (collective over the ranks; the device must be current).
+ *   drs_rccl_all_reduce : one in-place sum over the ranks on `stream` (dtype as in drs_net_buffer_info: 0 f32, 1 f64, 3 i32) -- the
+ *                         call the step engine issues; the host uses it to check a new communicator before handing it over. */
 int drs_rccl_available(void);
 int drs_rccl_unique_id(unsigned char* id128);
 int drs_rccl_comm_create(int world, int rank, const unsigned char* id128, void** comm);
 int drs_rccl_comm_destroy(void* comm);
+int drs_rccl_all_reduce(void* comm, void* dev_ptr, size_t count, int dtype, void* stream);
 int drs_net_set_rccl(drs_net_t* net, int world, int rank, void* comm_small, void* comm_big, void* comm_stream);
 int drs_train_step(drs_net_t* net, int B, int S, float lr0, int flags, double global_pixels, void* stream);
 int drs_forward(drs_net_t* net, int B, int S, int flags, int ignore_label, void* stream);
