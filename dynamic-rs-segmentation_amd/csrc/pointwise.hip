@@ -702,7 +702,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ gxh, const float* 
   // per-channel coefficients once per workgroup (they used to be 8 fp64 divisions and 96 bytes of loads per THREAD, for 48 bytes of
   // payload: the kernel was bound by that arithmetic, not by memory): [mu | rstd | sum g / N | sum g xhat / N][C], so that a
   // thread's four channels are one 16-byte LDS read per coefficient.  Same expressions, same rounding as before.
-  __shared__ __attribute__((aligned(16))) float coef[4 * 448];
+  extern __shared__ __attribute__((aligned(16))) float coef[];               // [4][C]
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     coef[c] = mean_rstd[2 * c];
     coef[C + c] = mean_rstd[2 * c + 1];
@@ -1561,7 +1561,7 @@ int drs_bn_backward_reduce(const float* ga, int ld_ga, int coff_ga, const float*
 static int bn_backward_apply_impl(const float* gxhat, const float* z, int B, int S, int C, const float* mean_rstd,
                                   const double* sums, double count, float* gz, int P_out, int ld_out, int coff_out,
                                   unsigned short* terms, int nterms, void* stream) {
-  if (!gxhat || !z || !mean_rstd || !sums || (!gz && !terms) || C % 4 || C > 448) return DRS_ERR_ARG;
+  if (!gxhat || !z || !mean_rstd || !sums || (!gz && !terms) || C % 4 || C > 1024) return DRS_ERR_ARG;
   if (terms && ((nterms != 2 && nterms != 3) || (ld_out & 31) || (coff_out & 31))) return DRS_ERR_ARG;
   const int Sp = S + 2 * P_out;
   if ((long long)B * Sp > 65535) return DRS_ERR_ARG;
@@ -1569,7 +1569,8 @@ static int bn_backward_apply_impl(const float* gxhat, const float* z, int B, int
   dim3 grid((per_row + 255) / 256, B * Sp);
   ActView v = mkview(gz, S, P_out, ld_out, coff_out);
   v.terms = terms; v.nt = terms ? nterms : 0;
-  DRS_LAUNCH(bn_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, gxhat, z, B, S, C, mean_rstd, sums, count, v);
+  DRS_LAUNCH(bn_bwd_apply_kernel, grid, dim3(256), (size_t)4 * C * sizeof(float), (hipStream_t)stream, gxhat, z, B, S, C, mean_rstd, sums,
+             count, v);
   return DRS_LAUNCH_CHECK();
 }
 
