@@ -412,15 +412,18 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
     if (!SK || (kb == 0 && ke == nks)) {
       conv_epilogue<BM, BN, WM, WN>(a, acc, lds, m0, n0);
     } else {
-      // partial sums of a tile this workgroup shares with others: a piece of the slab in accumulator order (256-byte stores);
-      // a workgroup has at most two such segments, its first (piece 2 w) and its last (piece 2 w + 1)
-      float* piece = a.sk_slab + (size_t)(2 * wg + (first_seg ? 0 : 1)) * (BM * BN) + (size_t)wave * (TM * TN * 16 * 64) + lane;
+      // partial sums of a tile this workgroup shares with others: a piece of the slab in accumulator order, four registers per
+      // access ([fragment quad][lane][4]: 1-KB wave stores); a workgroup has at most two such segments, its first (piece 2 w)
+      // and its last (piece 2 w + 1)
+      float* piece = a.sk_slab + (size_t)(2 * wg + (first_seg ? 0 : 1)) * (BM * BN) + (size_t)wave * (TM * TN * 16 * 64) + lane * 4;
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) piece[((mi * TN + ni) * 16 + r) * 64] = acc[mi][ni][r];
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4*>(piece + ((mi * TN + ni) * 4 + q) * 256) =
+                f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
     }
     if (!SK) break;
     u += ke - kb;
@@ -456,13 +459,17 @@ __global__ __launch_bounds__(256) void conv_sk_fixup_kernel(const ConvArgs a) {
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
   for (int w = w_first; w <= w_last; ++w) {
     const int slot = 2 * w + (sk_first_unit(w, a.sk_U, a.sk_W) >= x0 ? 0 : 1);      // the workgroup's first segment, or its last
-    const float* piece = a.sk_slab + (size_t)slot * (BM * BN) + (size_t)wave * (TM * TN * 16 * 64) + lane;
+    const float* piece = a.sk_slab + (size_t)slot * (BM * BN) + (size_t)wave * (TM * TN * 16 * 64) + lane * 4;
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
       for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][ni][r] += piece[((mi * TN + ni) * 16 + r) * 64];
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(piece + ((mi * TN + ni) * 4 + q) * 256);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[mi][ni][4 * q + j] += v[j];
+        }
   }
   conv_epilogue<BM, BN, WM, WN>(a, acc, lds, m0, n0);
 }
@@ -1094,7 +1101,7 @@ template <int BM, int BN, int WM, int WN>
 int launch_conv_dma(ConvArgs& a, float* ws, size_t ws_floats, hipStream_t st) {
   const int mt = (a.M + BM - 1) / BM, nt = a.Cout / BN;
   const int nks = a.k * a.k * (a.Cin / BK);
-  const int W = ws ? sk_workgroups(mt * nt, nks, BN, ws_floats) : 0;
+  const int W = ws && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 ? sk_workgroups(mt * nt, nks, BN, ws_floats) : 0;   // (16-byte piece accesses)
   a.sk_W = W; a.sk_nks = nks; a.sk_U = mt * nt * nks; a.sk_slab = ws;
   if (W) DRS_LAUNCH((conv_dma_kernel<BM, BN, WM, WN, true>), dim3(W), dim3(256), 0, st, a);
   else DRS_LAUNCH((conv_dma_kernel<BM, BN, WM, WN, false>), dim3(mt * nt), dim3(256), 0, st, a);
