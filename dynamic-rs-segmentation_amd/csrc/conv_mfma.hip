@@ -1045,6 +1045,32 @@ __global__ void flip_transpose_kernel(const float* __restrict__ w, float* __rest
   }
 }
 
+// What a training step needs done between its forward and its backward pass, in ONE launch (the step engine; at a per-rank batch
+// of 16 small patches a step is ~100 launches of ~15 us and every launch counts): the flipped / transposed filter of every layer
+// with an input gradient (blockIdx.y = entry) and two zero fills (the confusion matrix; the conv-bias gradients).
+__global__ void step_prep_kernel(const StepPrepArgs a) {
+  const int e = blockIdx.y;
+  const int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  if (e < a.n) {
+    const int k = a.k[e], cin = a.cin[e], cout = a.cout[e];
+    const float* __restrict__ w = a.w[e];
+    float* __restrict__ wt = a.wt[e];
+    const int n = k * k * cin * cout;
+    for (int i = i0; i < n; i += stride) {
+      const int c = i % cin;
+      int rest = i / cin;
+      const int o = rest % cout;
+      rest /= cout;
+      const int v = rest % k, u = rest / k;
+      wt[i] = w[(((k - 1 - u) * k + (k - 1 - v)) * cin + c) * cout + o];
+    }
+  } else if (e == a.n) {
+    for (int i = i0; i < a.nz0; i += stride) a.z0[i] = 0u;
+  } else {
+    for (int i = i0; i < a.nz1; i += stride) a.z1[i] = 0.f;
+  }
+}
+
 // Wp[tap][c < cin_pad][o] = c < cin ? W[tap][c][o] : 0
 __global__ void pad_cin_kernel(const float* __restrict__ w, float* __restrict__ wp, int taps, int cin, int cin_pad, int cout) {
   const int n = taps * cin_pad * cout;
@@ -1144,6 +1170,14 @@ int launch_wgrad_dma_only(const WgradArgs& a, int nwg, hipStream_t st) {
 }
 
 }  // namespace
+
+// (used by engine.hip)
+__attribute__((visibility("hidden"))) int drs_step_prep(const StepPrepArgs& a, hipStream_t stream) {
+  if (a.n < 0 || a.n > STEP_PREP_MAX) return DRS_ERR_ARG;
+  DRS_LAUNCH(step_prep_kernel, dim3(512, a.n + 2), dim3(256), 0, stream, a);
+  return DRS_LAUNCH_CHECK();
+}
+
 
 int drs_g_skip_halo_taps = 1;
 

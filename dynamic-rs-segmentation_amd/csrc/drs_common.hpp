@@ -59,6 +59,17 @@ __device__ __forceinline__ uint32_t padded_pixel_off(int p, int S, int P, int ld
   return (uint32_t)(((b * Sp + y + P + dy) * Sp + (x + P + dx))) * (uint32_t)ld;
 }
 
+// drs_step_prep (conv_mfma.hip; the step engine's one launch between forward and backward)
+constexpr int STEP_PREP_MAX = 24;
+struct StepPrepArgs {
+  const float* w[STEP_PREP_MAX];      // filters [k][k][cin][cout] ...
+  float* wt[STEP_PREP_MAX];           // ... flipped and transposed into [k][k][cout][cin]
+  int k[STEP_PREP_MAX], cin[STEP_PREP_MAX], cout[STEP_PREP_MAX];
+  int n;
+  unsigned int* z0; int nz0;          // zero fills
+  float* z1; int nz1;
+};
+
 // Filter-tap rows whose whole input row range lies in the zero halo contribute exact zeros to every pixel of an M tile:
 // for the tile of pixels [m0, m0 + BM) (clipped to M) return the range [lo, hi) of tap rows u, dy = u * rate - pad, for
 // which some pixel row y of the tile has 0 <= y + dy < S.  A tile that crosses an image boundary keeps every tap row.

@@ -25,6 +25,7 @@
 #include <string>
 #include <vector>
 
+__attribute__((visibility("hidden"))) int drs_step_prep(const StepPrepArgs& a, hipStream_t stream);      // conv_mfma.hip
 __attribute__((visibility("hidden"))) int drs_rccl_all_reduce_sum(void* comm, void* ptr, size_t count, int dtype, hipStream_t stream);      // rccl_comm.hip
 
 namespace {
@@ -793,17 +794,31 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
   float* params = n->p<float>("params");
   float* grads = n->p<float>("grads");
   const int nL = (int)n->layers.size();
-  for (int i = 1; i < nL; ++i) {
-    const Layer& L = n->layers[i];
-    DRS_TRY(drs_filter_flip_transpose(params + L.w_off, n->p<float>("wt" + std::to_string(i)), L.k, L.cin, L.cout, st));
+  unsigned int* conf = n->p<unsigned int>("conf");
+  {
+    // one launch: the flipped / transposed filters of the input-gradient passes, the confusion matrix zeroed, and the gradients of
+    // the conv biases zeroed (they sit in front of a mean-subtracting batch norm: their gradient is identically zero)
+    StepPrepArgs pa;
+    pa.n = 0;
+    for (int i = 1; i < nL; ++i) {
+      const Layer& L = n->layers[i];
+      if (pa.n == STEP_PREP_MAX) {                       // (deeper nets than any of the reference's: the rest one by one)
+        DRS_TRY(drs_filter_flip_transpose(params + L.w_off, n->p<float>("wt" + std::to_string(i)), L.k, L.cin, L.cout, st));
+        continue;
+      }
+      pa.w[pa.n] = params + L.w_off; pa.wt[pa.n] = n->p<float>("wt" + std::to_string(i));
+      pa.k[pa.n] = L.k; pa.cin[pa.n] = L.cin; pa.cout[pa.n] = L.cout;
+      ++pa.n;
+    }
+    pa.z0 = conf; pa.nz0 = n->K * n->K;
+    pa.z1 = grads + n->first_bias; pa.nz1 = (int)(n->cls_b - n->first_bias);
+    DRS_TRY(drs_step_prep(pa, st));
   }
   // classifier + loss + gradient wrt the features
   const Slab& f = n->slabs[n->feat];
   float* gfeat = n->p<float>("gact:" + f.name);
-  unsigned int* conf = n->p<unsigned int>("conf");
   double* scalars = n->p<double>("scalars");
   double* scratch = n->p<double>("colsum_scratch");
-  if (hipMemsetAsync(conf, 0, sizeof(unsigned int) * n->K * n->K, st) != hipSuccess) return DRS_ERR_HIP;
   {
     Timed t(n, st, K_CLS, M * n->c_last * 8.0);
     DRS_TRY(drs_classifier_loss(n->p<float>("act:" + f.name), B, S, f.P, f.C, 0, n->c_last, n->K, params + n->cls_w, params + n->cls_b,
@@ -817,8 +832,6 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
   DRS_TRY(drs_rows_reduce_f32(n->p<float>("db_partial"), crow, n->K, grads + n->cls_b, scratch, st));
   DRS_TRY(drs_sum_f64(n->p<double>("loss_partial"), crow, scalars, st));
   DRS_TRY(drs_l2_loss(params, n->n_decay, n->p<double>("l2_scratch"), scalars + 1, st));
-  // conv biases sit in front of a mean-subtracting batch norm: their gradient is identically zero
-  if (hipMemsetAsync(grads + n->first_bias, 0, sizeof(float) * (n->cls_b - n->first_bias), st) != hipSuccess) return DRS_ERR_HIP;
   // gradient all-reduce in buckets that overlap the rest of the backward pass: kernel gradients go as their layers finish, last
   // layers first; the small classifier / SE / bias tail goes last
   std::vector<int> pending;
