@@ -198,12 +198,15 @@ def per_rank_size_table(dev, pool, mean, std, sizes=(25, 35, 45, 55, 65, 75, 85)
             return net.train_step(B, S, LR)
         for i in range(3):
             step(i)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            step(i)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
+        dts = []
+        for _ in range(3):               # three blocks of `steps`, the median block: one host hiccup in a 20..100 ms block is not the GPU's step
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step(i)
+            torch.cuda.synchronize()
+            dts.append((time.perf_counter() - t0) / steps)
+        dt = sorted(dts)[1]
         net.timer = KernelTimer()
         for i in range(3):
             step(i)
