@@ -9,7 +9,6 @@ tests/test_gpu_engine.py.
 """
 import ctypes as C
 
-import numpy as np
 import torch
 
 from . import _lib
