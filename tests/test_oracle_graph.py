@@ -128,3 +128,76 @@ def test_lr_schedule_and_pool_ties():
     assert idx[0, 0, 0, 0] == 4 and idx[0, 1, 1, 0] == 0 and idx[0, 2, 2, 0] == 0 and idx[0, 0, 2, 0] == 3
     g = T.max_pool_3x3_bwd(idx, np.ones_like(x))
     assert g.sum() == 9 and g[0, 0, 0, 0] == 4
+
+
+# --------------------------------------------------------------------------- TensorFlow's own formulation of the dilated convolution
+def _space_to_batch(x, pads, r):
+    """tf.space_to_batch(input, paddings, block_size): zero-pad H and W, then move the r x r phases of the padded grid into the
+    batch: out[(dy * r + dx) * B + b, i, j, c] = padded[b, i * r + dy, j * r + dx, c]   (TF 1.x documentation of the op)"""
+    (pt, pb), (pl, pr) = pads
+    B, H, W, C = x.shape
+    xp = np.zeros((B, H + pt + pb, W + pl + pr, C), dtype=x.dtype)
+    xp[:, pt:pt + H, pl:pl + W] = x
+    Hp, Wp = xp.shape[1:3]
+    assert Hp % r == 0 and Wp % r == 0
+    out = np.zeros((r * r * B, Hp // r, Wp // r, C), dtype=x.dtype)
+    for dy in range(r):
+        for dx in range(r):
+            out[(dy * r + dx) * B:(dy * r + dx + 1) * B] = xp[:, dy::r, dx::r]
+    return out
+
+
+def _batch_to_space(y, crops, r, B):
+    """tf.batch_to_space(input, crops, block_size): the inverse interleave, then crop"""
+    (ct, cb), (cl, cr) = crops
+    _, h, w, C = y.shape
+    full = np.zeros((B, h * r, w * r, C), dtype=y.dtype)
+    for dy in range(r):
+        for dx in range(r):
+            full[:, dy::r, dx::r] = y[(dy * r + dx) * B:(dy * r + dx + 1) * B]
+    return full[:, ct:full.shape[1] - cb, cl:full.shape[2] - cr]
+
+
+def _conv2d_valid(x, w):
+    k = w.shape[0]
+    B, H, W, C = x.shape
+    out = np.zeros((B, H - k + 1, W - k + 1, w.shape[3]), dtype=x.dtype)
+    for u in range(k):
+        for v in range(k):
+            out += x[:, u:u + H - k + 1, v:v + W - k + 1] @ w[u, v]
+    return out
+
+
+def _atrous_conv2d_same_tf(x, w, rate):
+    """tf.nn.atrous_conv2d(value, filters, rate, padding='SAME') the way TensorFlow 1.x computes it (the algorithm its
+    documentation and nn_ops.atrous_conv2d state): the up-sampled filter has k + (k-1)(rate-1) taps, SAME pads that extent minus
+    one, the odd pixel going to the bottom / right "following the same convention as conv2d()"; the padded input is extended to a
+    multiple of `rate`, space_to_batch moves the rate x rate phases into the batch, an ordinary VALID convolution runs on every
+    phase, batch_to_space interleaves the phases back and crops the extension."""
+    k = w.shape[0]
+    H, W = x.shape[1:3]
+    k_up = k + (k - 1) * (rate - 1)
+    pad = k_up - 1
+    pt = pl = pad // 2
+    pb = pr = pad - pad // 2
+    eh = (rate - (H + pt + pb) % rate) % rate
+    ew = (rate - (W + pl + pr) % rate) % rate
+    s2b = _space_to_batch(x, ((pt, pb + eh), (pl, pr + ew)), rate)
+    y = _conv2d_valid(s2b, w)
+    return _batch_to_space(y, ((0, eh), (0, ew)), rate, x.shape[0])
+
+
+@pytest.mark.parametrize("k,rate,H,W", [(4, 3, 11, 13), (4, 4, 10, 9), (5, 2, 9, 12), (3, 8, 17, 20), (3, 5, 12, 7), (3, 7, 25, 25),
+                                        (4, 2, 8, 8), (3, 6, 6, 5), (5, 1, 7, 9)])
+def test_dilated_conv_matches_tensorflows_space_to_batch_formulation(k, rate, H, W):
+    """the oracle's direct form (one shifted product per tap, SAME split computed on the dilated extent) against an independent
+    restatement of the algorithm TensorFlow 1.x publishes for tf.nn.atrous_conv2d -- every (kernel, rate) pair of the three scripts'
+    nets (isprs:766-777, 966-981, 1001-1020; coffee:721-841), on sides that are not multiples of the rate.  The even kernels are the
+    interesting ones: 4 x 4 at rate 3 pads 4 before and 5 after."""
+    rng = np.random.default_rng(k * 100 + rate)
+    x = rng.normal(size=(2, H, W, 3))
+    w = rng.normal(size=(k, k, 3, 4))
+    got = T.conv2d_same(x, w, rate)
+    ref = _atrous_conv2d_same_tf(x, w, rate)
+    assert got.shape == ref.shape == (2, H, W, 4)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)
