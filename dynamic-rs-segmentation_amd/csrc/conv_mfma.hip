@@ -924,13 +924,17 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
         __builtin_amdgcn_global_load_lds(gbase + (tabg[slot][half * HP + gpix[i]] + goff[i]), (lds_ptr)(sg + (wave + NW * i) * 256), 16, 0, 0);
     }
   };
-  // pixels past the end (only in the last chunk) were fetched from a clamped address: their G rows must read as zero
+  // pixels past the end (only in the last chunk) were fetched from a clamped address: their G rows must read as zero.  Called AFTER
+  // the barrier that follows every wave's `s_waitcnt vmcnt(0)`: a thread zeroes rows that ANOTHER wave's DMA wrote, so all of the
+  // stage's DMA must have landed first (zeroing after only this wave's own wait let a late DMA put the clamped row back on top of
+  // the zeros -- harmless-looking alone, a run-to-run difference as soon as another kernel shared the chip: tools/soak.py), and a
+  // second barrier publishes the zeros before anybody multiplies.  `chunk` is uniform over the workgroup, so are the barriers.
   auto zero_tail = [&](int chunk, int half, int stage) {
     if (chunk != clast) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float* sg = lds + stage * STAGE + XSTAGE;
     for (int e = t; e < HP * TO; e += NT)
       if (chunk * BP + half * HP + e / TO >= a.M) sg[e] = 0.f;
+    __syncthreads();
   };
   const int xr = wr * WTR + li, gc = wc * WTO + li;
   auto compute = [&](int stage) {
@@ -970,22 +974,22 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
     int cB = w.c;
     chunk_bases(xbB, gbB);
     fill_tables(1, stepped);
-    zero_tail(cA, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA has landed; the barrier then publishes everybody's
     __syncthreads();
+    zero_tail(cA, 0, 0);
     for (int it = 0; cA < cend; ++it) {
       issue(xbA, gbA, it & 1, 1, 1);             // second half of A -> stage 1, lands while stage 0 is multiplied
       compute(0);
-      zero_tail(cA, 1, 1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      zero_tail(cA, 1, 1);
       if (cB < cend) issue(xbB, gbB, (it + 1) & 1, 0, 0);      // first half of B -> stage 0 (every wave is done with it)
       stepped = w.advance();                     // ... and on C, whose table goes into the slot A's table was in
       compute(1);
       fill_tables(it & 1, stepped);
-      if (cB < cend) zero_tail(cB, 0, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      if (cB < cend) zero_tail(cB, 0, 0);
       cA = cB; xbA = xbB; gbA = gbB;
       cB = w.c;
       chunk_bases(xbB, gbB);

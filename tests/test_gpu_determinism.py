@@ -1,0 +1,49 @@
+"""-m gpu: the step engine is bitwise reproducible from run to run in the regime that runs kernels side by side.
+
+Below 2^18 pixels the backward pass puts the filter gradients on a stream of their own beside the batch-norm backward / input
+gradient chain (csrc/engine.hip), so kernels share the chip and their timing varies from run to run; every promise of a fixed
+summation order has to survive that.  Two identical runs of a training loop with the patch side drawn per step (isprs:1727-1737:
+ragged pixel counts, stream-K cuts, partial last chunks of the filter gradient) must agree bit for bit in every loss and every
+variable.  (Round 3: this is the test that found wgrad_dma_kernel zeroing the tail rows of its last chunk before the other waves'
+LDS-DMA had landed -- deterministic alone, a run-to-run difference under concurrency.  tools/soak.py is the long form.)"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import DEV   # noqa: E402
+
+
+def _run(B, steps, sizes, pool):
+    from drs_amd.net import DilatedNet
+    from drs_amd import patches as P
+    from drs_amd.synthetic import grid_instances
+    net = DilatedNet("dilated_grsl_rate8", 5, 6, 0.005, b_max=B, s_max=max(sizes), device=DEV, seed=42)
+    rng = np.random.default_rng(7)
+    np.random.seed(11)
+    inst = {S: grid_instances(512, 512, S, 25, 1024, seed=S) for S in sizes}
+    losses = torch.zeros(steps, 2, dtype=torch.float64, device=DEV)
+    for i in range(steps):
+        S = int(sizes[rng.integers(0, len(sizes))])
+        rows = inst[S][(i * B) % 900:(i * B) % 900 + B]
+        aug = P.draw_augmentation(rows, S, 5, noise="device")
+        P.crop_to_net(net, pool, rows, S, [0.5] * 3, [0.2] * 3, aug)
+        losses[i] = net.train_step(B, S, 0.01)["loss_parts"]
+    torch.cuda.synchronize()
+    state = torch.cat([net.params.flatten(), net.mom.flatten(), net.bn.flatten()]).cpu().numpy()
+    return losses.cpu().numpy(), state
+
+
+@pytest.mark.parametrize("B,sizes,steps", [(16, (25, 33, 38, 45, 55, 61), 160), (8, (75, 85), 60)])
+def test_two_runs_of_a_mixed_size_training_loop_agree_bit_for_bit(B, sizes, steps):
+    from drs_amd import patches as P
+    from drs_amd.synthetic import make_tile
+    tile, lab = make_tile(512, 512, 5, 6, seed=1234)
+    pool = P.TilePool([tile], [lab], DEV)
+    l1, s1 = _run(B, steps, sizes, pool)
+    l2, s2 = _run(B, steps, sizes, pool)
+    assert np.isfinite(l1).all() and np.isfinite(s1).all()
+    diff = np.nonzero((l1 != l2).any(axis=1))[0]
+    assert diff.size == 0, "losses differ from step %d on" % diff[0]
+    assert np.array_equal(s1, s2)
