@@ -2,7 +2,7 @@
 """Soak / determinism run of the step engine in the per-rank regime: `steps` training steps at batch B with the patch side drawn
 uniformly from [lo, hi] per step (isprs:1727-1737), run TWICE from the same seeds; the two runs must agree bit for bit in every
 loss and in the final variables (stream-K cuts, the two-stream backward pass, the LDS-exchange BN kernels and the fixed-order
-reductions all promise that), and the loss must stay finite.   python tools/soak.py [B=16] [steps=1500] [lo=25] [hi=85]"""
+reductions all promise that), and the loss must stay finite.   python tools/soak.py [B=16] [steps=1500] [lo=25] [hi=85] [net=dilated_grsl_rate8 channels=5 classes=6]"""
 import os, sys, time
 import numpy as np
 import torch
@@ -12,8 +12,8 @@ from drs_amd import patches as P
 from drs_amd.synthetic import make_tile, grid_instances
 
 
-def run(B, steps, lo, hi, pool, dev):
-    net = DilatedNet("dilated_grsl_rate8", 5, 6, 0.005, b_max=B, s_max=hi, device=dev, seed=42)
+def run(B, steps, lo, hi, pool, dev, net_type="dilated_grsl_rate8", channels=5, classes=6):
+    net = DilatedNet(net_type, channels, classes, 0.005, b_max=B, s_max=hi, device=dev, seed=42)
     rng = np.random.default_rng(7)
     np.random.seed(11)
     inst = {}
@@ -24,7 +24,7 @@ def run(B, steps, lo, hi, pool, dev):
         if S not in inst:
             inst[S] = grid_instances(1024, 1024, S, 25, 4096, seed=S)
         rows = inst[S][(i * B) % 4000:(i * B) % 4000 + B]
-        aug = P.draw_augmentation(rows, S, 5, noise="device")
+        aug = P.draw_augmentation(rows, S, channels, noise="device")
         P.crop_to_net(net, pool, rows, S, [0.5] * 3, [0.2] * 3, aug)
         out = net.train_step(B, S, 0.01)
         losses[i] = out["loss_parts"]
@@ -34,15 +34,15 @@ def run(B, steps, lo, hi, pool, dev):
     return losses.cpu().numpy(), params.cpu().numpy(), dt
 
 
-def main(B=16, steps=1500, lo=25, hi=85):
+def main(B=16, steps=1500, lo=25, hi=85, net_type="dilated_grsl_rate8", channels=5, classes=6):
     dev = "cuda:0"
-    tile, lab = make_tile(1024, 1024, 5, 6, seed=1234)
+    tile, lab = make_tile(1024, 1024, channels, classes, seed=1234)
     pool = P.TilePool([tile], [lab], dev)
-    l1, p1, t1 = run(B, steps, lo, hi, pool, dev)
-    l2, p2, t2 = run(B, steps, lo, hi, pool, dev)
+    l1, p1, t1 = run(B, steps, lo, hi, pool, dev, net_type, channels, classes)
+    l2, p2, t2 = run(B, steps, lo, hi, pool, dev, net_type, channels, classes)
     ok = np.isfinite(l1).all() and np.isfinite(p1).all()
     same = np.array_equal(l1, l2) and np.array_equal(p1, p2)
-    print("B=%d, %d steps, sides uniform in [%d, %d]: %.1f s and %.1f s; CE first 10 steps %.4f, last 10 steps %.4f; finite: %s; the two runs "
+    print(net_type + " B=%d, %d steps, sides uniform in [%d, %d]: %.1f s and %.1f s; CE first 10 steps %.4f, last 10 steps %.4f; finite: %s; the two runs "
           "agree bit for bit (every loss, all %d variables): %s" % (B, steps, lo, hi, t1, t2, l1[:10, 0].mean(), l1[-10:, 0].mean(), ok, p1.size, same))
     if not (ok and same):
         bad = np.nonzero((l1 != l2).any(axis=1))[0]
@@ -52,4 +52,5 @@ def main(B=16, steps=1500, lo=25, hi=85):
 
 if __name__ == "__main__":
     kw = dict(a.split("=") for a in sys.argv[1:])
-    main(int(kw.get("B", 16)), int(kw.get("steps", 1500)), int(kw.get("lo", 25)), int(kw.get("hi", 85)))
+    main(int(kw.get("B", 16)), int(kw.get("steps", 1500)), int(kw.get("lo", 25)), int(kw.get("hi", 85)), kw.get("net", "dilated_grsl_rate8"),
+         int(kw.get("channels", 5)), int(kw.get("classes", 6)))
