@@ -47,3 +47,50 @@ def test_two_runs_of_a_mixed_size_training_loop_agree_bit_for_bit(B, sizes, step
     diff = np.nonzero((l1 != l2).any(axis=1))[0]
     assert diff.size == 0, "losses differ from step %d on" % diff[0]
     assert np.array_equal(s1, s2)
+
+
+KEEP = ("params", "momentum", "bn", "labels", "acc_mask", "loss_mask", "w0pad")
+
+
+def _steps(net_type, channels, classes, B, S, poison, pool):
+    from drs_amd.net import DilatedNet
+    from drs_amd import patches as P
+    from drs_amd.synthetic import grid_instances
+    net = DilatedNet(net_type, channels, classes, 0.005, b_max=B, s_max=S, device=DEV, seed=42)
+    inst = grid_instances(512, 512, S, 25, 512, seed=3)
+    np.random.seed(5)
+    outs = []
+    for i in range(3):
+        rows = inst[i * B:(i + 1) * B]
+        aug = P.draw_augmentation(rows, S, channels, noise="device")
+        if poison:
+            for name, t in net._bufs.items():
+                if name in KEEP or name.startswith("act:"):        # state that persists; the activation slabs' zero halos
+                    continue
+                if t.dtype in (torch.float32, torch.float64):
+                    t.fill_(float("nan"))
+                else:
+                    t.fill_(-1 if t.dtype in (torch.int32, torch.int64) else 255)
+        P.crop_to_net(net, pool, rows, S, [0.5] * 3, [0.2] * 3, aug)
+        o = net.train_step(B, S, 0.01)
+        torch.cuda.synchronize()
+        outs.append((o["loss_parts"].clone().cpu().numpy(), o["pred"].clone().cpu().numpy(), o["conf"].clone().cpu().numpy()))
+    return outs, torch.cat([net.params.flatten(), net.mom.flatten(), net.bn.flatten()]).cpu().numpy()
+
+
+@pytest.mark.parametrize("net_type,channels,classes,B,S", [("dilated_grsl_rate8", 5, 6, 16, 37), ("dilated_icpr_rate6_densely", 4, 2, 16, 41),
+                                                           ("dilated_icpr_rate6_SE", 3, 6, 8, 30), ("dilated_icpr_rate6_squeeze", 3, 6, 8, 33)])
+def test_a_step_reads_no_scratch_it_has_not_written(net_type, channels, classes, B, S):
+    """every scratch buffer of the step engine (partial-sum slabs, the stream-K workspace, gradient slabs, raw conv outputs, pool
+    positions, gradient / logits / prediction buffers, ...) filled with NaN / 0xFF before each of three steps: same bits as without"""
+    from drs_amd import patches as P
+    from drs_amd.synthetic import make_tile
+    tile, lab = make_tile(512, 512, channels, classes, seed=1234)
+    pool = P.TilePool([tile], [lab], DEV)
+    a, sa = _steps(net_type, channels, classes, B, S, False, pool)
+    b, sb = _steps(net_type, channels, classes, B, S, True, pool)
+    assert np.isfinite(sa).all()
+    for i, (x, y) in enumerate(zip(a, b)):
+        for j in range(3):
+            assert np.array_equal(x[j], y[j]), (i, j)
+    assert np.array_equal(sa, sb)
