@@ -146,6 +146,30 @@ def _check_eval_and_train(net, ch, K, B, S, arith):
     np.testing.assert_array_equal(out["conf"].cpu().numpy(), cm)
 
 
+@pytest.mark.parametrize("net,ch,K", [("dilated8_grsl", 5, 6), ("dilated_icpr_rate6_densely", 4, 2)])
+def test_training_trajectory_with_batch_and_side_changing_every_step(net, ch, K):
+    """isprs:1727-1737 draws a patch side per step: one net instance sees its slabs re-used at every size (zero halos that move,
+    gradient slabs of other extents, stream-K cuts that come and go, the two-stream backward pass).  Six steps with the batch and
+    the side changing every time, each against the oracle stepping the same sequence, then every variable and momentum slot."""
+    o, d, _, _ = _mk(net, ch, K, 5, 31, 4)
+    rng = np.random.default_rng(21)
+    for step, (B, S) in enumerate([(5, 31), (2, 9), (4, 26), (1, 31), (5, 12), (3, 25)]):
+        x = rng.normal(size=(B, S, S, ch)).astype(np.float32)
+        y = rng.integers(0, K, size=(B, S, S))
+        d.feed(x.reshape(B, -1), y.reshape(B, -1), S)
+        out = d.train_step(B, S, 0.01)
+        torch.cuda.synchronize()
+        lo, _ = o.train_step(x.astype(np.float64), y, 0.01, 0.005, decisions=_decisions(d, B, S))
+        assert abs(d.loss_value(out["loss_parts"]) - lo) < 1e-4 * abs(lo), (step, B, S)
+    for n in d.plan.offsets:
+        assert rel_err(d.get_variable(n), o.p[n]) < 1e-4, n
+        if not (n.endswith("/biases") and n != "conv_classifier/biases"):
+            assert rel_err(d.get_variable(n, "Momentum"), o.mom[n]) < 1e-3, n
+    for n in d.variable_names():
+        if "moving" in n:
+            assert rel_err(d.get_variable(n), o.p[n]) < 1e-5, n
+
+
 @pytest.mark.parametrize("arith", ["f32", "bf16x3", "bf16x6"])
 def test_training_trajectory_matches_oracle(arith):
     net, ch, K, B, S = "dilated8_grsl", 5, 6, 2, 17
