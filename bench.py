@@ -438,7 +438,10 @@ def main():
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if comm:
+        torch.cuda.synchronize()
         comm.barrier()
+        if hasattr(net, "close"):
+            net.close()              # the library's own RCCL communicators go before the process group does
         torch.distributed.destroy_process_group()
 
 

@@ -88,14 +88,19 @@ class EngineNet(DilatedNet):
     def workspace_bytes(self):
         return sum(t.numel() * t.element_size() for t in self._bufs.values())
 
+    def close(self):
+        """destroy the library's net and, after it, the RCCL communicators it was given (a data-parallel program calls this before it
+        tears its process group down; __del__ does the same when the object goes away)"""
+        if self.h is not None and _lib._lib is not None:
+            _lib.load().drs_net_destroy(self.h)
+            self.h = None
+            for c in getattr(self, "_rccl", []):
+                _lib.load().drs_rccl_comm_destroy(c)
+            self._rccl = []
+
     def __del__(self):
         try:
-            if self.h is not None and _lib._lib is not None:
-                _lib.load().drs_net_destroy(self.h)
-                self.h = None
-                for c in getattr(self, "_rccl", []):
-                    _lib.load().drs_rccl_comm_destroy(c)
-                self._rccl = []
+            self.close()
         except Exception:
             pass
 
