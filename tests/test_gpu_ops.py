@@ -292,8 +292,14 @@ def test_bn_act_pool_forward_backward(lib, C, pool, alpha, B, S, P):
     lib.call("drs_bn_backward_apply", gxh.data_ptr(), zd.data_ptr(), B, S, C, mr.data_ptr(), bs.data_ptr(), float(M), gz.data_ptr(),
              Pg, C, 0, stream())
     torch.cuda.synchronize()
-    assert rel_err(gxh.cpu().numpy().reshape(B, S, S, C), gxh_ref) < 2e-5
+    # (the activation's derivative jumps at 0: an element whose normalised value is within fp32 rounding of zero may take the other
+    #  branch on the device than in the fp64 oracle -- about one element in 10^7 -- and is left out; tools/fuzz_pointwise.py)
+    sure = np.abs(xh) > 1e-5
+    assert rel_err(np.where(sure, gxh.cpu().numpy().reshape(B, S, S, C), 0.0), np.where(sure, gxh_ref, 0.0)) < 2e-5
+    assert (~sure).sum() <= max(2, 1e-4 * sure.size)
     got, full = unpad(gz, B, S, Pg, C, 0, C)
+    if not sure.all():          # the batch-norm backward of what the device really fed it (one flipped element moves a channel's sums by 1 / M)
+        gz_ref = T.batch_norm_train_bwd(z64, mean, var, gxh.cpu().numpy().reshape(B, S, S, C).astype(np.float64))
     assert rel_err(got, gz_ref) < 5e-5
     full[:, Pg:Pg + S, Pg:Pg + S] = 0
     assert np.all(full == 0)
