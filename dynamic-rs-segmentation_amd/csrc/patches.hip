@@ -11,6 +11,12 @@
 // rounded once to fp32 on the store, so the result is bit-identical to the reference's feed.
 #include "drs_common.hpp"
 
+// Everything in this file restates host arithmetic that the reference does in numpy / scipy and is held to it BIT FOR BIT: no
+// multiply-add may be fused.  hipcc contracts a * b + c into an fma by default, and HIP's __dmul_rn / __dadd_rn are no
+// barrier against that (they are folded into fmas all the same): the rotation's source coordinate ((i m00) + j m01) + off came out as fma(j, m01, i m00) + off, which
+// picks the other neighbour than scipy.ndimage at exact ties (multiples of 15 / 45 degrees at some sides: tools/check_rotation.py).
+#pragma clang fp contract(off)
+
 namespace {
 
 struct CropArgs {
@@ -72,8 +78,14 @@ __global__ void crop_kernel(const CropArgs a) {
     if (a.rot_on && a.rot_on[b]) {
       const double* m = a.rot + 6 * b;
       // scipy.ndimage geometric transform, order 0: in = M . out + offset (no FMA contraction), nearest = floor(c + 0.5)
-      double c0 = __dadd_rn(__dadd_rn(__dadd_rn(0.0, __dmul_rn((double)fi, m[0])), __dmul_rn((double)fj, m[1])), m[4]);
-      double c1 = __dadd_rn(__dadd_rn(__dadd_rn(0.0, __dmul_rn((double)fi, m[2])), __dmul_rn((double)fj, m[3])), m[5]);
+      // (plain operators under this file's `fp contract(off)`: every product and every sum rounded on its own, as in ndimage's C)
+      const double p00 = (double)fi * m[0], p01 = (double)fj * m[1], p10 = (double)fi * m[2], p11 = (double)fj * m[3];
+      double c0 = 0.0 + p00;
+      c0 = c0 + p01;
+      c0 = c0 + m[4];
+      double c1 = 0.0 + p10;
+      c1 = c1 + p11;
+      c1 = c1 + m[5];
       valid = !(c0 < 0.0 || c0 > (double)(a.S - 1) || c1 < 0.0 || c1 > (double)(a.S - 1));
       si = (int)floor(c0 + 0.5);
       sj = (int)floor(c1 + 0.5);
@@ -93,11 +105,11 @@ __global__ void crop_kernel(const CropArgs a) {
       if (noisy) {
         const size_t ne = (((size_t)b * a.S + fi) * a.S + fj) * a.C + c;   // noise is indexed before the flip
         const size_t ng = ne + (size_t)a.b0 * a.S * a.S * a.C;             // ... and by the patch's place in the GLOBAL batch on the device path
-        if (a.noise) e = __dadd_rn(e, a.noise[ne]);
+        if (a.noise) e = e + a.noise[ne];
         else {
           unsigned r[4];
           philox(a.seed, (unsigned long long)ng, r);
-          e = __dadd_rn(e, 0.01 * normal_from(r[0], r[1]));
+          e = e + 0.01 * normal_from(r[0], r[1]);
         }
       }
       if (a.quantize_f16) {
@@ -117,7 +129,7 @@ __global__ void crop_kernel(const CropArgs a) {
         v[c] = (float)q;
         continue;
       }
-      if (c < 3) e = __ddiv_rn(__dsub_rn(e, a.mean[c]), a.stdv[c]);
+      if (c < 3) e = (e - a.mean[c]) / a.stdv[c];
       v[c] = (float)e;
     }
     if (a.out_lab) a.out_lab[opix] = lab;

@@ -171,3 +171,38 @@ def test_contest_sampler_with_void_mask_on_device(S):
     np.testing.assert_array_equal(x, g["patches_%d" % S])
     np.testing.assert_array_equal(lab, g["classes_%d" % S])
     np.testing.assert_array_equal(mask, g["masks_%d" % S])
+
+
+@pytest.mark.parametrize("S", [15, 16, 19, 40])
+def test_every_rotation_angle_matches_scipy(S):
+    """isprs:294-296 rotates patch, labels and an all-ones mask with scipy.ndimage.rotate(angle, order=0, reshape=False), the angle any
+    integer in [0, 360) (isprs:491).  At multiples of 15 / 45 degrees a source coordinate falls exactly between two pixels at some
+    sides, and which neighbour wins depends on every product and sum being rounded on its own, as in ndimage's C: a fused
+    multiply-add picked the other one (round 3: 23 of 3960 (side, angle) pairs, found by tools/fuzz_patches.py; csrc/patches.hip now
+    compiles with contraction off).  All 360 angles here, source pixel, label and mask of every output pixel."""
+    from scipy import ndimage
+    from drs_amd import patches as P
+    h = w = S + 6
+    tile = (np.arange(h * w, dtype=np.float64) + 1).reshape(h, w, 1).repeat(3, axis=2)
+    lab = (np.arange(h * w) % 6).reshape(h, w)
+    pool = P.TilePool([tile], [lab], DEV, dtype=np.float64)
+    B = 90
+    net = _net(3, B, S)
+    patch, plab = tile[3:3 + S, 2:2 + S, 0], lab[3:3 + S, 2:2 + S]
+    for a0 in range(0, 360, B):
+        inst = np.array([[0, 3, 2, a0 + k] for k in range(B)])
+        aug = P.Augmentation(B)
+        aug.rot_on[:] = 1
+        for k in range(B):
+            aug.rot[k] = P.rotation_params(a0 + k, S)
+        P.crop_to_net(net, pool, inst, S, [0, 0, 0], [1, 1, 1], aug)
+        torch.cuda.synchronize()
+        a, Pd, ld = _slab(net, B, S)
+        got = a[:, Pd:Pd + S, Pd:Pd + S, 0]
+        labs = net.labels[:B * S * S].cpu().numpy().reshape(B, S, S)
+        mask = net.acc_mask[:B * S * S].cpu().numpy().reshape(B, S, S).astype(bool)
+        for k in range(B):
+            ang = a0 + k
+            np.testing.assert_array_equal(got[k], ndimage.rotate(patch, ang, order=0, reshape=False).astype(np.float32), err_msg="angle %d" % ang)
+            np.testing.assert_array_equal(labs[k], ndimage.rotate(plab, ang, order=0, reshape=False), err_msg="angle %d" % ang)
+            np.testing.assert_array_equal(mask[k], ndimage.rotate(np.ones((S, S), dtype=bool), ang, order=0, reshape=False), err_msg="angle %d" % ang)
