@@ -14,7 +14,7 @@
 // Everything in this file restates host arithmetic that the reference does in numpy / scipy and is held to it BIT FOR BIT: no
 // multiply-add may be fused.  hipcc contracts a * b + c into an fma by default, and HIP's __dmul_rn / __dadd_rn are no
 // barrier against that (they are folded into fmas all the same): the rotation's source coordinate ((i m00) + j m01) + off came out as fma(j, m01, i m00) + off, which
-// picks the other neighbour than scipy.ndimage at exact ties (multiples of 15 / 45 degrees at some sides: tools/check_rotation.py).
+// picks the other neighbour than scipy.ndimage at exact ties (multiples of 15 / 45 degrees at some sides: tests/fuzz/check_rotation.py).
 #pragma clang fp contract(off)
 
 namespace {

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Every rotation angle 0..359 at several patch sides through the crop kernel against scipy.ndimage.rotate(order=0, reshape=False)
-(what isprs:294-296 calls): source pixel, label and validity mask of every output pixel.  python tools/check_rotation.py [S=9,15,16,25,33]"""
+(what isprs:294-296 calls): source pixel, label and validity mask of every output pixel.  python tests/fuzz/check_rotation.py [S=9,15,16,25,33]"""
 import os, sys
 import numpy as np
 import torch
 from scipy import ndimage
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from drs_amd import patches as P

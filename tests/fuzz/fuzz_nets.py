@@ -2,10 +2,10 @@
 """Randomised (net type, bands, classes, batch, side) through the whole-net checks of tests/test_gpu_net.py (eval and train parity
 against the fp64 oracle: logits, loss, decision margins, every gradient, moving statistics, confusion matrix) and
 tests/test_gpu_engine.py (the step engine bitwise equal to the op-level sequence), called as functions.  Test infrastructure.
-    python tools/fuzz_nets.py [n=60] [seed=0]"""
+    python tests/fuzz/fuzz_nets.py [n=60] [seed=0]"""
 import os, sys, traceback
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_net as N

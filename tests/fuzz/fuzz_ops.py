@@ -2,12 +2,13 @@
 """Randomised shapes through the convolution entry points against the fp64 oracle: forward (plain and with the stream-K workspace),
 input gradient, filter gradient -- kernel 1..5, rate 1..9, channels in steps of 32 / 64, batches and sides that leave ragged tiles and
 partial chunks, halos wider than needed, slices of wider slabs, NaN-poisoned scratch.  Test infrastructure (uses oracle/); prints
-every case that misses 1e-5.      python tools/fuzz_ops.py [n=200] [seed=0]"""
+every case that misses 1e-5.      python tests/fuzz/fuzz_ops.py [n=200] [seed=0]"""
 import os, sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from drs_amd import _lib
 from oracle import nets as onets
 from oracle import tf_ops as T

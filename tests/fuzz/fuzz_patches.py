@@ -2,11 +2,11 @@
 """Randomised tiles, instances and sizes through the crop + augment + normalise kernel (against oracle/host_ref.py's restatement of
 dynamically_create_patches under the same numpy seed: bit-exact, rotations / flips / host noise included) and random tile / window /
 batch geometries through the stitch kernels (tests/test_gpu_patches.py's check, called as a function).  Test infrastructure.
-    python tools/fuzz_patches.py [n=150] [seed=0]"""
+    python tests/fuzz/fuzz_patches.py [n=150] [seed=0]"""
 import os, sys, traceback
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import host_ref as H

@@ -2,10 +2,10 @@
 """Randomised shapes through the BN / activation / pool forward and backward entry points and the classifier + loss block, against
 the fp64 oracle: the checks are those of tests/test_gpu_ops.py (called as functions), the shapes are drawn here -- channels 4..576 in
 steps of 4, sides 1..40, batches 1..6, halos 0..8, pool on / off, ReLU / leaky.  Test infrastructure.
-    python tools/fuzz_pointwise.py [n=300] [seed=0]"""
+    python tests/fuzz/fuzz_pointwise.py [n=300] [seed=0]"""
 import os, sys, traceback
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from drs_amd import _lib

@@ -3,10 +3,10 @@
 loops) against the REFERENCE'S OWN FUNCTIONS, imported from /root/reference the way tests/golden/make_goldens.py does (inert
 placeholders for tensorflow / gdal / skimage; np.int restored).  Random inputs, same numpy / random seeds on both sides, exact
 equality.  Runs only where /root/reference exists (the build container): nothing here travels to the GPU box, and nothing of the
-reference is copied -- it is called.      python tools/fuzz_vs_reference.py [n=300] [seed=0]"""
+reference is copied -- it is called.      python tests/fuzz/fuzz_vs_reference.py [n=300] [seed=0]"""
 import os, random, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 if not os.path.isdir("/root/reference"):

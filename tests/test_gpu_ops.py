@@ -293,7 +293,7 @@ def test_bn_act_pool_forward_backward(lib, C, pool, alpha, B, S, P):
              Pg, C, 0, stream())
     torch.cuda.synchronize()
     # (the activation's derivative jumps at 0: an element whose normalised value is within fp32 rounding of zero may take the other
-    #  branch on the device than in the fp64 oracle -- about one element in 10^7 -- and is left out; tools/fuzz_pointwise.py)
+    #  branch on the device than in the fp64 oracle -- about one element in 10^7 -- and is left out; tests/fuzz/fuzz_pointwise.py)
     sure = np.abs(xh) > 1e-5
     assert rel_err(np.where(sure, gxh.cpu().numpy().reshape(B, S, S, C), 0.0), np.where(sure, gxh_ref, 0.0)) < 2e-5
     assert (~sure).sum() <= max(2, 1e-4 * sure.size)

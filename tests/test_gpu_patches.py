@@ -178,7 +178,7 @@ def test_every_rotation_angle_matches_scipy(S):
     """isprs:294-296 rotates patch, labels and an all-ones mask with scipy.ndimage.rotate(angle, order=0, reshape=False), the angle any
     integer in [0, 360) (isprs:491).  At multiples of 15 / 45 degrees a source coordinate falls exactly between two pixels at some
     sides, and which neighbour wins depends on every product and sum being rounded on its own, as in ndimage's C: a fused
-    multiply-add picked the other one (round 3: 23 of 3960 (side, angle) pairs, found by tools/fuzz_patches.py; csrc/patches.hip now
+    multiply-add picked the other one (round 3: 23 of 3960 (side, angle) pairs, found by tests/fuzz/fuzz_patches.py; csrc/patches.hip now
     compiles with contraction off).  All 360 angles here, source pixel, label and mask of every output pixel."""
     from scipy import ndimage
     from drs_amd import patches as P
