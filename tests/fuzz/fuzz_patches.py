@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised tiles, instances and sizes through the crop + augment + normalise kernel (against oracle/host_ref.py's restatement of
-dynamically_create_patches under the same numpy seed: bit-exact, rotations / flips / host noise included) and random tile / window /
-batch geometries through the stitch kernels (tests/test_gpu_patches.py's check, called as a function).  Test infrastructure.
+dynamically_create_patches under the same numpy seed: bit-exact, rotations / flips / host noise included), the coffee / contest
+samplers (flip by index, float16 patches and normalisation, void mask) and random tile / window / batch geometries through the
+stitch kernels (tests/test_gpu_patches.py's check, called as a function).  Test infrastructure.
     python tests/fuzz/fuzz_patches.py [n=150] [seed=0]"""
 import os, sys, traceback
 import numpy as np
@@ -75,11 +76,50 @@ def stitch_case(rng):
         return tag, [traceback.format_exc().strip().splitlines()[-1][:160]]
 
 
+def flavour_case(rng):
+    """the coffee (flip by index, float16 patches, float16 in-place normalisation) and contest (void mask) samplers on the device
+    against oracle/host_ref.py's restatement (itself held to the reference's functions by fuzz_vs_reference.py)"""
+    coffee = bool(rng.integers(0, 2))
+    nt = int(rng.integers(1, 3)) if coffee else 1
+    h = int(rng.integers(24, 60))
+    w = h if coffee else int(rng.integers(24, 60))
+    K = 2 if coffee else 7
+    data = rng.uniform(0, 1, size=(nt, h, w, 3)).astype(np.float32)
+    lab = rng.integers(0, K + (0 if coffee else 1), size=(nt, h, w)).astype(np.uint8)
+    S = int(rng.integers(5, min(h, w, 22) + 1))
+    nd = int(rng.integers(1, 30))
+    dist = [(int(rng.integers(0, nt)), int(rng.integers(0, h - 2)), int(rng.integers(0, w - 2))) for _ in range(nd)]
+    B = int(rng.integers(1, 12))
+    g = dict(shuffle=rng.integers(0, 3 * nd, size=B))
+    tag = "%s %dx%d S%d windows %d B%d" % ("coffee" if coffee else "contest", h, w, S, nd, B)
+    bad = []
+    tiles, labs = [data[k] for k in range(nt)], [lab[k] for k in range(nt)]
+    void = -1 if coffee else 7
+    x, l, m = G._indexed_on_device(g, S, 3, K, dist, tiles, labs, void_label=void)
+    p, c, q = H.indexed_create_patches(data, lab, S, dist, g["shuffle"], void_label=None if coffee else 7)
+    if not np.array_equal(x, p.astype(np.float32)):
+        bad.append("pixels")
+    if not np.array_equal(l, c):
+        bad.append("labels")
+    if not coffee and not np.array_equal(m, q):
+        bad.append("void mask")
+    if coffee:
+        p16, _, _ = H.indexed_create_patches(data, lab, S, dist, g["shuffle"], float16=True)
+        xq, _, _ = G._indexed_on_device(g, S, 3, K, dist, tiles, labs, quantize=True)
+        if not np.array_equal(xq, p16.astype(np.float32)):
+            bad.append("float16 patches")
+        mean, std = rng.uniform(0.2, 0.7, size=3).astype(np.float32), rng.uniform(0.1, 0.4, size=3).astype(np.float32)
+        xn, _, _ = G._indexed_on_device(g, S, 3, K, dist, tiles, labs, quantize=True, mean=mean, std=std)
+        if not np.array_equal(xn, H.normalize_images_f16(p16.copy(), mean, std).astype(np.float32)):
+            bad.append("float16 normalisation")
+    return tag, bad
+
+
 def main(n=150, seed=0):
     rng = np.random.default_rng(seed)
     nbad = 0
     for i in range(n):
-        tag, bad = (crop_case if i % 3 else stitch_case)(rng)
+        tag, bad = (stitch_case if i % 4 == 0 else flavour_case if i % 4 == 1 else crop_case)(rng)
         if bad:
             nbad += 1
             print("FAIL", tag, bad, flush=True)
