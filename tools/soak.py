@@ -30,6 +30,12 @@ def run(B, steps, lo, hi, pool, dev, net_type="dilated_grsl_rate8", channels=5, 
         losses[i] = out["loss_parts"]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    try:
+        import psutil
+        free, total = torch.cuda.mem_get_info()
+        print("   after %d steps: process RSS %.0f MB, device memory in use %.0f MB" % (steps, psutil.Process().memory_info().rss / 1e6, (total - free) / 1e6), flush=True)
+    except Exception:
+        pass
     params = torch.cat([net.params.flatten(), net.mom.flatten(), net.bn.flatten()]).clone()       # variables, momentum slots, moving statistics
     return losses.cpu().numpy(), params.cpu().numpy(), dt
 
