@@ -267,8 +267,9 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ ga, int ld_ga, in
 
 // ------------------------------------------------------------------------------------------------ pooled nets: sliding kernels
 // With the 3x3 pool every output needs a 3x3 neighbourhood.  Instead of 9 loads per output, a thread owns one image
-// column x and four channels and slides down a strip of rows, keeping what it needs of the two previous rows in
-// registers: 3 loads per output forward (one row of 3 neighbours), 3 (code, gradient) pairs backward.
+// column x and four channels and slides down a strip of rows: ONE load per output of its own column, the horizontal
+// neighbours through LDS, the two previous rows' partial results in registers (forward: row maxima + positions; backward: the
+// running sums of the rows above / at / below the window row that arrives).
 // block = TX columns x (C/4) channel quads; grid.x = column blocks, grid.y = (image, row strip).
 struct SlideCfg { int TX, ncol, nstrips, rps; };
 static int g_slide_blocks = 2048, g_slide_minrows = 8;     // (development switches: drs_debug_slide_*)
@@ -300,8 +301,9 @@ __global__ void zero_halo_kernel(ActView out, int B, int C) {
   view_store4(out, ((size_t)(b * Sp + yy) * Sp + xx) * out.ld + out.coff + cq * 4, f32x4{0.f, 0.f, 0.f, 0.f});
 }
 
-// Both sliding kernels, r03: a thread is a chain of dependent rows, and what bounded the launches was the data it keeps in flight
-// (one 16-byte load per wave at first: 0.56 of HBM with nothing else to wait for), not the arithmetic.  So each thread loads ONLY its
+// Both sliding kernels, r03: a thread is a chain of dependent rows; such a launch is bound by the instruction stream of the few waves
+// a SIMD holds and by what they keep in flight, not by HBM (one 16-byte load per wave at first, each neighbour under its own branch
+// and wait: 0.56 of HBM; profiles/r03/elementwise_sliding_kernels.txt).  So each thread loads ONLY its
 // own column, three rows ahead of the row it works on, and the horizontal neighbours come through LDS: every thread publishes what
 // it derived from its own load (the activation forward; the (position word, gradient) pair backward), one barrier per row, two
 // cells in turn.  The first / last column thread of a workgroup also loads and publishes the column beyond its edge.  Columns
