@@ -506,7 +506,9 @@ class DilatedNet(object):
         p, st = self.plan, self._stream()
         M = B * S * S
         n_bn = float(M * self.comm.world)        # batch-norm statistics run over every pixel of the global batch
-        n_glob = float(global_pixels if global_pixels is not None else M * self.comm.world)
+        # (<= 0, like None, means "every pixel of every rank": the step engine's rule, csrc/engine.hip train_step_impl -- a mask that
+        #  leaves no pixel must not divide by zero here and by B*S*S there)
+        n_glob = float(global_pixels if global_pixels is not None and global_pixels > 0 else M * self.comm.world)
         self._forward_layers(B, S, True, n_bn)
         nL = len(p.layers)
         for i in range(1, nL):
