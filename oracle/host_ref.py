@@ -2,7 +2,9 @@
 
 TEST INFRASTRUCTURE (see oracle/__init__.py).  Parity status: PINNED against
 tests/golden/*.npz, which were produced by importing the reference's own functions
-(tests/golden/make_goldens.py) -- see tests/test_oracle_host.py.
+(tests/golden/make_goldens.py) -- see tests/test_oracle_host.py -- and against the reference's functions
+themselves on random inputs (tests/fuzz/fuzz_vs_reference.py, a differential fuzz that runs in the build container only;
+tests/test_reference_differential.py is its short seeded form).
 
 Citations are to /root/reference/isprs_dilated_random.py unless another file is named.
 RNG: the reference draws from the *global* ``random`` / ``numpy.random`` streams; the
