@@ -28,6 +28,8 @@ def run(B, steps, lo, hi, pool, dev, net_type="dilated_grsl_rate8", channels=5, 
         P.crop_to_net(net, pool, rows, S, [0.5] * 3, [0.2] * 3, aug)
         out = net.train_step(B, S, 0.01)
         losses[i] = out["loss_parts"]
+        if i and i % 5000 == 0:
+            print("   step %d, CE %.4f" % (i, float(losses[i, 0])), flush=True)     # (a sign of life for whoever watches a long run)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     try:
