@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: training patches/sec of dilated_grsl_rate8 (Dilated8Pooling) on 64x64x5 patches.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                      (N > 1: starts torch.distributed.run itself, as a child)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -14,6 +14,13 @@ live with HIP events on the launch stream), "kernels" (the same figures for ever
 "cpu_baseline" (the oracle's PyTorch-CPU port of the reference step, bounded sample, rank 0 at N=1 only) and, at N=1,
 "opt_in_arithmetic": a short measurement of the same step on the split-bf16 convolution kernels (--arith bf16x3), which is
 never the headline `value`.
+
+N > 1 cannot be lost to a hang in the collectives.  Every rank process of the launcher is a SUPERVISOR that never touches the
+GPU: it starts the measuring process as a fresh child, relays its output, and watches its progress markers on stderr.  If a child
+is silent for DRS_BENCH_WATCHDOG_S seconds (default 300) or dies, the supervisor kills it and starts a fresh child with the next
+entry of DRS_BENCH_FALLBACKS (default "torch,single": the torch.distributed callback for every sum, then library-side RCCL with one
+communicator on the compute stream) on a rendezvous port of its own; the JSON line then says which path ran and why
+(`config.collectives`, `config.fallback_reason`).  A process that has touched the GPU is never re-executed.
 """
 import argparse
 import json
@@ -23,11 +30,178 @@ import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver; must be set before the runtime starts
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+np = torch = None            # numpy / torch are imported by the measuring process only (load_numerics): a supervisor stays light
+
+
+def load_numerics():
+    global np, torch
+    import numpy
+    import torch as _torch
+    np, torch = numpy, _torch
+
+
+# ------------------------------------------------------------------------------------------------ launch plumbing (no GPU, no torch)
+MARK = "DRS_BENCH_MARK"
+FALLBACK_ENV = {"torch": {"DRS_COMM": "torch"}, "single": {"DRS_COMM": "rccl", "DRS_RCCL_SINGLE_COMM": "1"}}
+
+
+def mark(stage, rank=None):
+    """progress marker of a measuring process (stderr): what the supervisor's watchdog listens for"""
+    sys.stderr.write("%s rank=%s stage=%s t=%.1f\n" % (MARK, os.environ.get("RANK", "0") if rank is None else rank, stage, time.time()))
+    sys.stderr.flush()
+
+
+def _kill_group(proc):
+    import signal
+    for sig, wait in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 10.0)):
+        try:
+            os.killpg(proc.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            pass
+        try:
+            proc.wait(timeout=wait)
+            return
+        except Exception:
+            continue
+
+
+def _run_watched(cmd, env, limit_s, need_marks=True, rendezvous_slack=1.0):
+    """start `cmd` as a fresh process group, relay its stderr (watching the markers) and collect its stdout.
+    Returns (rc or None if killed by the watchdog, stdout text, last marker stage).  `rendezvous_slack` multiplies the limit until the
+    process group is up: the ranks of a fall-back attempt arrive up to one watchdog period apart (each supervisor times out alone)."""
+    import subprocess
+    import threading
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+    state = dict(last=time.time(), stage="started", out=[])
+
+    def pump_err():
+        for raw in iter(proc.stderr.readline, b""):
+            line = raw.decode("utf-8", "replace")
+            if MARK in line:
+                state["last"] = time.time()
+                try:
+                    state["stage"] = line.split("stage=", 1)[1].split(" t=")[0].strip()
+                except IndexError:
+                    pass
+            sys.stderr.write(line)
+            sys.stderr.flush()
+
+    def pump_out():
+        for raw in iter(proc.stdout.readline, b""):
+            state["out"].append(raw.decode("utf-8", "replace"))
+    th = [threading.Thread(target=pump_err, daemon=True), threading.Thread(target=pump_out, daemon=True)]
+    for t in th:
+        t.start()
+    killed = False
+    while True:
+        try:
+            proc.wait(timeout=1.0)
+            break
+        except subprocess.TimeoutExpired:
+            lim = limit_s * (rendezvous_slack if state["stage"] in ("started", "imports done") else 1.0)
+            if need_marks and time.time() - state["last"] > lim:
+                sys.stderr.write("bench.py watchdog: no progress marker for %.0f s after stage '%s': killing the process group\n" % (lim, state["stage"]))
+                _kill_group(proc)
+                killed = True
+                break
+    for t in th:
+        t.join(timeout=5.0)
+    return (None if killed else proc.returncode), "".join(state["out"]), state["stage"]
+
+
+def supervise(argv):
+    """one rank of the launcher: start the measuring process as a child, fall back on a hang or a crash.  Never touches the GPU."""
+    limit = float(os.environ.get("DRS_BENCH_WATCHDOG_S", "300"))
+    chain = [("default", {})] + [(k, FALLBACK_ENV[k]) for k in os.environ.get("DRS_BENCH_FALLBACKS", "torch,single").split(",") if k in FALLBACK_ENV]
+    port0 = int(os.environ.get("MASTER_PORT", "29500"))
+    reason = ""
+    for i, (label, extra) in enumerate(chain):
+        env = dict(os.environ)
+        env.update(extra)
+        env.update(DRS_BENCH_CHILD="1", DRS_BENCH_ATTEMPT=label, DRS_BENCH_FALLBACK_REASON=reason)
+        if i > 0:
+            # a rendezvous of its own: the launcher's store still holds the keys of the attempt that was killed.  Rank 0's child hosts it.
+            env.update(MASTER_PORT=str(port0 + 101 * i), TORCHELASTIC_USE_AGENT_STORE="False")
+        rc, out, stage = _run_watched([sys.executable, os.path.abspath(__file__)] + argv, env, limit, rendezvous_slack=1.0 if i == 0 else 2.5)
+        if rc == 0:
+            # stdout carries the ONE JSON line (rank 0's) and nothing else: whatever a library printed to the child's descriptor 1 goes to stderr
+            for ln in out.splitlines():
+                (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln + "\n")
+            sys.stdout.flush()
+            return 0
+        reason = ("timeout: silent for %.0f s after stage '%s'" % (limit, stage)) if rc is None else ("exit code %s after stage '%s'" % (rc, stage))
+        reason = "%s attempt: %s" % (label, reason)
+        sys.stderr.write("bench.py supervisor (rank %s): %s%s\n" % (os.environ.get("RANK", "?"), reason, "; falling back" if i + 1 < len(chain) else "; giving up"))
+    if os.environ.get("RANK", "0") == "0":
+        sys.stdout.write(json.dumps({"metric": "training patches/sec dilated_grsl_rate8 64x64x5", "value": None, "unit": "patches/s",
+                                     "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "error": "every attempt failed; last: " + reason}) + "\n")
+        sys.stdout.flush()
+    return 1
+
+
+def plain_parent(args, argv):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a fresh child (whose ranks supervise themselves),
+    relay its one JSON line and its exit code.  Never touches the GPU."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    rc, out, _ = _run_watched(cmd, dict(os.environ), 0.0, need_marks=False)
+    lines = [ln for ln in out.splitlines() if ln.strip().startswith("{")]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    return rc if rc is not None else 1
+
+
+def selftest_worker(args):
+    """DRS_BENCH_SELFTEST=1: the launch plumbing alone, on CPU (tests/test_bench_launch.py): gloo process group, one barrier, the
+    markers, one JSON line from rank 0.  DRS_BENCH_FAKE_HANG=<attempt label> makes that attempt hang before its warm-up marker."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    attempt = os.environ.get("DRS_BENCH_ATTEMPT", "default")
+    sys.stdout.flush()
+    json_fd = os.dup(1)          # gloo prints its connection lines to descriptor 1
+    os.dup2(2, 1)
+    mark("imports done")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        dist.barrier()
+    mark("process group up")
+    if attempt in os.environ.get("DRS_BENCH_FAKE_HANG", "").split(","):
+        time.sleep(3600)
+    if attempt in os.environ.get("DRS_BENCH_FAKE_CRASH", "").split(","):
+        sys.exit(7)
+    mark("warm-up done")
+    ones = None
+    if world > 1:
+        import torch as _t
+        ones = _t.ones(1, dtype=_t.int32)
+        dist.all_reduce(ones)
+        dist.barrier()
+    if rank == 0:
+        os.write(json_fd, (json.dumps({"metric": "selftest", "value": 1.0, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "config": {"collectives": collectives_label("selftest"), "fallback_reason": os.environ.get("DRS_BENCH_FALLBACK_REASON") or None,
+                                     "ranks_observed": int(ones.item()) if ones is not None else 1,
+                                     "env": {k: os.environ.get(k) for k in ("DRS_COMM", "DRS_RCCL_SINGLE_COMM", "MASTER_PORT")}}}) + "\n").encode())
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def collectives_label(base):
+    """`config.collectives` of the JSON line: the path the step's sums took, and whether it is a fall-back of the supervisor"""
+    attempt, reason = os.environ.get("DRS_BENCH_ATTEMPT", "default"), os.environ.get("DRS_BENCH_FALLBACK_REASON", "")
+    if attempt != "default" and reason:
+        return "%s (fallback after %s)" % (base, "timeout" if "timeout" in reason else "failure")
+    return base
+
 
 NET, CHANNELS, CLASSES = "dilated_grsl_rate8", 5, 6
 GLOBAL_BATCH, PATCH = 128, 64
@@ -92,11 +266,12 @@ def allowed_cores():
     return n, note
 
 
-def cpu_baseline(batch=GLOBAL_BATCH, warmup=1, timed=3):
+def cpu_baseline(batch=GLOBAL_BATCH, warmup=2, timed=5):
     """The reference step restated with PyTorch-CPU fp32 ops (oracle/torch_ref.py) + the reference's host pipeline (numpy crop /
     rotate / noise / flip, normalise of bands 0..2, confusion matrix), on this host's cores, as SURVEY.md 8(d) specifies it: the
     bench's own workload (same net, 64x64x5 patches of the same 2048 x 2048 synthetic tile, same instances), `warmup` + `timed`
-    steps at the GPU line's own batch of 128 (a CPU step is ~10 s long: 1 + 3 steps bound the sample to well under a minute), every core
+    steps at the GPU line's own batch of 128 (2 warm-up + 5 timed; a CPU step is ~10 s long, so ~70 s in all, each step
+    leaving a progress marker), every core
     the process is allowed (allowed_cores: affinity mask cut to the cgroup's CPU quota), median step; plus a 1-thread figure from one step
     of 8 patches.  Both are stated in `sample`."""
     from oracle.torch_ref import TorchNet
@@ -124,7 +299,11 @@ def cpu_baseline(batch=GLOBAL_BATCH, warmup=1, timed=3):
         return time.time() - t0
     for i in range(warmup):
         step(i, batch)
-    times = [step(warmup + i, batch) for i in range(timed)]
+        mark("cpu baseline warm-up %d" % i)
+    times = []
+    for i in range(timed):
+        times.append(step(warmup + i, batch))
+        mark("cpu baseline step %d" % i)
     med = float(np.median(times))
     torch.set_num_threads(1)
     b1 = 8
@@ -237,6 +416,17 @@ def main():
                     help="arithmetic of the convolution kernels: exact fp32 MFMA (default) or split-bf16 (conv_split.hip)")
     args = ap.parse_args()
     ar = ARITH[args.arith]
+    # ---- which process is this?  (decided before anything imports torch or touches the GPU)
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    child = os.environ.get("DRS_BENCH_CHILD") == "1"
+    if not launched and args.gpus > 1:
+        sys.exit(plain_parent(args, sys.argv[1:]))                # `python bench.py --gpus N`: start the launcher as a child
+    if launched and not child and int(os.environ["WORLD_SIZE"]) > 1 and os.environ.get("DRS_BENCH_SUPERVISE", "1") != "0":
+        sys.exit(supervise(sys.argv[1:]))                         # a rank of the launcher: supervise a fresh measuring process
+    if os.environ.get("DRS_BENCH_SELFTEST") == "1":
+        sys.exit(selftest_worker(args))
+    load_numerics()
+    mark("imports done")
     # stdout carries the ONE JSON line and nothing else: RCCL prints a version banner, gloo its connection lines, straight to file
     # descriptor 1 of every rank.  From here on descriptor 1 is stderr; the JSON line goes to the saved descriptor at the end.
     sys.stdout.flush()
@@ -245,9 +435,6 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     # rehearsal knob (one-GPU boxes): DRS_BENCH_REHEARSAL=1 runs all ranks on cuda:0 over gloo, to exercise the
     # N > 1 code path without a second device; never set by the driver, and the JSON line says so
     rehearsal = os.environ.get("DRS_BENCH_REHEARSAL") == "1"
@@ -271,6 +458,7 @@ def main():
     if world > 1 or forced:
         comm = TorchComm("gloo" if rehearsal else "nccl")
     rank = comm.rank if comm else 0
+    mark("process group up")
     B_local = GLOBAL_BATCH // world
     if GLOBAL_BATCH % world:
         sys.exit("global batch %d not divisible by %d ranks" % (GLOBAL_BATCH, world))
@@ -282,6 +470,9 @@ def main():
     std = tile[:, :, :3].std(axis=(0, 1)).tolist()
     net = DilatedNet(NET, CHANNELS, CLASSES, WD, b_max=B_local, s_max=PATCH, device=dev, seed=42, comm=comm, arith=args.arith)
     sl = shard_slice(GLOBAL_BATCH, rank, world)
+    mark("net built, collectives=%s" % (getattr(net, "collectives", None) if comm else None))
+    if os.environ.get("DRS_BENCH_ATTEMPT", "default") in os.environ.get("DRS_BENCH_FAKE_HANG", "-").split(","):
+        time.sleep(3600)                      # (tests: a hang in the collectives, as the supervisor sees it)
 
     import random
     random.seed(7)
@@ -306,16 +497,29 @@ def main():
     if comm:
         comm.barrier()
     torch.cuda.synchronize()
+    mark("warm-up done")
+    # one HIP event per step on the launch stream (an asynchronous record: not on the host's critical path): the MEDIAN step, SURVEY 8(d)
+    step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     out = None
-    for _ in range(args.steps):
+    step_events[0].record()
+    for k in range(args.steps):
         out = one_step()
+        step_events[k + 1].record()
+    t_local = time.perf_counter()
     if comm:
         comm.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = elapsed_local = time.perf_counter() - t0
+    step_ms = sorted(step_events[k].elapsed_time(step_events[k + 1]) for k in range(args.steps))
+    per_rank_ms = None
     if comm:
         elapsed = comm.max_float(elapsed, dev)
+        mine_ms = 1e3 * elapsed_local / args.steps
+        per_rank_ms = dict(min=round(-comm.max_float(-mine_ms, dev), 3), max=round(comm.max_float(mine_ms, dev), 3),
+                           note="wall time of the timed region / steps on each rank (barrier included)")
+    del t_local
+    mark("timed region done")
     loss = net.loss_value(out["loss_parts"])
 
     # ---- per-kernel timing pass (outside the timed region): HIP events around every launch
@@ -356,6 +560,7 @@ def main():
             roofline["mfma_issued_tflops"] = round(ach * ar["products"], 1)
             roofline["mfma_issued_frac"] = round(ach * ar["products"] / ar["peak"], 4)
 
+    mark("kernel timing done")
     # ---- validation half of the metric: forward-only pixels/sec (eval-mode BN, arg-max, confusion), isprs:1569-1618
     vb = 25             # B * 100 patches per validation pass; 25 batches of 128 bound the sample (0.4 s)
     for _ in range(2):
@@ -375,6 +580,7 @@ def main():
     if comm:
         tv = comm.max_float(tv, dev)
     val_pixels_per_s = vb * GLOBAL_BATCH * PATCH * PATCH / tv
+    mark("validation done")
 
     # ---- the opt-in arithmetics beside the headline (N = 1 only; never `value`): the same step on the split-bf16 kernels (op-level path).
     # bf16x6 is the fp32-EQUIVALENT one (tests/test_gpu_split.py: its errors against the fp64 oracle are no larger than the fp32 MFMA
@@ -405,9 +611,11 @@ def main():
                           "product, ~3x an fp32 FMA's rounding, when a few large terms dominate a sum "
                           "(tests/test_gpu_split.py::test_three_term_arithmetic_on_adversarial_operands); bf16x3 carries 2^-16")
 
+    mark("opt-in done")
     size_table = None
     if world == 1 and args.arith == "f32" and not args.no_size_table and not forced:
         size_table = per_rank_size_table(dev, pool, mean, std)
+    mark("size table done")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -423,20 +631,28 @@ def main():
         line = {
             "metric": "training patches/sec dilated_grsl_rate8 64x64x5", "value": round(value, 2), "unit": "patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "median_step_ms": round(step_ms[len(step_ms) // 2], 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": ar["dtype"], "data": "synthetic",
             "config": {"workload": "dilated_grsl_rate8 (Dilated8Pooling) training step, single_fixed 64x64, 5-band synthetic "
                                    "2048x2048 tile, global batch 128 (crop+augment+normalise, fwd, loss, bwd, momentum, confusion)",
                        "global_batch": GLOBAL_BATCH, "patch": PATCH, "bands": CHANNELS, "classes": CLASSES,
                        "parallelism": "dp%d" % world + (" (REHEARSAL: all ranks on one GPU over gloo)" if rehearsal else "")
                                       + (" (collectives forced through RCCL at world 1)" if forced else ""),
-                       "sync_bn": True, "collectives": getattr(net, "collectives", None) if comm else None},
+                       "sync_bn": True, "collectives": collectives_label(getattr(net, "collectives", None)) if comm else None,
+                       "fallback_reason": os.environ.get("DRS_BENCH_FALLBACK_REASON") or None,
+                       # the sum of one `1` per rank over the step's own communicator (engine.py: the known-answer check of a new
+                       # RCCL communicator, or the same through the callback's): > 1 only if that many ranks really took part
+                       "rccl_ranks_observed": getattr(net, "ranks_observed", 1) if comm else 1},
             "val_pixels_per_sec": round(val_pixels_per_s, 1), "final_loss": round(loss, 5),
             "workspace_gb_per_gpu": round(net.workspace_bytes() / 1e9, 2),
             "train_tflops": round(value * 3 * 2 * net.plan.mac_per_pixel() * PATCH * PATCH / 1e12, 2),
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "opt_in_arithmetic": opt_in,
-            "extra": {"per_rank_size_table": size_table},
+            "extra": {"per_rank_size_table": size_table, "per_rank_ms": per_rank_ms,
+                      "step_ms_events": dict(median=round(step_ms[len(step_ms) // 2], 3), min=round(step_ms[0], 3), max=round(step_ms[-1], 3),
+                                             note="HIP events between consecutive steps on rank 0's launch stream; `value` stays steps / wall time")},
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())
+        mark("json written")
     if comm:
         torch.cuda.synchronize()
         comm.barrier()

@@ -154,8 +154,9 @@ struct drs_net {
   void* rccl_big;
   hipStream_t comm_stream, small_stream;
   bool own_comm_stream;
+  bool rccl_inline;                         // DRS_RCCL_SINGLE_COMM=1: one communicator, every sum on the compute stream itself, no side stream
   std::vector<hipEvent_t> comm_events;      // ring: [2 h] = data ready on the compute stream, [2 h + 1] = sum done on the side stream
-  int comm_next;
+  int comm_next, comm_ring, comm_in_flight; // ring size (from the number of blocks), asynchronous sums issued since the last wait_handles
   // backward pass of small steps: the filter gradients on a stream of their own beside the batch-norm-backward -> input-gradient
   // chain (two alternating gz slabs); created at first use
   hipStream_t wg_stream;
@@ -401,18 +402,23 @@ struct Timed {
 // lets a one-GPU box drive the whole collective path, RCCL included)
 inline bool collectives(const drs_net* n) { return n->world > 1 || n->allreduce != nullptr || n->rccl_small != nullptr; }
 
-constexpr int COMM_RING = 64;             // asynchronous sums in flight per step: 8 backward sync-BN sums + <= 6 gradient buckets
 constexpr size_t SMALL_BYTES = 16384;     // sums up to here go to the small communicator
 
-int all_reduce(drs_net* n, void* ptr, size_t count, int dtype, int async, hipStream_t st, int* handle) {
+// `big_only`: an asynchronous sum that must not touch the small communicator whatever its size (two-stream backward pass: the
+// small communicator is then driven from the compute stream alone, so every asynchronous sum goes to the big one's stream --
+// one communicator is never driven from two streams that no event orders)
+int all_reduce(drs_net* n, void* ptr, size_t count, int dtype, int async, hipStream_t st, int* handle, bool big_only = false) {
   if (handle) *handle = -1;
   if (!collectives(n)) return DRS_OK;
   if (n->rccl_small) {
     static const size_t esz[4] = {4, 8, 1, 4};
-    const bool small = count * esz[dtype] <= SMALL_BYTES || !n->rccl_big;
+    if (n->rccl_inline) return drs_rccl_all_reduce_sum(n->rccl_small, ptr, count, dtype, st);
+    const bool small = !n->rccl_big || (!(big_only && async) && count * esz[dtype] <= SMALL_BYTES);
     if (!async) return drs_rccl_all_reduce_sum(small ? n->rccl_small : n->rccl_big, ptr, count, dtype, st);
+    if (n->comm_in_flight >= n->comm_ring) return DRS_ERR_ARG;      // an event slot still waited for would be recorded again
+    ++n->comm_in_flight;
     const int h = n->comm_next;
-    n->comm_next = (h + 1) % COMM_RING;
+    n->comm_next = (h + 1) % n->comm_ring;
     hipStream_t side = small ? n->small_stream : n->comm_stream;
     if (hipEventRecord(n->comm_events[2 * h], st) != hipSuccess) return DRS_ERR_HIP;
     if (hipStreamWaitEvent(side, n->comm_events[2 * h], 0) != hipSuccess) return DRS_ERR_HIP;
@@ -430,8 +436,11 @@ int all_reduce(drs_net* n, void* ptr, size_t count, int dtype, int async, hipStr
 
 int wait_handles(drs_net* n, const std::vector<int>& hs, hipStream_t st) {
   if (n->rccl_small) {
-    for (int h : hs)
-      if (h >= 0 && hipStreamWaitEvent(st, n->comm_events[2 * h + 1], 0) != hipSuccess) return DRS_ERR_HIP;
+    for (int h : hs) {
+      if (h < 0) continue;
+      if (hipStreamWaitEvent(st, n->comm_events[2 * h + 1], 0) != hipSuccess) return DRS_ERR_HIP;
+      --n->comm_in_flight;
+    }
     return DRS_OK;
   }
   if (!collectives(n) || !n->wait) return DRS_OK;
@@ -537,6 +546,7 @@ int drs_net_create(const char* net_type, int channels, int num_classes, float we
     n->bessel = bessel_moving_var ? 1 : 0; n->lr_decay = lr_decay_factor; n->global_step = 0;
     n->world = 1; n->rank = 0; n->allreduce = nullptr; n->wait = nullptr; n->comm_user = nullptr; n->timing = false;
     n->rccl_small = n->rccl_big = nullptr; n->comm_stream = n->small_stream = nullptr; n->own_comm_stream = false; n->comm_next = 0;
+    n->rccl_inline = false; n->comm_ring = 0; n->comm_in_flight = 0;
     n->wg_stream = nullptr;
     { const char* e = std::getenv("DRS_TWO_STREAMS"); n->two_stream_mode = e ? std::atoi(e) : -1; }
     build_plan(n);
@@ -558,6 +568,8 @@ static void release_rccl(drs_net* n) {
   n->small_stream = n->comm_stream = nullptr;
   n->own_comm_stream = false;
   n->rccl_small = n->rccl_big = nullptr;
+  n->rccl_inline = false;
+  n->comm_in_flight = 0;
 }
 
 void drs_net_destroy(drs_net_t* n) {
@@ -685,6 +697,7 @@ long long drs_net_global_step(drs_net_t* n, long long set_to) {
 
 int drs_net_set_comm(drs_net_t* n, int world, int rank, drs_allreduce_fn allreduce, drs_wait_fn wait, void* user) {
   if (!n || world < 1 || rank < 0 || rank >= world || (world > 1 && !allreduce)) return DRS_ERR_ARG;
+  release_rccl(n);         // the callback replaces library-side collectives (their streams and events go; the communicators are the caller's)
   n->world = world; n->rank = rank; n->allreduce = allreduce; n->wait = wait; n->comm_user = user;
   return DRS_OK;
 }
@@ -693,13 +706,22 @@ int drs_net_set_comm(drs_net_t* n, int world, int rank, drs_allreduce_fn allredu
 // are ncclComm_t of `world` ranks on this process's GPU (drs_rccl_comm_create, or the host's own from the same librccl);
 // comm_big may be NULL (everything then goes through comm_small); comm_stream (hipStream_t, may be NULL: the library then
 // creates one) carries the gradient buckets.  The communicators stay the caller's: destroy them after the net.
-// Passing comm_small = NULL returns the net to the callback / single-rank form.
+// Passing comm_small = NULL removes library-side collectives: a net that had them returns to the single-rank form; a net on the
+// callback (drs_net_set_comm) or without any communicator is left as it is.
+// DRS_RCCL_SINGLE_COMM=1 in the environment (read here): the conservative form -- comm_big is ignored, every sum is issued on the
+// compute stream itself in program order (no side streams, no events, no two-stream backward pass).
 static int set_rccl_impl(drs_net_t* n, int world, int rank, void* comm_small, void* comm_big, void* comm_stream) {
   if (!n || world < 1 || rank < 0 || rank >= world) return DRS_ERR_ARG;
+  const bool had = n->rccl_small != nullptr;
   release_rccl(n);
-  if (!comm_small) { n->world = 1; n->rank = 0; return DRS_OK; }
+  if (!comm_small) { if (had) { n->world = 1; n->rank = 0; } return DRS_OK; }
   if (!drs_rccl_available()) return DRS_ERR_ARG;
-  n->comm_events.resize(2 * COMM_RING);
+  { const char* e = std::getenv("DRS_RCCL_SINGLE_COMM"); n->rccl_inline = e && std::atoi(e) != 0; }
+  if (n->rccl_inline) comm_big = nullptr;
+  // asynchronous sums in flight between two waits: one per block (backward sync-BN) + one per two blocks (gradient buckets) + 4
+  n->comm_ring = std::max(64, 2 * (int)n->layers.size() + 8);
+  n->comm_in_flight = 0;
+  n->comm_events.resize(2 * (size_t)n->comm_ring);
   for (auto& e : n->comm_events)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return DRS_ERR_HIP;
   if (hipStreamCreateWithFlags(&n->small_stream, hipStreamNonBlocking) != hipSuccess) return DRS_ERR_HIP;
@@ -850,7 +872,7 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
   // host-callback collectives (the host's communicator is ordered against ITS stream, not this one), not while launches are timed
   // (per-kernel figures want kernels alone on the chip), and not from 2^18 pixels (measured: nothing to gain at B >= 64).
   bool two = n->two_stream_mode > 0 || (n->two_stream_mode < 0 && M < (1 << 18));
-  if (n->allreduce || n->timing) two = false;
+  if (n->allreduce || n->timing || n->rccl_inline || (n->rccl_small && !n->rccl_big)) two = false;     // (one communicator: one stream)
   if (two && !n->wg_stream) {
     bool ok = hipStreamCreateWithFlags(&n->wg_stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < 2; ++i)
@@ -870,7 +892,7 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     }
     if (collectives(n) && i > 0 && (nL - i) % 2 == 0) {      // every second layer: one bucket
       int h;
-      DRS_TRY(all_reduce(n, grads + L.w_off, bucket_hi - L.w_off, F32, 1, ws, &h));
+      DRS_TRY(all_reduce(n, grads + L.w_off, bucket_hi - L.w_off, F32, 1, ws, &h, two));
       pending.push_back(h);
       bucket_hi = L.w_off;
     }
@@ -941,12 +963,14 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
   }
   if (collectives(n)) {
     int h;
-    DRS_TRY(all_reduce(n, grads, bucket_hi, F32, 1, st, &h));                         // the remaining (earliest) layers
+    DRS_TRY(all_reduce(n, grads, bucket_hi, F32, 1, st, &h, two));                         // the remaining (earliest) layers
     pending.push_back(h);
-    DRS_TRY(all_reduce(n, grads + n->cls_w, n->n_params - n->cls_w, F32, 1, st, &h)); // classifier, SE layers and every bias (small)
+    DRS_TRY(all_reduce(n, grads + n->cls_w, n->n_params - n->cls_w, F32, 1, st, &h, two)); // classifier, SE layers and every bias (small)
     pending.push_back(h);
-    // (library-side RCCL: the backward phase's small sums all go through the small communicator's side stream, in order -- one
-    // communicator is never driven from two streams at once)
+    // (library-side RCCL: one communicator is never driven from two streams that no event orders.  One-stream backward pass: the
+    // backward phase's small sums all go through the small communicator's side stream, in order.  Two-stream backward pass: the
+    // small communicator is driven from the compute stream alone -- the backward sync-BN sums above, these two -- and every
+    // asynchronous sum, the small tail bucket included, went to the big communicator's stream: `big_only`.)
     const int side = (n->rccl_small && !two) ? 1 : 0;
     DRS_TRY(all_reduce(n, scalars, 1, F64, side, st, &h));
     pending.push_back(h);

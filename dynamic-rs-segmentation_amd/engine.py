@@ -37,6 +37,7 @@ class EngineTimer(KernelTimer):
 
 class EngineNet(DilatedNet):
     h = None
+    ranks_observed = 1          # ranks a sum of ones over the step's communicator came back with (set when a communicator is installed)
 
     # ------------------------------------------------------------------ buffers
     def _alloc_params(self):
@@ -122,8 +123,9 @@ class EngineNet(DilatedNet):
             # the choice of path is itself collective: every rank takes the callback unless every rank holds two working communicators
             ok = self.comm.all_true(err is None)
             if ok:
-                _lib.call("drs_net_set_rccl", self.h, self.comm.world, self.comm.rank, self._rccl[0], self._rccl[1], None)
-                self.collectives = "rccl"
+                single = len(self._rccl) == 1
+                _lib.call("drs_net_set_rccl", self.h, self.comm.world, self.comm.rank, self._rccl[0], None if single else self._rccl[1], None)
+                self.collectives = "rccl (one communicator, compute stream only: DRS_RCCL_SINGLE_COMM)" if single else "rccl"
                 return
             if os.environ.get("DRS_COMM") == "rccl":
                 raise err or _lib.DrsError("library-side RCCL collectives failed on another rank")
@@ -132,12 +134,23 @@ class EngineNet(DilatedNet):
         self._install_callback()
 
     def _install_rccl(self):
-        ids = []
-        for _ in range(2):                      # small (latency-bound sums) and big (gradient buckets) communicators
-            buf = (C.c_ubyte * 128)()
-            if self.comm.rank == 0:
-                _lib.call("drs_rccl_unique_id", buf)
-            ids.append(self.comm.broadcast_object(bytes(buf), src=0))
+        import os
+        # small (latency-bound sums) and big (gradient buckets) communicators; DRS_RCCL_SINGLE_COMM=1: one, driven from the compute
+        # stream alone (the library reads the same variable in drs_net_set_rccl)
+        ncomm = 1 if os.environ.get("DRS_RCCL_SINGLE_COMM", "0") not in ("", "0") else 2
+        ok, payload = True, []
+        if self.comm.rank == 0:
+            try:
+                for _ in range(ncomm):
+                    buf = (C.c_ubyte * 128)()
+                    _lib.call("drs_rccl_unique_id", buf)
+                    payload.append(bytes(buf))
+            except Exception as e:          # every rank must leave the id exchange together (loops.rank0_call does the same)
+                ok, payload = False, repr(e)
+        ok, payload = self.comm.broadcast_object((ok, payload), src=0)
+        if not ok:
+            raise _lib.DrsError("rank 0 could not make the RCCL ids: %s" % payload)
+        ids = payload
         torch.cuda.set_device(self.dev)
         self._rccl = []
         for raw in ids:
@@ -152,13 +165,18 @@ class EngineNet(DilatedNet):
             for dt, code in ((torch.float32, 0), (torch.float64, 1), (torch.int32, 3)):
                 t = torch.tensor([r + 1, 1, -(r + 1) * 3], dtype=dt, device=self.dev)
                 _lib.call("drs_rccl_all_reduce", h, t.data_ptr(), 3, code, st)
-                if t.cpu().tolist() != [W * (W + 1) // 2, W, -3 * (W * (W + 1) // 2)]:
-                    bad.append((str(dt), t.cpu().tolist()))
+                got = t.cpu().tolist()
+                if got != [W * (W + 1) // 2, W, -3 * (W * (W + 1) // 2)]:
+                    bad.append((str(dt), got))
+                self.ranks_observed = int(got[1])        # the sum of one `1` per rank, as RCCL delivered it
         if bad:
             raise _lib.DrsError("library-side RCCL all-reduce at world %d returned %s" % (W, bad))
 
     def _install_callback(self):
         self.collectives = "callback"
+        ones = torch.ones(1, dtype=torch.int32, device=self.dev)
+        self.comm.all_reduce_sum(ones)
+        self.ranks_observed = int(ones.item())           # what the host's communicator sums one `1` per rank to
         spans = sorted((t.data_ptr(), t.data_ptr() + t.numel() * t.element_size(), t) for t in self._bufs.values())
         self._works = {}
         self._next_handle = 0

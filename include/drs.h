@@ -299,7 +299,16 @@ int drs_net_set_comm(drs_net_t* net, int world, int rank, drs_allreduce_fn allre
  * `world` ranks on this process's GPU, made by drs_rccl_comm_create below or by the host from the same librccl; comm_big may be
  * NULL.  comm_small carries the latency-bound sums (forward sync-BN statistics on the compute stream itself, backward ones on a
  * side stream under the filter gradient of the block above), comm_big the gradient buckets on comm_stream (hipStream_t; NULL: the
- * library creates one).  The communicators remain the caller's (destroy them after the net).  comm_small = NULL undoes it.
+ * library creates one).  The communicators remain the caller's (destroy them after the net).  comm_small = NULL removes the
+ * library-side collectives (a net on the drs_net_set_comm callback, or without any communicator, is left as it is); conversely
+ * drs_net_set_comm replaces library-side collectives by the callback.  One communicator is never driven from two streams that no
+ * event orders: with the two-stream backward pass of small steps (fewer than 2^18 pixels per rank) comm_small stays on the compute
+ * stream and every asynchronous sum goes to comm_big; with comm_big = NULL that pass is off.
+ * DRS_RCCL_SINGLE_COMM=1 in the environment (read by drs_net_set_rccl): the conservative form -- comm_big is ignored and every sum
+ * is issued on the compute stream itself in program order (no side streams, no events, no second communicator).
+ * A host that binds this ABI directly must have HSA_ENABLE_IPC_MODE_LEGACY=0 in its environment BEFORE the HIP runtime starts
+ * (the first HIP call of the process): on this driver RCCL's intra-node transport needs dmabuf IPC and ncclCommInitRank otherwise
+ * fails with `hipIpcGetMemHandle: invalid argument` (the Python client and bench.py set it at import).
  *   drs_rccl_available : 1 if librccl could be bound.
  *   drs_rccl_unique_id : ncclGetUniqueId into id128 (128 bytes, host memory); rank 0 calls it, the host hands the bytes to every rank.
  *   drs_rccl_comm_create / _destroy : ncclCommInitRank / ncclCommDestroy (collective over the ranks; the device must be current).

@@ -1,0 +1,67 @@
+"""CPU: the launch plumbing of bench.py for N > 1 (no GPU: DRS_BENCH_SELFTEST=1 replaces the measurement by a gloo barrier).
+
+`python bench.py --gpus N` without a launcher must start torch.distributed.run itself as a fresh child; under either launch shape
+every rank is a supervisor that starts the measuring process as a child, watches its progress markers and, on a hang or a crash,
+kills it and starts a FRESH child on the next collectives path (DRS_COMM=torch, then DRS_RCCL_SINGLE_COMM=1) -- the one 8-GPU run
+a round gets must not be lost to a hang in the dual-communicator RCCL path."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(cmd, tmp_path, **env):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "DRS_BENCH_CHILD", "DRS_COMM", "DRS_RCCL_SINGLE_COMM"):
+        e.pop(k, None)
+    e.update(DRS_BENCH_SELFTEST="1", **env)
+    r = subprocess.run(cmd, cwd=str(tmp_path), env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    out = r.stdout.decode()
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    return r.returncode, lines, r.stderr.decode()
+
+
+def test_plain_launch_starts_the_launcher_itself(tmp_path):
+    rc, lines, err = _run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1"], tmp_path)
+    assert rc == 0, err
+    assert len(lines) == 1                                   # ONE JSON line on stdout, nothing else
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["ranks_observed"] == 2
+    assert d["config"]["collectives"] == "selftest" and d["config"]["fallback_reason"] is None
+    assert "stage=warm-up done" in err
+
+
+def test_under_the_launcher_every_rank_supervises_a_fresh_child(tmp_path):
+    port = 23000 + os.getpid() % 5000
+    rc, lines, err = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), BENCH, "--gpus", "2"], tmp_path)
+    assert rc == 0, err
+    assert len(lines) == 1 and json.loads(lines[0])["config"]["ranks_observed"] == 2
+
+
+def test_a_hang_before_warm_up_falls_back_to_the_callback_path(tmp_path):
+    rc, lines, err = _run([sys.executable, BENCH, "--gpus", "2"], tmp_path, DRS_BENCH_FAKE_HANG="default", DRS_BENCH_WATCHDOG_S="4")
+    assert rc == 0, err
+    d = json.loads(lines[-1])
+    assert len(lines) == 1 and d["config"]["collectives"] == "selftest (fallback after timeout)"
+    assert "timeout" in d["config"]["fallback_reason"] and "process group up" in d["config"]["fallback_reason"]
+    assert d["config"]["env"]["DRS_COMM"] == "torch" and d["config"]["ranks_observed"] == 2
+    assert err.count("killing the process group") == 2      # both ranks' supervisors killed their own child
+
+
+def test_crashes_walk_the_chain_to_the_single_communicator_form(tmp_path):
+    rc, lines, err = _run([sys.executable, BENCH, "--gpus", "2"], tmp_path, DRS_BENCH_FAKE_CRASH="default,torch", DRS_BENCH_WATCHDOG_S="30")
+    assert rc == 0, err
+    d = json.loads(lines[-1])
+    assert d["config"]["collectives"] == "selftest (fallback after failure)"
+    assert d["config"]["env"]["DRS_RCCL_SINGLE_COMM"] == "1" and d["config"]["env"]["DRS_COMM"] == "rccl"
+
+
+def test_every_attempt_failing_is_reported_not_hung(tmp_path):
+    rc, lines, err = _run([sys.executable, BENCH, "--gpus", "2"], tmp_path, DRS_BENCH_FAKE_CRASH="default,torch,single", DRS_BENCH_WATCHDOG_S="30")
+    assert rc != 0
+    d = json.loads(lines[-1])
+    assert d["value"] is None and "every attempt failed" in d["error"]

@@ -60,6 +60,83 @@ def test_two_rank_step_equals_single_rank(tmp_path):
     np.testing.assert_array_equal(r["conf"], res["conf"].cpu().numpy())
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# several steps, decision-aligned: data-parallel equivalence beyond one step.  Two correct runs drift apart step by step through
+# ReLU signs / pool winners that flip on last-bit differences of the batch statistics, so a free comparison of a
+# two-rank run with a one-rank run says little after the first update; the ORACLE can be told the ranks' own discrete decisions
+# (concatenated along the batch) and then has to reproduce every continuous quantity of every step tightly -- the same device the
+# single-rank trajectory tests use (tests/test_gpu_net.py).
+DP_STEPS = 4
+
+
+def _dp_inputs(step):
+    rng = np.random.default_rng(100 + step)
+    return rng.normal(size=(B, S, S, CH)).astype(np.float32), rng.integers(0, K, size=(B, S, S))
+
+
+def _multi_worker(rank, world, port, root):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from drs_amd.dist import TorchComm, shard_slice
+    from drs_amd.net import DilatedNet
+    torch.cuda.set_device(0)
+    comm = TorchComm("gloo")
+    sl = shard_slice(B, rank, world)
+    b = B // world
+    d = DilatedNet(NET, CH, K, 0.005, b_max=b, s_max=S, device="cuda:0", seed=3, comm=comm)
+    M = b * S * S
+    for step in range(DP_STEPS):
+        x, y = _dp_inputs(step)
+        d.feed(x[sl].reshape(b, -1), y[sl].reshape(b, -1), S)
+        res = d.train_step(b, S, 0.01)
+        torch.cuda.synchronize()
+        dec = {}
+        for i, L in enumerate(d.plan.layers):
+            z = d.z[i][:M * L.cout].cpu().numpy().reshape(b, S, S, L.cout)
+            mr = d.mean_rstd[i].cpu().numpy().reshape(L.cout, 2)
+            dec["pos%d" % i] = (z - mr[:, 0]) * mr[:, 1] > 0
+            dec["idx%d" % i] = d.idx[i][:M * L.cout].cpu().numpy().reshape(b, S, S, L.cout)
+        np.savez(os.path.join(root, "dec_r%d_s%d.npz" % (rank, step)), loss=d.loss_value(res["loss_parts"]), conf=res["conf"].cpu().numpy(), **dec)
+    if rank == 0:
+        np.savez(os.path.join(root, "final.npz"), **d.state_dict())
+    comm.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_trajectory_follows_the_decision_aligned_oracle(tmp_path):
+    from oracle import tf_ops as T
+    from drs_amd.net import DilatedNet
+    root = str(tmp_path)
+    mp.spawn(_multi_worker, args=(2, 29800 + os.getpid() % 1000, root), nprocs=2, join=True)
+    ref = DilatedNet(NET, CH, K, 0.005, b_max=B, s_max=S, device="cuda:0", seed=3)      # the same initial variables (seed 3)
+    o = T.OracleNet(NET, CH, K, dtype=np.float64, seed=0)
+    for n in ref.variable_names():
+        o.p[n] = ref.get_variable(n).astype(np.float64)
+    nl = len(ref.plan.layers)
+    for step in range(DP_STEPS):
+        x, y = _dp_inputs(step)
+        r = [np.load(os.path.join(root, "dec_r%d_s%d.npz" % (q, step))) for q in range(2)]
+        dec = [{"pos": np.concatenate([r[0]["pos%d" % i], r[1]["pos%d" % i]]), "idx": np.concatenate([r[0]["idx%d" % i], r[1]["idx%d" % i]])}
+               for i in range(nl)]
+        lo, _ = o.train_step(x.astype(np.float64), y, 0.01, 0.005, decisions=dec)
+        assert float(r[0]["loss"]) == float(r[1]["loss"])                                # every rank holds the global loss
+        assert abs(float(r[0]["loss"]) - lo) < 1e-4 * abs(lo), (step, float(r[0]["loss"]), lo)
+        np.testing.assert_array_equal(r[0]["conf"], r[1]["conf"])
+        assert int(r[0]["conf"].sum()) == B * S * S                                      # the confusion matrix counts the GLOBAL batch
+    fin = np.load(os.path.join(root, "final.npz"))
+
+    def rel(a, b):
+        return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
+    for n in ref.plan.offsets:
+        assert rel(fin[n], o.p[n]) < 1e-4, n
+        if not (n.endswith("/biases") and n != "conv_classifier/biases"):
+            assert rel(fin[n + "/Momentum"], o.mom[n]) < 1e-3, n
+    for n in ref.variable_names():
+        if "moving" in n:
+            assert rel(fin[n], o.p[n]) < 1e-5, n
+    assert int(fin["main_global_step"]) == DP_STEPS
+
+
 def _rccl_worker(rank, world, port, out, mode):
     """ONE rank on the real backend ('nccl' = RCCL) with every collective of the step forced on (sums over one rank are identities):
     communicator bound to the device, asynchronous gradient buckets, sync-BN sums, stream waits -- the code an 8-GPU run executes."""
