@@ -65,6 +65,9 @@ SIGNATURES = {
     "drs_net_buffer": (_i, [_p, C.c_char_p, C.POINTER(_p), C.POINTER(_sz)]),
     "drs_net_layout": (_i, [_p, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "drs_net_layer_info": (_i, [_p, _i, C.c_char_p, _i, C.POINTER(_i), C.c_char_p, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "drs_net_info": (_i, [_p, C.c_char_p, _i, C.POINTER(_f), C.POINTER(_i), C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "drs_net_se_info": (_i, [_p, _i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "drs_net_type_name": (_i, [_i, C.c_char_p, _i, C.POINTER(_i)]),
     "drs_net_num_variables": (_i, [_p]),
     "drs_net_variable_info": (_i, [_p, _i, C.c_char_p, _i, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_i), C.POINTER(_i)]),
     "drs_params_get": (_i, [_p, C.c_char_p, C.c_char_p, _p, _sz, _p]),

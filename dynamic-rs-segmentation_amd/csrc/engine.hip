@@ -647,6 +647,50 @@ int drs_net_layer_info(const drs_net_t* n, int index, char* name, int name_cap, 
   return DRS_OK;
 }
 
+// the net as a whole: the canonical net_type (aliases resolved: 'dilated8_grsl' -> 'dilated_grsl_rate8'), the activation's alpha
+// (max(alpha x, x): 0 = ReLU, 0.1 = leaky ReLU, isprs:620-621), the classifier's input width, the slab the classifier reads, the
+// topology (0 chain, 1 dense concat isprs:921-948, 2 squeeze isprs:726-742) and the number of squeeze-and-excitation blocks
+int drs_net_info(const drs_net_t* n, char* net_type, int name_cap, float* alpha, int* c_last, char* feat_slab, int slab_cap, int* topology,
+                 int* n_se) {
+  if (!n) return DRS_ERR_ARG;
+  auto put = [](char* dst, int cap, const std::string& v) { if (dst && cap > 0) { std::strncpy(dst, v.c_str(), cap - 1); dst[cap - 1] = 0; } };
+  put(net_type, name_cap, n->table->net_type);
+  put(feat_slab, slab_cap, n->slabs[n->feat].name);
+  if (alpha) *alpha = n->alpha;
+  if (c_last) *c_last = n->c_last;
+  if (topology) *topology = (int)n->table->topo;
+  if (n_se) *n_se = (int)n->se.size();
+  return DRS_OK;
+}
+
+// squeeze-and-excitation block `index` (isprs:682-697, 1042-1050): its scope ("se1": variables <scope>_fc1/weights, ...), the block
+// whose activation it scales, channels and the reduced width C / 4
+int drs_net_se_info(const drs_net_t* n, int index, char* scope, int scope_cap, int* layer, int* channels, int* reduced) {
+  if (!n || index < 0 || index >= (int)n->se.size()) return DRS_ERR_ARG;
+  const SeBlock& s = n->se[index];
+  if (scope && scope_cap > 0) { std::strncpy(scope, s.scope.c_str(), scope_cap - 1); scope[scope_cap - 1] = 0; }
+  if (layer) *layer = s.layer;
+  if (channels) *channels = s.C;
+  if (reduced) *reduced = s.R;
+  return DRS_OK;
+}
+
+// the net_type strings drs_net_create accepts (the if-chains isprs:1660-1680, coffee:1188-1215, contest:995-1012), one per index:
+// the tables first, then the aliases; *canonical = index of the table an alias resolves to (its own index for a table)
+int drs_net_type_name(int index, char* name, int name_cap, int* canonical) {
+  const int nt = (int)(sizeof(kTables) / sizeof(kTables[0])), na = (int)(sizeof(kAliases) / sizeof(kAliases[0]));
+  if (index < 0 || index >= nt + na) return DRS_ERR_ARG;
+  const char* v = index < nt ? kTables[index].net_type : kAliases[index - nt][0];
+  if (name && name_cap > 0) { std::strncpy(name, v, name_cap - 1); name[name_cap - 1] = 0; }
+  if (canonical) {
+    *canonical = index;
+    if (index >= nt)
+      for (int i = 0; i < nt; ++i)
+        if (std::string(kTables[i].net_type) == kAliases[index - nt][1]) *canonical = i;
+  }
+  return DRS_OK;
+}
+
 int drs_net_layout(const drs_net_t* n, size_t* n_params, size_t* n_decay, size_t* n_bn, int* n_layers, int* x0_channels, int* x0_halo) {
   if (!n) return DRS_ERR_ARG;
   if (n_params) *n_params = n->n_params;

@@ -281,6 +281,17 @@ int drs_net_layout(const drs_net_t* net, size_t* n_params, size_t* n_decay, size
  * its activation: 0 none, 1 max 3x3 / stride 1, 2 + 256 k = k x k average */
 int drs_net_layer_info(const drs_net_t* net, int index, char* name, int name_cap, int* geom8, char* src_slab, char* dst_slab, int slab_cap,
                        int* dst_coff, int* pool);
+/* the net as a whole: canonical net_type (aliases resolved), alpha of max(alpha x, x) (0 ReLU, 0.1 leaky ReLU: isprs:620-621), the
+ * classifier's input width (isprs:1024-1031), the slab it reads, the topology (0 chain, 1 dense concat isprs:921-948, 2 squeeze
+ * isprs:726-742) and the number of squeeze-and-excitation blocks (isprs:1036-1061) */
+int drs_net_info(const drs_net_t* net, char* net_type, int name_cap, float* alpha, int* c_last, char* feat_slab, int slab_cap, int* topology,
+                 int* n_se);
+/* squeeze-and-excitation block `index`: scope ("se1": variables <scope>_fc1/weights ...), the block whose activation it scales,
+ * channels C and the reduced width C / 4 (isprs:682-697) */
+int drs_net_se_info(const drs_net_t* net, int index, char* scope, int scope_cap, int* layer, int* channels, int* reduced);
+/* the net_type strings drs_net_create accepts -- the if-chains isprs:1660-1680, coffee:1188-1215, contest:995-1012 -- one per index
+ * (DRS_ERR_ARG past the end): the tables, then the aliases; *canonical = index of the table the name resolves to */
+int drs_net_type_name(int index, char* name, int name_cap, int* canonical);
 /* variables under their TensorFlow scope names (`conv1/weights`, `conv1/biases`, `conv1/moving_mean`, `conv1/moving_variance`,
  * `conv_classifier/weights`, ...: what tf.train.Saver stores, isprs:1693-1695): offset / count in floats inside "params" (and
  * "grads", "momentum") or, with *in_bn = 1, inside "bn"; shape4 = HWIO for kernels */

@@ -354,7 +354,7 @@ def _band_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 6])       # (6: as many ranks as a one-GPU box lets share its card; an 8-GPU node runs 8 bands)
 def test_band_partitioned_inference_equals_single_process(tmp_path, world):
     from drs_amd import loops, patches as P
     from drs_amd.net import DilatedNet
@@ -374,3 +374,52 @@ def test_band_partitioned_inference_equals_single_process(tmp_path, world):
     assert clear.mean() > 0.99 and got.shape == want.shape
     np.testing.assert_array_equal(got[clear], want[clear])        # the float sums associate differently at band boundaries only
     assert (got != want).mean() < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# rehearsals at the rank counts of the BASELINE configurations, as far as one GPU allows (a GPU box admits 6 processes on its card):
+# configs[2]'s command line with the per-rank batch of the 8-GPU run (16 patches, `uniform` over [25, 85]) on 6 ranks, and
+# configs[3] (DenseDilated6, `multinomial`, update_type=loss, coffee tiles) on its own 4 ranks.  All ranks on cuda:0 over gloo.
+CONFIG3_ARGV = ["isprs_dilated_random.py", "synthetic:200x220x5/vaihingen/", "OUT", "none", "a", "c", "0.01", "0.005", "96", "3", "25", "10",
+                "dilated_grsl_rate8", "uniform", "25,85", "acc", "training"]
+CONFIG4_ARGV = ["coffee_dilated_random.py", "synthetic:2x120x120x4/", "synthetic:1x120x120x4/", "OUT", "none", "0.01", "0.001", "16", "3", "25", "10",
+                "dilated_icpr_rate6_densely", "multinomial", "25,50,75,100", "loss"]
+
+
+def _rehearsal_worker(rank, world, port, root, which):
+    import random
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      DRS_DIST_REHEARSAL="1")
+    import torch.distributed as dist
+    from drs_amd import cli
+    os.chdir(root)
+    random.seed(80 + rank)
+    np.random.seed(90 + rank)
+    argv = list(CONFIG3_ARGV if which == "config3" else CONFIG4_ARGV)
+    argv[argv.index("OUT")] = os.path.join(root, "dp_")
+    net = (cli.main if which == "config3" else cli.main_coffee)(argv)
+    assert net.comm.world == world and net.b_max == int(argv[8 if which == "config3" else 7]) // world
+    torch.cuda.synchronize()
+    np.save(os.path.join(root, "params_r%d.npy" % rank), net.params.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("which,world", [("config3", 6), ("config4", 4)])
+def test_rank_counts_of_the_baseline_configurations_rehearsed_on_one_gpu(tmp_path, which, world):
+    root = str(tmp_path)
+    env0 = dict(os.environ)
+    try:
+        mp.spawn(_rehearsal_worker, args=(world, 30900 + os.getpid() % 1000, root, which), nprocs=world, join=True)
+    finally:
+        os.environ.clear()
+        os.environ.update(env0)
+    files = sorted(os.listdir(root))
+    assert "dp_model-3.npz" in files and not [f for f in files if ".tmp" in f]
+    side = "dp_patch_occur_step_3.npy" if which == "config3" else "dp_errorOccur_step_3.npy"
+    occ = np.load(os.path.join(root, side))
+    assert occ.sum() == 3 and len(occ) == (61 if which == "config3" else 76)          # every step scored its size once, on rank 0 only
+    ref = np.load(os.path.join(root, "params_r0.npy"))
+    assert np.isfinite(ref).all()
+    for r in range(1, world):                                                           # replicated optimizer: every rank holds the same variables
+        np.testing.assert_array_equal(np.load(os.path.join(root, "params_r%d.npy" % r)), ref)
