@@ -17,9 +17,10 @@ never the headline `value`.
 
 N > 1 cannot be lost to a hang in the collectives.  Every rank process of the launcher is a SUPERVISOR that never touches the
 GPU: it starts the measuring process as a fresh child, relays its output, and watches its progress markers on stderr.  If a child
-is silent for DRS_BENCH_WATCHDOG_S seconds (default 300) or dies, the supervisor kills it and starts a fresh child with the next
-entry of DRS_BENCH_FALLBACKS (default "torch,single": the torch.distributed callback for every sum, then library-side RCCL with one
-communicator on the compute stream) on a rendezvous port of its own; the JSON line then says which path ran and why
+is silent for DRS_BENCH_WATCHDOG_S seconds (default 300; DRS_BENCH_WATCHDOG_STAGE_S = 120 once its imports are done) or dies, the supervisor kills it and starts a fresh child with the next
+entry of DRS_BENCH_FALLBACKS (default "torch,async": the torch.distributed callback for every sum, then library-side RCCL in its
+asynchronous two-communicator form; the first attempt is library-side RCCL inline, one communicator on the compute stream) on a
+rendezvous port of its own; the JSON line then says which path ran and why
 (`config.collectives`, `config.fallback_reason`).  A process that has touched the GPU is never re-executed.
 """
 import argparse
@@ -45,7 +46,7 @@ def load_numerics():
 
 # ------------------------------------------------------------------------------------------------ launch plumbing (no GPU, no torch)
 MARK = "DRS_BENCH_MARK"
-FALLBACK_ENV = {"torch": {"DRS_COMM": "torch"}, "single": {"DRS_COMM": "rccl", "DRS_RCCL_SINGLE_COMM": "1"}}
+FALLBACK_ENV = {"torch": {"DRS_COMM": "torch"}, "async": {"DRS_COMM": "rccl", "DRS_RCCL_ASYNC": "1"}}
 
 
 def mark(stage, rank=None):
@@ -101,7 +102,12 @@ def _run_watched(cmd, env, limit_s, need_marks=True, rendezvous_slack=1.0):
             proc.wait(timeout=1.0)
             break
         except subprocess.TimeoutExpired:
-            lim = limit_s * (rendezvous_slack if state["stage"] in ("started", "imports done") else 1.0)
+            # until its imports are done a process may be paging the image in (minutes on a fresh box): the long limit; after that
+            # every stage is seconds long: the short one (rendezvous of a fall-back attempt: the ranks arrive up to a period apart)
+            stage_s = float(os.environ.get("DRS_BENCH_WATCHDOG_STAGE_S", "120"))
+            lim = limit_s if state["stage"] == "started" else min(limit_s, stage_s)
+            if state["stage"] in ("started", "imports done"):
+                lim *= rendezvous_slack
             if need_marks and time.time() - state["last"] > lim:
                 sys.stderr.write("bench.py watchdog: no progress marker for %.0f s after stage '%s': killing the process group\n" % (lim, state["stage"]))
                 _kill_group(proc)
@@ -115,7 +121,7 @@ def _run_watched(cmd, env, limit_s, need_marks=True, rendezvous_slack=1.0):
 def supervise(argv):
     """one rank of the launcher: start the measuring process as a child, fall back on a hang or a crash.  Never touches the GPU."""
     limit = float(os.environ.get("DRS_BENCH_WATCHDOG_S", "300"))
-    chain = [("default", {})] + [(k, FALLBACK_ENV[k]) for k in os.environ.get("DRS_BENCH_FALLBACKS", "torch,single").split(",") if k in FALLBACK_ENV]
+    chain = [("default", {})] + [(k, FALLBACK_ENV[k]) for k in os.environ.get("DRS_BENCH_FALLBACKS", "torch,async").split(",") if k in FALLBACK_ENV]
     port0 = int(os.environ.get("MASTER_PORT", "29500"))
     reason = ""
     for i, (label, extra) in enumerate(chain):
@@ -189,7 +195,7 @@ def selftest_worker(args):
         os.write(json_fd, (json.dumps({"metric": "selftest", "value": 1.0, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "config": {"collectives": collectives_label("selftest"), "fallback_reason": os.environ.get("DRS_BENCH_FALLBACK_REASON") or None,
                                      "ranks_observed": int(ones.item()) if ones is not None else 1,
-                                     "env": {k: os.environ.get(k) for k in ("DRS_COMM", "DRS_RCCL_SINGLE_COMM", "MASTER_PORT")}}}) + "\n").encode())
+                                     "env": {k: os.environ.get(k) for k in ("DRS_COMM", "DRS_RCCL_ASYNC", "MASTER_PORT")}}}) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
     return 0

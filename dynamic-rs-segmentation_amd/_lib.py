@@ -33,6 +33,7 @@ SIGNATURES = {
     "drs_bn_finish": (_i, [_p, _d, _i, _p, _p, _p, _d, _i, _p]),
     "drs_bn_eval_coeffs": (_i, [_p, _p, _i, _p, _p]),
     "drs_bn_act_pool_forward": (_i, [_p, _i, _i, _i, _p, _f, _i, _p, _i, _i, _i, _p, _p]),
+    "drs_bn_finish_act_pool_forward": (_i, [_p, _d, _p, _p, _p, _d, _i, _p, _i, _i, _i, _f, _i, _p, _i, _i, _i, _p, _p]),
     "drs_bn_act_pool_forward_terms": (_i, [_p, _i, _i, _i, _p, _f, _i, _p, _i, _i, _i, _p, _p, _i, _p]),
     "drs_bn_backward_rows": (_i, [_i, _i, _i, _i]),
     "drs_bn_backward_reduce": (_i, [_p, _i, _i, _p, _p, _i, _i, _i, _p, _f, _i, _p, _p, _p]),

@@ -154,7 +154,7 @@ struct drs_net {
   void* rccl_big;
   hipStream_t comm_stream, small_stream;
   bool own_comm_stream;
-  bool rccl_inline;                         // DRS_RCCL_SINGLE_COMM=1: one communicator, every sum on the compute stream itself, no side stream
+  bool rccl_inline;                         // (default) one communicator, every sum on the compute stream itself in program order; DRS_RCCL_ASYNC=1: side streams
   std::vector<hipEvent_t> comm_events;      // ring: [2 h] = data ready on the compute stream, [2 h + 1] = sum done on the side stream
   int comm_next, comm_ring, comm_in_flight; // ring size (from the number of blocks), asynchronous sums issued since the last wait_handles
   // backward pass of small steps: the filter gradients on a stream of their own beside the batch-norm-backward -> input-gradient
@@ -476,12 +476,15 @@ int forward_layers(drs_net* n, int B, int S, bool training, double count, hipStr
     }
     float* mm = bn + L.bn_off;
     float* mv = mm + L.cout;
+    bool fold_finish = false;
     if (training && !collectives(n)) {
       DRS_TRY(drs_conv_stats_finish(partial, (int)M, drs_conv_mtile(L.cout), L.cout, count, mr, mm, mv, BN_DECAY, n->bessel, nullptr, st));
     } else if (training) {
       DRS_TRY(drs_conv_stats_reduce(partial, (int)M, drs_conv_mtile(L.cout), L.cout, sums, nullptr, st));
       DRS_TRY(all_reduce(n, sums, 2 * (size_t)L.cout, F64, 0, st, nullptr));          // sync batch norm over the global batch
-      DRS_TRY(drs_bn_finish(sums, count, L.cout, mr, mm, mv, BN_DECAY, n->bessel, st));
+      // (a plain pooled block: the kernel that normalises works mean / rstd / moving averages out of the sums itself, below)
+      fold_finish = L.pool == 1 && L.se < 0 && L.cout <= 512;
+      if (!fold_finish) DRS_TRY(drs_bn_finish(sums, count, L.cout, mr, mm, mv, BN_DECAY, n->bessel, st));
     } else {
       DRS_TRY(drs_bn_eval_coeffs(mm, mv, L.cout, mr, st));
     }
@@ -513,7 +516,11 @@ int forward_layers(drs_net* n, int B, int S, bool training, double count, hipStr
       const int hz = (mx && whole && n->halo_ok[L.dst] == key) ? 2 : 0;
       n->halo_ok[L.dst] = (mx && whole) ? key : -1;
       Timed t(n, st, K_BN_FWD, M * L.cout * ((training && mx) ? 9.0 : 8.0));
-      DRS_TRY(drs_bn_act_pool_forward(z, B, S, L.cout, mr, n->alpha, (mx ? 1 : 0) | hz, outp, out.P, out.C, L.dst_coff, idx, st));
+      if (fold_finish)
+        DRS_TRY(drs_bn_finish_act_pool_forward(sums, count, mr, mm, mv, BN_DECAY, n->bessel, z, B, S, L.cout, n->alpha, 1 | hz, outp, out.P, out.C,
+                                               L.dst_coff, idx, st));
+      else
+        DRS_TRY(drs_bn_act_pool_forward(z, B, S, L.cout, mr, n->alpha, (mx ? 1 : 0) | hz, outp, out.P, out.C, L.dst_coff, idx, st));
     }
   }
   return DRS_OK;
@@ -752,15 +759,21 @@ int drs_net_set_comm(drs_net_t* n, int world, int rank, drs_allreduce_fn allredu
 // creates one) carries the gradient buckets.  The communicators stay the caller's: destroy them after the net.
 // Passing comm_small = NULL removes library-side collectives: a net that had them returns to the single-rank form; a net on the
 // callback (drs_net_set_comm) or without any communicator is left as it is.
-// DRS_RCCL_SINGLE_COMM=1 in the environment (read here): the conservative form -- comm_big is ignored, every sum is issued on the
-// compute stream itself in program order (no side streams, no events, no two-stream backward pass).
+// Default form (r04): INLINE -- comm_big is ignored; every sum is issued on the compute stream itself, in program order: the 16 sync-BN
+// sums where they are needed, the whole gradient buffer as ONE all-reduce after the last filter gradient, then the loss and the
+// confusion matrix.  No side stream, no event, one communicator driven from one stream.  Measured at world 1 with every collective
+// forced on (B = 16, S = 64; profiles/r04/collectives_forms_world1.txt): no collectives 6.97 ms, inline 7.10, the asynchronous form
+// below 7.36 -- and 7.36 with the RCCL calls themselves skipped: what the asynchronous form costs is its own cross-stream event
+// hand-overs (~25 of them a step), which is about what overlapping 8 MB of gradient buckets and eight 2 KB sums could save on 8 GPUs.
+// DRS_RCCL_ASYNC=1 in the environment (read here) selects that form: backward sync-BN sums on a side stream under the filter
+// gradient of the block above, gradient buckets on comm_big's stream as the layers finish.
 static int set_rccl_impl(drs_net_t* n, int world, int rank, void* comm_small, void* comm_big, void* comm_stream) {
   if (!n || world < 1 || rank < 0 || rank >= world) return DRS_ERR_ARG;
   const bool had = n->rccl_small != nullptr;
   release_rccl(n);
   if (!comm_small) { if (had) { n->world = 1; n->rank = 0; } return DRS_OK; }
   if (!drs_rccl_available()) return DRS_ERR_ARG;
-  { const char* e = std::getenv("DRS_RCCL_SINGLE_COMM"); n->rccl_inline = e && std::atoi(e) != 0; }
+  { const char* e = std::getenv("DRS_RCCL_ASYNC"); n->rccl_inline = !(e && std::atoi(e) != 0); }
   if (n->rccl_inline) comm_big = nullptr;
   // asynchronous sums in flight between two waits: one per block (backward sync-BN) + one per two blocks (gradient buckets) + 4
   n->comm_ring = std::max(64, 2 * (int)n->layers.size() + 8);
@@ -916,7 +929,10 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
   // host-callback collectives (the host's communicator is ordered against ITS stream, not this one), not while launches are timed
   // (per-kernel figures want kernels alone on the chip), and not from 2^18 pixels (measured: nothing to gain at B >= 64).
   bool two = n->two_stream_mode > 0 || (n->two_stream_mode < 0 && M < (1 << 18));
-  if (n->allreduce || n->timing || n->rccl_inline || (n->rccl_small && !n->rccl_big)) two = false;     // (one communicator: one stream)
+  // (inline collectives all run on `st`: the filter-gradient stream never touches the communicator, so the two go together;
+  //  the asynchronous form with a single communicator would drive it from both streams)
+  if (n->allreduce || n->timing || (n->rccl_small && !n->rccl_inline && !n->rccl_big)) two = false;
+  const bool inline_comm = n->rccl_small && n->rccl_inline;
   if (two && !n->wg_stream) {
     bool ok = hipStreamCreateWithFlags(&n->wg_stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < 2; ++i)
@@ -934,7 +950,7 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
       DRS_TRY(drs_conv_wgrad(n->p<float>("act:" + in.name), B, S, in.P, in.C, 0, gzb[two ? (i & 1) : 0], L.halo, L.cout, 0, L.k, L.rate, L.pad_b, L.cin_k,
                              L.cin, L.cout, n->p<float>("slab"), grads + L.w_off, ws));
     }
-    if (collectives(n) && i > 0 && (nL - i) % 2 == 0) {      // every second layer: one bucket
+    if (collectives(n) && !inline_comm && i > 0 && (nL - i) % 2 == 0) {      // every second layer: one bucket
       int h;
       DRS_TRY(all_reduce(n, grads + L.w_off, bucket_hi - L.w_off, F32, 1, ws, &h, two));
       pending.push_back(h);
@@ -1005,7 +1021,11 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     if (hipStreamWaitEvent(st, n->ev_wg[0], 0) != hipSuccess) return DRS_ERR_HIP;
     if (nL > 1 && hipStreamWaitEvent(st, n->ev_wg[1], 0) != hipSuccess) return DRS_ERR_HIP;
   }
-  if (collectives(n)) {
+  if (inline_comm) {      // one all-reduce of the whole flat gradient buffer, then the loss and the confusion matrix, in program order
+    DRS_TRY(all_reduce(n, grads, n->n_params, F32, 0, st, nullptr));
+    DRS_TRY(all_reduce(n, scalars, 1, F64, 0, st, nullptr));
+    DRS_TRY(all_reduce(n, conf, (size_t)n->K * n->K, I32, 0, st, nullptr));
+  } else if (collectives(n)) {
     int h;
     DRS_TRY(all_reduce(n, grads, bucket_hi, F32, 1, st, &h, two));                         // the remaining (earliest) layers
     pending.push_back(h);

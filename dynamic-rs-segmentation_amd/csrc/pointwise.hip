@@ -319,9 +319,35 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// the second half of a batch norm whose sums arrive from an all-reduce (data parallelism): (mean, rstd) of a thread's four channels
+// from the global sums, bn_finish_kernel's arithmetic exactly; the chosen thread also leaves them in mean_rstd (the backward pass
+// reads them) and updates the moving averages -- the "finish" launch of the multi-rank forward pass folded into its consumer
+struct BnFinish { const double* sums; double count; float* moving_mean; float* moving_var; float one_minus_decay; int bessel; };
+__device__ __forceinline__ void bn_finish4(const BnFinish& f, int c0, bool writer, float* __restrict__ mean_rstd, float (&mu)[4], float (&rs)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + j;
+    const double m = f.sums[2 * c] / f.count;
+    double var = f.sums[2 * c + 1] / f.count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)m, vf = (float)var;
+    mu[j] = mf;
+    rs[j] = 1.0f / sqrtf(vf + BN_EPS);
+    if (writer) {
+      mean_rstd[2 * c] = mf;
+      mean_rstd[2 * c + 1] = rs[j];
+      if (f.moving_mean) {
+        const float vu = f.bessel && f.count > 1.0 ? (float)(var * (f.count / (f.count - 1.0))) : vf;
+        f.moving_mean[c] = f.moving_mean[c] - (f.moving_mean[c] - mf) * f.one_minus_decay;
+        f.moving_var[c] = f.moving_var[c] - (f.moving_var[c] - vu) * f.one_minus_decay;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_act_pool_fwd_slide_kernel(const float* __restrict__ z, int B, int S, int C,
-                                                                    const float* __restrict__ mean_rstd, float alpha, ActView out,
-                                                                    unsigned char* __restrict__ idx, int nstrips, int rps) {
+                                                                    float* __restrict__ mean_rstd, float alpha, ActView out,
+                                                                    unsigned char* __restrict__ idx, int nstrips, int rps, const BnFinish fin) {
   extern __shared__ __attribute__((aligned(16))) float xch[];                // [2][TX + 2][C]: the activations of a row
   const int CQ = C >> 2, TX = blockDim.x / CQ;                               // TX >= 2
   const int tx = threadIdx.x / CQ, cq = threadIdx.x - tx * CQ;
@@ -332,10 +358,15 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_slide_kernel(const float*
   const int y0 = strip * rps;
   int y1 = y0 + rps;
   y1 = y1 < S ? y1 : S;
-  const f32x4 mr0 = *reinterpret_cast<const f32x4*>(mean_rstd + cq * 8);
-  const f32x4 mr1 = *reinterpret_cast<const f32x4*>(mean_rstd + cq * 8 + 4);
-  const float mu[4] = {mr0[0], mr0[2], mr1[0], mr1[2]};
-  const float rs[4] = {mr0[1], mr0[3], mr1[1], mr1[3]};
+  float mu[4], rs[4];
+  if (fin.sums) {       // (kernel-uniform)
+    bn_finish4(fin, cq * 4, blockIdx.x == 0 && blockIdx.y == 0 && tx == 0, mean_rstd, mu, rs);
+  } else {
+    const f32x4 mr0 = *reinterpret_cast<const f32x4*>(mean_rstd + cq * 8);
+    const f32x4 mr1 = *reinterpret_cast<const f32x4*>(mean_rstd + cq * 8 + 4);
+    mu[0] = mr0[0]; mu[1] = mr0[2]; mu[2] = mr1[0]; mu[3] = mr1[2];
+    rs[0] = mr0[1]; rs[1] = mr0[3]; rs[2] = mr1[1]; rs[3] = mr1[3];
+  }
   const float NEG = -__builtin_inff();
   const bool vl = x > 0;
   const bool edge_l = tx == 0, edge = edge_l || tx == TX - 1;
@@ -1479,8 +1510,9 @@ int drs_bn_eval_coeffs(const float* moving_mean, const float* moving_var, int C,
 
 static int bn_act_pool_forward_impl(const float* z, int B, int S, int C, const float* mean_rstd, float alpha, int pool,
                                     float* out, int P_out, int ld_out, int coff_out, unsigned char* argmax,
-                                    unsigned short* terms, int nterms, void* stream) {
+                                    unsigned short* terms, int nterms, void* stream, const BnFinish* fin = nullptr) {
   if (!z || !mean_rstd || (!out && !terms) || C % 4) return DRS_ERR_ARG;
+  if (fin && !((pool & 1) && slide_ok(C) && !terms)) return DRS_ERR_ARG;     // the folded finish exists in the pooled sliding kernel only
   if (terms && ((nterms != 2 && nterms != 3) || (ld_out & 31) || (coff_out & 31))) return DRS_ERR_ARG;
   const int Sp = S + 2 * P_out;
   if ((long long)B * Sp > 65535) return DRS_ERR_ARG;
@@ -1494,8 +1526,9 @@ static int bn_act_pool_forward_impl(const float* z, int B, int S, int C, const f
     const SlideCfg c = slide_cfg(B, S, C);
     if (P_out > 0 && !halo_is_zero) DRS_LAUNCH(zero_halo_kernel, grid, dim3(256), 0, (hipStream_t)stream, v, B, C);
     const size_t shm = (size_t)2 * (c.TX + 2) * C * sizeof(float);
+    const BnFinish none = {nullptr, 1.0, nullptr, nullptr, 0.f, 0};
     DRS_LAUNCH(bn_act_pool_fwd_slide_kernel, dim3(c.ncol, B * c.nstrips), dim3(c.TX * (C / 4)), shm, (hipStream_t)stream, z, B, S, C,
-               mean_rstd, alpha, v, argmax, c.nstrips, c.rps);
+               const_cast<float*>(mean_rstd), alpha, v, argmax, c.nstrips, c.rps, fin ? *fin : none);
   } else if (pool)
     DRS_LAUNCH(bn_act_pool_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, z, B, S, C, mean_rstd, alpha, v, argmax);
   else
@@ -1507,6 +1540,17 @@ int drs_bn_act_pool_forward(const float* z, int B, int S, int C, const float* me
                             float* out, int P_out, int ld_out, int coff_out, unsigned char* argmax, void* stream) {
   if (!out) return DRS_ERR_ARG;
   return bn_act_pool_forward_impl(z, B, S, C, mean_rstd, alpha, pool, out, P_out, ld_out, coff_out, argmax, nullptr, 0, stream);
+}
+
+// drs_bn_finish + drs_bn_act_pool_forward in ONE launch (pooled blocks, C <= 512): the multi-rank form of the forward batch norm is
+// tile statistics -> fp64 sums -> all-reduce -> finish -> normalise; the finish (mean, rstd, moving averages) is worked out by the
+// normalising kernel itself from the all-reduced sums (same arithmetic: same bits), which also leaves (mean, rstd) in mean_rstd
+int drs_bn_finish_act_pool_forward(const double* sums, double count, float* mean_rstd, float* moving_mean, float* moving_var, double decay,
+                                   int bessel, const float* z, int B, int S, int C, float alpha, int pool, float* out, int P_out, int ld_out,
+                                   int coff_out, unsigned char* argmax, void* stream) {
+  if (!sums || !mean_rstd || !out || count < 1.0 || !(pool & 1) || !slide_ok(C)) return DRS_ERR_ARG;
+  const BnFinish fin = {sums, count, moving_mean, moving_var, (float)(1.0 - decay), bessel};
+  return bn_act_pool_forward_impl(z, B, S, C, mean_rstd, alpha, pool, out, P_out, ld_out, coff_out, argmax, nullptr, 0, stream, &fin);
 }
 
 int drs_bn_act_pool_forward_terms(const float* z, int B, int S, int C, const float* mean_rstd, float alpha, int pool,

@@ -125,7 +125,7 @@ class EngineNet(DilatedNet):
             if ok:
                 single = len(self._rccl) == 1
                 _lib.call("drs_net_set_rccl", self.h, self.comm.world, self.comm.rank, self._rccl[0], None if single else self._rccl[1], None)
-                self.collectives = "rccl (one communicator, compute stream only: DRS_RCCL_SINGLE_COMM)" if single else "rccl"
+                self.collectives = "rccl (inline: one communicator on the compute stream)" if single else "rccl (asynchronous: DRS_RCCL_ASYNC)"
                 return
             if os.environ.get("DRS_COMM") == "rccl":
                 raise err or _lib.DrsError("library-side RCCL collectives failed on another rank")
@@ -135,9 +135,9 @@ class EngineNet(DilatedNet):
 
     def _install_rccl(self):
         import os
-        # small (latency-bound sums) and big (gradient buckets) communicators; DRS_RCCL_SINGLE_COMM=1: one, driven from the compute
-        # stream alone (the library reads the same variable in drs_net_set_rccl)
-        ncomm = 1 if os.environ.get("DRS_RCCL_SINGLE_COMM", "0") not in ("", "0") else 2
+        # one communicator, driven from the compute stream alone (the library's default, inline form); DRS_RCCL_ASYNC=1: a small
+        # (latency-bound sums) and a big (gradient buckets) one for the asynchronous form (the library reads the same variable)
+        ncomm = 2 if os.environ.get("DRS_RCCL_ASYNC", "0") not in ("", "0") else 1
         ok, payload = True, []
         if self.comm.rank == 0:
             try:

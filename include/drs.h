@@ -130,6 +130,12 @@ int drs_bn_eval_coeffs(const float* moving_mean, const float* moving_var, int C,
  * position 0..8 of the first maximum, which the backward pass routes gradients to (TF MaxPoolGrad). */
 int drs_bn_act_pool_forward(const float* z, int B, int S, int C, const float* mean_rstd, float alpha, int pool,
                             float* out, int P_out, int ld_out, int coff_out, unsigned char* argmax, void* stream);
+/* drs_bn_finish + drs_bn_act_pool_forward in one launch (pooled blocks with C <= 512): under data parallelism the batch-norm sums
+ * come back from an all-reduce, and the kernel that normalises works (mean, rstd) out of them itself (drs_bn_finish's arithmetic, the
+ * same bits), leaves them in mean_rstd for the backward pass and updates the moving averages (isprs:655-663).  pool must have bit 0 set. */
+int drs_bn_finish_act_pool_forward(const double* sums, double count, float* mean_rstd, float* moving_mean, float* moving_var, double decay,
+                                   int bessel_moving_var, const float* z, int B, int S, int C, float alpha, int pool, float* out, int P_out,
+                                   int ld_out, int coff_out, unsigned char* argmax, void* stream);
 /* the same, also (out != NULL) or only (out == NULL) writing the split-bf16 terms of the output slab (layout above) */
 int drs_bn_act_pool_forward_terms(const float* z, int B, int S, int C, const float* mean_rstd, float alpha, int pool,
                                   float* out, int P_out, int ld_out, int coff_out, unsigned char* argmax,
@@ -315,8 +321,11 @@ int drs_net_set_comm(drs_net_t* net, int world, int rank, drs_allreduce_fn allre
  * drs_net_set_comm replaces library-side collectives by the callback.  One communicator is never driven from two streams that no
  * event orders: with the two-stream backward pass of small steps (fewer than 2^18 pixels per rank) comm_small stays on the compute
  * stream and every asynchronous sum goes to comm_big; with comm_big = NULL that pass is off.
- * DRS_RCCL_SINGLE_COMM=1 in the environment (read by drs_net_set_rccl): the conservative form -- comm_big is ignored and every sum
- * is issued on the compute stream itself in program order (no side streams, no events, no second communicator).
+ * Default form: INLINE -- comm_big is ignored and every sum is issued on the compute stream itself in program order (the sync-BN sums
+ * where they are needed, the whole gradient buffer as one all-reduce after the last filter gradient, the loss, the confusion matrix):
+ * no side stream, no event, one communicator on one stream.  DRS_RCCL_ASYNC=1 in the environment (read by drs_net_set_rccl) selects
+ * the asynchronous form described above (side streams, gradient buckets on comm_big as the layers finish); measured at world 1 its
+ * cross-stream hand-overs cost more than the overlap can return on 8 GPUs.
  * A host that binds this ABI directly must have HSA_ENABLE_IPC_MODE_LEGACY=0 in its environment BEFORE the HIP runtime starts
  * (the first HIP call of the process): on this driver RCCL's intra-node transport needs dmabuf IPC and ncclCommInitRank otherwise
  * fails with `hipIpcGetMemHandle: invalid argument` (the Python client and bench.py set it at import).

@@ -2,7 +2,7 @@
 
 `python bench.py --gpus N` without a launcher must start torch.distributed.run itself as a fresh child; under either launch shape
 every rank is a supervisor that starts the measuring process as a child, watches its progress markers and, on a hang or a crash,
-kills it and starts a FRESH child on the next collectives path (DRS_COMM=torch, then DRS_RCCL_SINGLE_COMM=1) -- the one 8-GPU run
+kills it and starts a FRESH child on the next collectives path (DRS_COMM=torch, then DRS_RCCL_ASYNC=1) -- the one 8-GPU run
 a round gets must not be lost to a hang in the dual-communicator RCCL path."""
 import json
 import os
@@ -15,7 +15,7 @@ BENCH = os.path.join(ROOT, "bench.py")
 
 def _run(cmd, tmp_path, **env):
     e = dict(os.environ)
-    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "DRS_BENCH_CHILD", "DRS_COMM", "DRS_RCCL_SINGLE_COMM"):
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "DRS_BENCH_CHILD", "DRS_COMM", "DRS_RCCL_ASYNC"):
         e.pop(k, None)
     e.update(DRS_BENCH_SELFTEST="1", **env)
     r = subprocess.run(cmd, cwd=str(tmp_path), env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
@@ -52,16 +52,16 @@ def test_a_hang_before_warm_up_falls_back_to_the_callback_path(tmp_path):
     assert err.count("killing the process group") == 2      # both ranks' supervisors killed their own child
 
 
-def test_crashes_walk_the_chain_to_the_single_communicator_form(tmp_path):
+def test_crashes_walk_the_chain_to_its_last_entry(tmp_path):
     rc, lines, err = _run([sys.executable, BENCH, "--gpus", "2"], tmp_path, DRS_BENCH_FAKE_CRASH="default,torch", DRS_BENCH_WATCHDOG_S="30")
     assert rc == 0, err
     d = json.loads(lines[-1])
     assert d["config"]["collectives"] == "selftest (fallback after failure)"
-    assert d["config"]["env"]["DRS_RCCL_SINGLE_COMM"] == "1" and d["config"]["env"]["DRS_COMM"] == "rccl"
+    assert d["config"]["env"]["DRS_RCCL_ASYNC"] == "1" and d["config"]["env"]["DRS_COMM"] == "rccl"
 
 
 def test_every_attempt_failing_is_reported_not_hung(tmp_path):
-    rc, lines, err = _run([sys.executable, BENCH, "--gpus", "2"], tmp_path, DRS_BENCH_FAKE_CRASH="default,torch,single", DRS_BENCH_WATCHDOG_S="30")
+    rc, lines, err = _run([sys.executable, BENCH, "--gpus", "2"], tmp_path, DRS_BENCH_FAKE_CRASH="default,torch,async", DRS_BENCH_WATCHDOG_S="30")
     assert rc != 0
     d = json.loads(lines[-1])
     assert d["value"] is None and "every attempt failed" in d["error"]

@@ -50,7 +50,11 @@ def lib(monkeypatch):
 def test_every_rank_fine_takes_the_library_path(lib):
     net, calls = make_net(FakeComm(8, 3))
     engine.EngineNet._install_comm(net)
-    assert calls == ["rccl"] and lib["set_rccl"] == 1 and net.collectives == "rccl"
+    assert calls == ["rccl"] and lib["set_rccl"] == 1 and net.collectives.startswith("rccl (asynchronous")      # two communicators were made
+    net, calls = make_net(FakeComm(8, 3))
+    net._rccl = ["one"]                                # the default: one communicator, the inline form
+    engine.EngineNet._install_comm(net)
+    assert net.collectives.startswith("rccl (inline")
     assert net.comm.asked == [True, True]          # two collective questions: bound everywhere?  working everywhere?
 
 
