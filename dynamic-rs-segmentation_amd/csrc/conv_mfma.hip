@@ -1117,8 +1117,20 @@ int g_conv_variant = -1;     // development switch (drs_debug_conv_variant): 0 =
 
 int g_conv_splitk = -1;      // development switch (drs_debug_conv_splitk): -1 = stream-K by the rule below, 0 = never, n >= 1: n workgroups
 
-constexpr int SK_MAX_W = 768;          // most workgroups of a stream-K launch: 3 per CU
 constexpr int SK_MAX_TILES = 4096;     // from here on the tiles fill the chip many times over (and the all-halo tap rows are skipped instead)
+
+// compute units of the device the process runs on (MI355X: 256), asked once; the stream-K geometry is "a whole number of
+// workgroups per CU", so it follows the part instead of a literal
+int cu_count() {
+  static const int n = [] {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess || p.multiProcessorCount < 1) return 256;
+    return p.multiProcessorCount;
+  }();
+  return n;
+}
+inline int sk_max_w() { return 3 * cu_count(); }      // most workgroups of a stream-K launch: 3 per CU
 
 // Stream-K launch geometry of the forward / input-gradient pass: 0 = one workgroup per tile.
 // A launch of few tiles leaves CUs idle (B = 16, S = 25: 79 M tiles for 256 CUs) and ends with its longest K loop; a launch of a
@@ -1129,8 +1141,9 @@ constexpr int SK_MAX_TILES = 4096;     // from here on the tiles fill the chip m
 int sk_workgroups(int tiles, int nks, int bn, size_t ws_floats) {
   if (g_conv_splitk == 0 || tiles >= SK_MAX_TILES || nks < 2) return 0;
   const long long U = (long long)tiles * nks;
+  const long long NCU = cu_count();
   long long cap = (long long)(ws_floats / (2ull * 128 * (size_t)bn));
-  if (cap > SK_MAX_W) cap = SK_MAX_W;
+  if (cap > sk_max_w()) cap = sk_max_w();
   if (cap < 1) return 0;
   long long W;
   if (g_conv_splitk > 0) {
@@ -1140,17 +1153,19 @@ int sk_workgroups(int tiles, int nks, int bn, size_t ws_floats) {
     // launch is the faster one (no slab, no fix-up, 4 instead of 3 workgroups per CU); measured at B = 16, S = 25 .. 85
     // (profiles/r03/ab_streamk_b16.log): plain 0.85-0.87 of the fp32 roof at a perfect fit and proportionally less otherwise,
     // stream-K 0.78-0.85 at every tile count
-    const long long per = (tiles + 255) / 256;
-    if ((double)tiles >= 0.93 * 256.0 * (double)per) return 0;
+    const long long per = (tiles + NCU - 1) / NCU;
+    if ((double)tiles >= 0.93 * (double)NCU * (double)per) return 0;
     const int MINU = 12;                                       // K-steps a workgroup should at least have (prologue + epilogue cost ~2)
     const int occ = 3;                                         // workgroups a CU holds of the stream-K form (136 / 168 VGPRs)
-    long long per_cu = U / (256LL * MINU);
+    long long per_cu = U / (NCU * MINU);
     per_cu = per_cu < 1 ? 1 : (per_cu > occ ? occ : per_cu);
-    W = 256 * per_cu;
-    if (U < 256LL * MINU) W = U / MINU > 0 ? U / MINU : 1;
+    W = NCU * per_cu;
+    if (U < NCU * MINU) W = U / MINU > 0 ? U / MINU : 1;
   }
-  if (W > cap) W = cap;
   if (W > U) W = U;
+  // the cut must follow from the SHAPE alone: a workspace too small for it gets the plain launch, not a smaller cut (the sums of a
+  // convolution would otherwise associate differently from one caller's workspace to another's)
+  if (W > cap) return g_conv_splitk > 0 ? (int)cap : 0;
   return (int)W;
 }
 
@@ -1443,7 +1458,7 @@ int drs_conv_mtile(int cout) { return pick_tile(cout) >= 64 ? 128 : 256; }
 
 size_t drs_conv_workspace_floats(int cout) {
   const int bn = pick_conv_tile(cout, 32);
-  return bn >= 64 ? 2ull * SK_MAX_W * 128 * (size_t)bn : 0;
+  return bn >= 64 ? 2ull * (size_t)sk_max_w() * 128 * (size_t)bn : 0;
 }
 
 int drs_conv_forward_ws(const float* in, int B, int S, int P, int ld_in, int coff_in, const float* w, const float* bias,

@@ -762,8 +762,9 @@ int drs_net_set_comm(drs_net_t* n, int world, int rank, drs_allreduce_fn allredu
 // Default form (r04): INLINE -- comm_big is ignored; every sum is issued on the compute stream itself, in program order: the 16 sync-BN
 // sums where they are needed, the whole gradient buffer as ONE all-reduce after the last filter gradient, then the loss and the
 // confusion matrix.  No side stream, no event, one communicator driven from one stream.  Measured at world 1 with every collective
-// forced on (B = 16, S = 64; profiles/r04/collectives_forms_world1.txt): no collectives 6.97 ms, inline 7.10, the asynchronous form
-// below 7.36 -- and 7.36 with the RCCL calls themselves skipped: what the asynchronous form costs is its own cross-stream event
+// forced on (B = 16, S = 64; profiles/r04/collectives_forms_world1.txt): no collectives 6.97 ms, inline 6.96 (the two-stream backward
+// pass stays on: its filter-gradient stream never touches the communicator), the asynchronous form below 7.35 -- and 7.36 with the RCCL
+// calls themselves skipped: what the asynchronous form costs is its own cross-stream event
 // hand-overs (~25 of them a step), which is about what overlapping 8 MB of gradient buckets and eight 2 KB sums could save on 8 GPUs.
 // DRS_RCCL_ASYNC=1 in the environment (read here) selects that form: backward sync-BN sums on a side stream under the filter
 // gradient of the block above, gradient buckets on comm_big's stream as the layers finish.
@@ -778,14 +779,16 @@ static int set_rccl_impl(drs_net_t* n, int world, int rank, void* comm_small, vo
   // asynchronous sums in flight between two waits: one per block (backward sync-BN) + one per two blocks (gradient buckets) + 4
   n->comm_ring = std::max(64, 2 * (int)n->layers.size() + 8);
   n->comm_in_flight = 0;
-  n->comm_events.resize(2 * (size_t)n->comm_ring);
-  for (auto& e : n->comm_events)
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return DRS_ERR_HIP;
-  if (hipStreamCreateWithFlags(&n->small_stream, hipStreamNonBlocking) != hipSuccess) return DRS_ERR_HIP;
-  if (comm_stream) { n->comm_stream = (hipStream_t)comm_stream; n->own_comm_stream = false; }
-  else {
-    if (hipStreamCreateWithFlags(&n->comm_stream, hipStreamNonBlocking) != hipSuccess) return DRS_ERR_HIP;
-    n->own_comm_stream = true;
+  if (!n->rccl_inline) {      // (the inline form needs no stream and no event of its own)
+    n->comm_events.resize(2 * (size_t)n->comm_ring);
+    for (auto& e : n->comm_events)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return DRS_ERR_HIP;
+    if (hipStreamCreateWithFlags(&n->small_stream, hipStreamNonBlocking) != hipSuccess) return DRS_ERR_HIP;
+    if (comm_stream) { n->comm_stream = (hipStream_t)comm_stream; n->own_comm_stream = false; }
+    else {
+      if (hipStreamCreateWithFlags(&n->comm_stream, hipStreamNonBlocking) != hipSuccess) return DRS_ERR_HIP;
+      n->own_comm_stream = true;
+    }
   }
   n->world = world; n->rank = rank; n->rccl_small = comm_small; n->rccl_big = comm_big; n->comm_next = 0;
   n->allreduce = nullptr; n->wait = nullptr; n->comm_user = nullptr;

@@ -45,8 +45,9 @@ extern "C" {
  * The input-gradient pass is this same call on the haloed output gradient with the filter from
  * drs_filter_flip_transpose and pad_before := pad_after. */
 int drs_conv_mtile(int cout);
-/* drs_conv_forward_ws: the same with a caller-owned workspace (>= drs_conv_workspace_floats(cout) floats to enable every
- * geometry, 16-byte aligned; NULL / unaligned / smaller: fewer or none).  With it, launches of fewer than 4096 tiles run "stream-K": the K-steps of all
+/* drs_conv_forward_ws: the same with a caller-owned workspace (>= drs_conv_workspace_floats(cout) floats, 16-byte aligned, enables
+ * every geometry; NULL, unaligned or too small for the cut the shape asks for: the plain launch of drs_conv_forward -- the cut, and with
+ * it the association of the sums, follows from the shape and the device's CU count alone, never from the workspace size).  With it, launches of fewer than 4096 tiles run "stream-K": the K-steps of all
  * tiles are cut into equal ranges, one per workgroup and a whole number of workgroups per CU, the tiles that a cut crosses are
  * completed from partial sums in the workspace in a fixed order (bitwise reproducible; sums associate differently from
  * drs_conv_forward's).  This is the path of the per-rank batches of data parallelism (16 patches of 25..85 pixels a side). */

@@ -305,6 +305,43 @@ def test_bn_act_pool_forward_backward(lib, C, pool, alpha, B, S, P):
     assert np.all(full == 0)
 
 
+@pytest.mark.parametrize("C,alpha,B,S,P", [(64, 0.1, 2, 9, 4), (256, 0.1, 3, 25, 8), (192, 0.0, 1, 12, 0), (448, 0.0, 1, 7, 3), (32, 0.1, 2, 5, 2)])
+def test_finish_folded_into_the_pooled_forward_kernel_gives_the_same_bits(lib, C, alpha, B, S, P):
+    """drs_bn_finish_act_pool_forward (the multi-rank forward batch norm: the sums come back from an all-reduce and the normalising
+    kernel works mean / rstd / moving averages out of them itself) against drs_bn_finish followed by drs_bn_act_pool_forward:
+    output slab, positions, (mean, rstd) and both moving averages bit for bit."""
+    rng = np.random.default_rng(C * 7 + S)
+    M = B * S * S
+    z = (rng.normal(size=(M, C)) * 2.0 - 0.4).astype(np.float32)
+    zd = dev(z)
+    z64 = z.astype(np.float64)
+    sums = dev(np.stack([z64.sum(axis=0), (z64 ** 2).sum(axis=0)], axis=1).reshape(-1), torch.float64)
+    count = float(3 * M)                                   # as if three ranks had contributed
+    res = []
+    for fused in (False, True):
+        mr = torch.zeros(C * 2, dtype=torch.float32, device=DEV)
+        mm = dev(rng.normal(size=C).astype(np.float32) * 0 + 0.25)
+        mv = dev(np.full(C, 1.5, dtype=np.float32))
+        out = torch.full((B * (S + 2 * P) ** 2 * C,), 7.0, dtype=torch.float32, device=DEV)
+        idx = torch.zeros(M * C, dtype=torch.uint8, device=DEV)
+        if fused:
+            lib.call("drs_bn_finish_act_pool_forward", sums.data_ptr(), count, mr.data_ptr(), mm.data_ptr(), mv.data_ptr(), 0.999, 1, zd.data_ptr(),
+                     B, S, C, alpha, 1, out.data_ptr(), P, C, 0, idx.data_ptr(), stream())
+        else:
+            lib.call("drs_bn_finish", sums.data_ptr(), count, C, mr.data_ptr(), mm.data_ptr(), mv.data_ptr(), 0.999, 1, stream())
+            lib.call("drs_bn_act_pool_forward", zd.data_ptr(), B, S, C, mr.data_ptr(), alpha, 1, out.data_ptr(), P, C, 0, idx.data_ptr(), stream())
+        torch.cuda.synchronize()
+        res.append((out, idx, mr, mm, mv))
+    for a, b, what in zip(res[0], res[1], ("out", "positions", "mean_rstd", "moving_mean", "moving_variance")):
+        assert torch.equal(a, b), what
+    assert float(res[1][3][0]) != 0.25                      # the moving averages moved
+    # the folded form exists for pooled blocks only: anything else is rejected, not silently run unfused
+    mr = torch.zeros(C * 2, dtype=torch.float32, device=DEV)
+    out = torch.zeros(B * (S + 2 * P) ** 2 * C, dtype=torch.float32, device=DEV)
+    assert lib.load().drs_bn_finish_act_pool_forward(sums.data_ptr(), count, mr.data_ptr(), None, None, 0.999, 1, zd.data_ptr(), B, S, C, alpha, 0,
+                                                     out.data_ptr(), P, C, 0, None, stream()) == 1
+
+
 def test_bn_eval_coeffs(lib):
     rng = np.random.default_rng(0)
     C = 192
