@@ -40,7 +40,35 @@ struct ConvArgs {
   // by that workgroup, the others leave their partial sums in sk_slab and conv_sk_fixup_kernel adds them in a fixed order
   float* sk_slab;
   int sk_W, sk_nks, sk_U;
+  // launch order "long tiles first" (plain launches with halo-tap skipping, whole patches per XCD chunk): lpt_T = M tiles per patch
+  // (0 = natural order), tiles [lpt_ta, lpt_tb) of a patch multiply every tap row, the others skip some; lpt_P = patches per XCD chunk
+  int lpt_T, lpt_ta, lpt_tb, lpt_P;
+#ifdef DRS_DEV
+  unsigned long long* trace;      // development build: [workgroup][2] = (start, end) of the workgroup on the 100 MHz real-time clock, or null
+#endif
 };
+
+// Launch order "full tiles first" of a plain launch: logical workgroup index (after the XCD remap: every XCD owns one contiguous
+// chunk of `P` whole patches) -> tile.  Inside a chunk first the tiles [ta, tb) of every patch (they multiply every tap row), patch
+// by patch in natural order, then the tiles that skip halo tap rows (the top / bottom ones of every patch).  A bijection on
+// [0, chunks * P * T * ntn) that keeps the ntn column tiles of an M tile adjacent.
+__host__ __device__ __forceinline__ int lpt_tile(int wg, int T, int ta, int tb, int P, int ntn) {
+  const int per = P * T * ntn, nI = tb - ta, nE = T - nI;
+  const int chunk = wg / per;
+  int wl = wg - chunk * per, p, t;
+  if (wl < P * nI * ntn) {
+    p = wl / (nI * ntn);
+    wl -= p * nI * ntn;
+    t = ta + wl / ntn;
+  } else {
+    wl -= P * nI * ntn;
+    p = wl / (nE * ntn);
+    wl -= p * nE * ntn;
+    const int e = wl / ntn;
+    t = e < ta ? e : tb + (e - ta);
+  }
+  return ((chunk * P + p) * T + t) * ntn + wl % ntn;
+}
 
 // first K-step (of the tile-major sequence) of workgroup w, and the workgroup that owns K-step x: the static cut both the
 // convolution kernel and the fix-up kernel work out for themselves
@@ -264,6 +292,9 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
   const int wm = wave / WN, wn = wave % WN;
   const int ntn = a.Cout / BN;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
+#ifdef DRS_DEV
+  if (a.trace && t == 0) a.trace[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
   const int Sp = a.S + 2 * a.P;
   const int cpt = a.Cin / BK;
   const char* inb = reinterpret_cast<const char*>(a.in);
@@ -280,9 +311,13 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
     u_end = __builtin_amdgcn_readfirstlane(sk_first_unit(wg + 1, a.sk_U, a.sk_W));
     if (u >= u_end) return;
   }
+  // the workgroups of a launch start in index order and the launch ends with its last round draining: let that round be the SHORT
+  // tiles (r04, tools/conv_tail.py: the drain of conv8's forward launch 419 -> 216 us, idle workgroup slots 6.4 -> 3.5 % of the launch;
+  // in-process A/B over the 14 forward / input-gradient launches at B = 128: -1.2 .. -5.5 % each, 29.7 -> 28.8 ms)
+  const int tile0 = (!SK && a.lpt_T) ? __builtin_amdgcn_readfirstlane(lpt_tile(wg, a.lpt_T, a.lpt_ta, a.lpt_tb, a.lpt_P, ntn)) : wg;
   bool first_seg = true;
   for (;;) {
-    int tile = wg, kb = 0, ke = 0;
+    int tile = tile0, kb = 0, ke = 0;
     if (SK) {
       tile = u / a.sk_nks;
       kb = u - tile * a.sk_nks;
@@ -431,6 +466,9 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
     first_seg = false;
     __syncthreads();                                // the epilogue's LDS scratch is free before the next segment's DMA lands
   }
+#ifdef DRS_DEV
+  if (a.trace && t == 0) a.trace[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 #endif
 }
 
@@ -1115,6 +1153,10 @@ __global__ void pad_cin_kernel(const float* __restrict__ w, float* __restrict__ 
 
 int g_conv_variant = -1;     // development switch (drs_debug_conv_variant): 0 = register-staged tiles, 1 = LDS-DMA double-buffered halves, -1 = per tile
 
+#ifdef DRS_DEV
+unsigned long long* g_conv_trace = nullptr;      // development build (drs_debug_conv_trace): per-workgroup (start, end) stamps of the next launches
+#endif
+int g_conv_lpt = 1;          // development switch (drs_debug_conv_lpt): 1 = plain launches start their full tiles first, the halo-skipping ones last
 int g_conv_splitk = -1;      // development switch (drs_debug_conv_splitk): -1 = stream-K by the rule below, 0 = never, n >= 1: n workgroups
 
 constexpr int SK_MAX_TILES = 4096;     // from here on the tiles fill the chip many times over (and the all-halo tap rows are skipped instead)
@@ -1169,12 +1211,37 @@ int sk_workgroups(int tiles, int nks, int bn, size_t ws_floats) {
   return (int)W;
 }
 
+// parameters of the "full tiles first" launch order (lpt_tile): only for plain launches that skip halo tap rows, whose M tiles are
+// whole image rows of whole patches (S * S and the tile height multiples of each other's parts: S = 32, 64, 128 ...) and whose XCD
+// chunks are whole patches; everything else keeps the natural order
+void conv_lpt_setup(ConvArgs& a, int BM, int mt, int nt, int W) {
+  a.lpt_T = 0; a.lpt_ta = a.lpt_tb = a.lpt_P = 0;
+  if (W || !a.skip_halo || !g_conv_lpt) return;
+  const int S2 = a.S * a.S, T = S2 % BM == 0 ? S2 / BM : 0, nblk = mt * nt;
+  if (T < 2 || BM % a.S != 0 || nblk % 8 != 0 || (nblk / 8) % (T * nt) != 0) return;
+  const int rows = BM / a.S;                                   // image rows per tile
+  auto full = [&](int t) {                                     // live_tap_rows' rule for the tile of rows [t rows, (t + 1) rows)
+    const int y0 = t * rows, y1 = y0 + rows - 1;
+    const int lo = a.pad - y1 > 0 ? (a.pad - y1 + a.rate - 1) / a.rate : 0;
+    int hi = (a.S - 1 - y0 + a.pad) / a.rate + 1;
+    hi = hi < a.k ? hi : a.k;
+    return lo == 0 && hi == a.k;
+  };
+  int ta = 0, tb = T;
+  while (ta < T && !full(ta)) ++ta;
+  while (tb > ta && !full(tb - 1)) --tb;
+  bool ok = ta < tb;
+  for (int t = ta; ok && t < tb; ++t) ok = full(t);
+  if (ok && (ta > 0 || tb < T)) { a.lpt_T = T; a.lpt_ta = ta; a.lpt_tb = tb; a.lpt_P = nblk / 8 / (T * nt); }
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_conv_dma(ConvArgs& a, float* ws, size_t ws_floats, hipStream_t st) {
   const int mt = (a.M + BM - 1) / BM, nt = a.Cout / BN;
   const int nks = a.k * a.k * (a.Cin / BK);
   const int W = ws && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 ? sk_workgroups(mt * nt, nks, BN, ws_floats) : 0;   // (16-byte piece accesses)
   a.sk_W = W; a.sk_nks = nks; a.sk_U = mt * nt * nks; a.sk_slab = ws;
+  conv_lpt_setup(a, BM, mt, nt, W);
   if (W) DRS_LAUNCH((conv_dma_kernel<BM, BN, WM, WN, true>), dim3(W), dim3(256), 0, st, a);
   else DRS_LAUNCH((conv_dma_kernel<BM, BN, WM, WN, false>), dim3(mt * nt), dim3(256), 0, st, a);
   int rc = DRS_LAUNCH_CHECK();
@@ -1447,6 +1514,25 @@ int drs_debug_conv_wide192(int v) { const int old = g_conv_wide192; if (v >= 0) 
 
 int drs_debug_conv_variant(int v) { const int old = g_conv_variant; if (v >= -1) g_conv_variant = v; return old; }
 
+int drs_debug_conv_lpt(int v) { const int old = g_conv_lpt; if (v >= 0) g_conv_lpt = v; return old; }
+/* the tile every logical workgroup index (after the XCD remap) of a plain forward launch of this shape would take: out[w] = tile;
+   returns the number of workgroups, 0 when the launch keeps the natural order, negative on a rejected shape */
+int drs_debug_conv_order(int B, int S, int k, int rate, int pad_before, int cin, int cout, int* out, int cap) {
+  const long long M = (long long)B * S * S;
+  if (M <= 0 || M >= (1 << 24) || cout % 32 || k < 1 || rate < 1) return -1;
+  ConvArgs a;
+  a.S = S; a.M = (int)M; a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout;
+  a.skip_halo = drs_skip_halo_taps_fwd(M, cout);
+  const int bn = pick_conv_tile(cout, cin);
+  if (bn < 64) return 0;
+  const int mt = (int)((M + 127) / 128), nt = cout / bn;
+  conv_lpt_setup(a, 128, mt, nt, 0);
+  if (!a.lpt_T) return 0;
+  for (int w = 0; w < mt * nt && w < cap; ++w) out[w] = lpt_tile(w, a.lpt_T, a.lpt_ta, a.lpt_tb, a.lpt_P, nt);
+  return mt * nt;
+}
+int drs_debug_conv_trace(void* dev_buffer) { g_conv_trace = (unsigned long long*)dev_buffer; return 0; }
+
 int drs_debug_conv_splitk(int v) { const int old = g_conv_splitk; if (v >= -1) g_conv_splitk = v; return old; }
 
 int drs_debug_wgrad_variant(int v) { const int old = g_wgrad_variant; if (v >= -1) g_wgrad_variant = v; return old; }
@@ -1479,6 +1565,9 @@ int drs_conv_forward_ws(const float* in, int B, int S, int P, int ld_in, int cof
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
   a.skip_halo = drs_skip_halo_taps_fwd(M, cout);
   a.sk_slab = nullptr; a.sk_W = 0; a.sk_nks = 0; a.sk_U = 0;
+#ifdef DRS_DEV
+  a.trace = g_conv_trace;
+#endif
   hipStream_t st = (hipStream_t)stream;
   if (!workspace) workspace_floats = 0;
   switch (pick_conv_tile(cout, cin)) {

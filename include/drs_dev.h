@@ -16,6 +16,9 @@ extern "C" {
 int drs_debug_skip_taps(int v);          /* 0 multiply the all-halo taps / chunks too, 1 skip them where it pays (default), 2 always; < 0 reads */
 int drs_debug_conv_variant(int v);       /* forward / input gradient: 0 register-staged tiles, 1 LDS-DMA halves, -1 per tile (default) */
 int drs_debug_conv_wide192(int v);       /* Cout = 192 as one 128 x 192 tile (1, default) or three 128 x 64 tiles (0) */
+int drs_debug_conv_lpt(int v);           /* plain forward / input-gradient launches: 1 start the full tiles first and the halo-skipping ones last (default), 0 natural order */
+int drs_debug_conv_order(int B, int S, int k, int rate, int pad_before, int cin, int cout, int* out, int cap);   /* out[w] = tile of logical workgroup w of that plain launch; returns the workgroup count, 0 = natural order */
+int drs_debug_conv_trace(void* dev_buffer); /* forward / input gradient (LDS-DMA form): device buffer [workgroups][2] of u64 that receives every workgroup's (start, end) on the 100 MHz real-time clock; NULL = off */
 int drs_debug_conv_splitk(int v);        /* split-K of the forward / input-gradient pass: -1 by the cost model (default), 0 never, n >= 1 that many ranges */
 int drs_debug_wgrad_variant(int v);      /* filter gradient: 0 register-staged, 1 LDS-DMA halves, -1 per tile (default) */
 int drs_debug_wgrad_balance(int v);      /* 1 cut the pixel dimension by live pixels (default), 0 equal chunk ranges */

@@ -188,3 +188,36 @@ def test_full_size_training_step_is_reproducible_and_learns():
         assert int(out["conf"].sum().item()) == M
     assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])      # bitwise, no float atomics anywhere
     assert runs[0][0][2] < runs[0][0][0]
+
+
+@pytest.mark.parametrize("k,rate,cin,cout", [(3, 8, 256, 256), (4, 3, 64, 128), (5, 2, 64, 64), (3, 6, 192, 192)])
+def test_full_tiles_first_launch_order_changes_no_bit(k, rate, cin, cout):
+    """The plain forward / input-gradient launches of the headline size start their full tiles first and the halo-skipping tiles of
+    every patch last (conv_mfma.hip lpt_tile): a launch ORDER only -- outputs and the per-tile batch-norm statistics must be the bits
+    of the natural order, and both must be the bits of the launch that multiplies every tap (whose skipped products are exact zeros)."""
+    from drs_amd import _lib
+    from drs_amd.nets import same_pad
+    d = _lib.dev()
+    g0 = torch.Generator(device=DEV).manual_seed(k * 10 + rate)
+    pb, pa = same_pad(k, rate)
+    P = max(pb, pa)
+    xp = _padded(torch.randn(B, S, S, cin, device=DEV, generator=g0), P)
+    w = torch.randn(k * k * cin * cout, device=DEV, generator=g0) * 0.05
+    bias = torch.randn(cout, device=DEV, generator=g0)
+    mt = d.query("drs_conv_mtile", cout)
+    assert d.drs_debug_conv_order(B, S, k, rate, pb, cin, cout, None, 0) > 0          # this shape does take the new order
+    res = []
+    for skip, lpt in ((1, 1), (1, 0), (0, 0)):
+        d.drs_debug_skip_taps(2 * skip)
+        d.drs_debug_conv_lpt(lpt)
+        z = torch.full((M * cout,), 3.0, device=DEV)
+        stats = torch.zeros((M // mt) * cout * 2, device=DEV)
+        d.call("drs_conv_forward", xp.data_ptr(), B, S, P, cin, 0, w.data_ptr(), bias.data_ptr(), k, rate, pb, cin, cout, z.data_ptr(), cout, 0, 0,
+               stats.data_ptr(), stream())
+        torch.cuda.synchronize()
+        res.append((z, stats))
+    d.drs_debug_skip_taps(1)
+    d.drs_debug_conv_lpt(1)
+    for z, st in res[1:]:
+        assert torch.equal(z, res[0][0]) and torch.equal(st, res[0][1])
+    assert float(res[0][0].abs().max()) > 1.0 and torch.isfinite(res[0][0]).all()

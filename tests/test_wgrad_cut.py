@@ -149,3 +149,56 @@ def test_slab_sized_at_the_largest_step_serves_every_smaller_one():
                         n = lib.drs_debug_wgrad_cut(b, s, L.k, L.rate, L.pad_b, L.cin_k, L.cout, None, 0, nt.ctypes.data, None)
                         assert n > 0 and int(nt.max()) <= alloc, (net_type, L.name, b, s, int(nt.max()), alloc, b_max, s_max)
                         nt[:] = 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# launch order of the plain forward / input-gradient launches: "full tiles first, the tiles that skip halo tap rows last"
+# (conv_mfma.hip lpt_tile / conv_lpt_setup, read back through the development library on the host)
+def _conv_order(B, S, k, rate, pad, cin, cout):
+    import ctypes as C
+    from drs_amd import _lib
+    d = _lib.dev()
+    n = d.drs_debug_conv_order(B, S, k, rate, pad, cin, cout, None, 0)
+    if n <= 0:
+        return n, None
+    out = (C.c_int * n)()
+    assert d.drs_debug_conv_order(B, S, k, rate, pad, cin, cout, out, n) == n
+    return n, list(out)
+
+
+@pytest.mark.parametrize("B,S,k,rate,cin,cout", [(128, 64, 3, 8, 256, 256), (128, 64, 3, 5, 128, 192), (128, 64, 5, 2, 64, 64), (128, 64, 4, 3, 64, 128),
+                                                 (64, 64, 3, 6, 256, 256), (512, 32, 3, 4, 128, 256), (32, 128, 3, 8, 256, 256)])
+def test_full_tiles_first_order_is_a_bijection_that_ends_with_the_short_tiles(B, S, k, rate, cin, cout):
+    pad = (k - 1) * rate // 2
+    n, order = _conv_order(B, S, k, rate, pad, cin, cout)
+    M = B * S * S
+    bn = 192 if cout % 192 == 0 and cout % 128 else (128 if cout % 128 == 0 else 64)
+    nt = cout // bn
+    assert n == (M // 128) * nt and sorted(order) == list(range(n))                 # every tile exactly once
+    for w in range(0, n, nt):                                                       # the column tiles of an M tile stay adjacent
+        assert [t % nt for t in order[w:w + nt]] == list(range(nt)) and len({t // nt for t in order[w:w + nt]}) == 1
+    T, rows = S * S // 128, 128 // S
+
+    def full(t):                                                                    # drs_common.hpp live_tap_rows for rows [t rows, (t+1) rows)
+        y0, y1 = t * rows, t * rows + rows - 1
+        lo = -(-(pad - y1) // rate) if pad - y1 > 0 else 0
+        hi = min((S - 1 - y0 + pad) // rate + 1, k)
+        return lo == 0 and hi == k
+    chunk = n // 8
+    for c in range(8):                                                              # per XCD chunk: whole patches, full tiles first
+        part = order[c * chunk:(c + 1) * chunk]
+        patches = sorted({t // nt // T for t in part})
+        assert len(patches) * T * nt == chunk and patches == list(range(patches[0], patches[0] + len(patches)))
+        kinds = [full((t // nt) % T) for t in part]
+        first_short = kinds.index(False)
+        assert all(kinds[:first_short]) and not any(kinds[first_short:]) and 0 < first_short < chunk
+        m_full = [t // nt for t in part[:first_short:nt]]
+        assert m_full == sorted(m_full)                                             # the full tiles keep their natural (patch-major) order
+
+
+@pytest.mark.parametrize("B,S,k,rate,cin,cout", [(16, 64, 3, 8, 256, 256),       # fewer than 4096 tiles: no halo-tap skipping, natural order
+                                                 (128, 65, 3, 8, 256, 256),      # tiles do not hold whole image rows
+                                                 (128, 64, 1, 1, 256, 256)])     # nothing to skip: every tile is full
+def test_full_tiles_first_order_is_off_where_it_does_not_apply(B, S, k, rate, cin, cout):
+    n, order = _conv_order(B, S, k, rate, (k - 1) * rate // 2, cin, cout)
+    assert n == 0 and order is None
