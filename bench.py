@@ -330,18 +330,25 @@ def cpu_baseline(batch=GLOBAL_BATCH, warmup=2, timed=5):
                        "step of %d patches, %.2f s" % (timed, warmup, batch, med, min(times), max(times), b1, one))
 
 
+def _lib_query(name, *args):
+    from drs_amd import _lib
+    return _lib.query(name, *args)
+
+
 def executed_fraction(plan, B, S):
     """Share of the algorithmic multiply-adds of the forward / input-gradient launches that the kernels really issue: filter-tap
-    rows that meet only the zero halo for a whole M tile are skipped (drs_common.hpp live_tap_rows; taken from 4096 workgroups).
-    Mirrors that rule on the host: M tiles of 128 pixels, whole tap rows, a tile that crosses an image boundary keeps every row."""
+    rows that meet only the zero halo for a whole M tile are skipped (drs_common.hpp live_tap_rows) in the launches the library says
+    (drs_conv_halo_skip: plain launches of >= 4096 tiles, or any plain launch that takes the full-tiles-first order).  Which rows a
+    tile skips is mirrored here: M tiles of 128 pixels, whole tap rows, a tile that crosses an image boundary keeps every row."""
     M = B * S * S
     tot = live = 0.0
     for i, L in enumerate(plan.layers):
-        for pad, cout, on in ((L.pad_b, L.cout, True), (L.pad_a, L.cin, i > 0)):          # forward; input gradient (none for conv1), N = Cin
+        # forward (N = Cout, contraction over Cin); input gradient (none for conv1; N = Cin, contraction over Cout)
+        for pad, cout, gemm_k, on in ((L.pad_b, L.cout, L.cin_k, True), (L.pad_a, L.cin, L.cout, i > 0)):
             if not on:
                 continue
             work = float(L.k * L.k * L.cin * L.cout)
-            skip = L.cin_k >= 32 and ((M + 127) // 128) * ((cout + 127) // 128) >= 4096
+            skip = bool(_lib_query("drs_conv_halo_skip", B, S, L.k, L.rate, pad, gemm_k, cout))      # the library's own rule (conv_mfma.hip)
             frac = 1.0
             if skip:
                 rows = 0

@@ -15,6 +15,7 @@ SIGNATURES = {
     "drs_conv_mtile": (_i, [_i]),
     "drs_conv_forward": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p]),
     "drs_conv_workspace_floats": (_sz, [_i]),
+    "drs_conv_halo_skip": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "drs_conv_forward_ws": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p, _sz, _p]),
     "drs_conv_wgrad_splits": (_i, [_i, _i, _i, _i, _i]),
     "drs_conv_wgrad": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),

@@ -570,6 +570,9 @@ struct WgradArgs {
   int ablate;                // timing experiments only (libdrs_hip_dev.so): 1 = every tap reads the un-shifted pixels (wrong sums)
   float rcpS, rcpSS;
   WgradPlan plan;
+#ifdef DRS_DEV
+  unsigned long long* trace;      // development build: [workgroup][2] = (start, end) on the 100 MHz real-time clock, or null
+#endif
 };
 
 // workgroup id -> (tile, split), the split's chunk range [cbeg, cend) and the tile's live pixel range
@@ -705,6 +708,12 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   const int wr = wave / WC, wc = wave % WC;
 
   int tile, split, cbeg, cend, live_lo, live_hi;
+#ifdef DRS_DEV
+  if (a.trace && t == 0) {
+    a.trace[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    a.trace[32768 + blockIdx.x] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);   // HW_ID, XCC_ID
+  }
+#endif
   wgrad_assign(a, TR, xcd_remap(blockIdx.x, gridDim.x), tile, split, cbeg, cend, live_lo, live_hi);
   const int R0 = (tile / a.nto) * TR;         // first row of the [k*k*Cin] dimension; a tile may span several taps
   const int o0 = (tile % a.nto) * TO;         // and the last one may be ragged (rows beyond k*k*Cin are not stored)
@@ -858,6 +867,9 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
         const int col = wc * WTO + ni * 32 + li;
         if (R0 + row < rows_all) dst[(size_t)row * a.Cout + col] = acc[mi][ni][r];
       }
+#ifdef DRS_DEV
+  if (a.trace && t == 0) a.trace[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // The same tile with its operands brought in by LDS-DMA (global_load_lds_dwordx4: global memory -> LDS without passing through
@@ -891,6 +903,12 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   const int wr = wave / WC, wc = wave % WC;
 
   int tile, split, cbeg, cend, live_lo, live_hi;
+#ifdef DRS_DEV
+  if (a.trace && t == 0) {
+    a.trace[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    a.trace[32768 + blockIdx.x] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);   // HW_ID, XCC_ID
+  }
+#endif
   wgrad_assign(a, TR, xcd_remap(blockIdx.x, gridDim.x), tile, split, cbeg, cend, live_lo, live_hi);
   const int R0 = (tile / a.nto) * TR;
   const int o0 = (tile % a.nto) * TO;
@@ -1072,6 +1090,9 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
         const int col = wc * WTO + ni * 32 + li;
         if (R0 + row < rows_all) dst[(size_t)row * a.Cout + col] = acc[mi][ni][r];
       }
+#ifdef DRS_DEV
+  if (a.trace && t == 0) a.trace[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 #endif
 }
 
@@ -1211,12 +1232,15 @@ int sk_workgroups(int tiles, int nks, int bn, size_t ws_floats) {
   return (int)W;
 }
 
-// parameters of the "full tiles first" launch order (lpt_tile): only for plain launches that skip halo tap rows, whose M tiles are
-// whole image rows of whole patches (S * S and the tile height multiples of each other's parts: S = 32, 64, 128 ...) and whose XCD
-// chunks are whole patches; everything else keeps the natural order
+// parameters of the "full tiles first" launch order (lpt_tile): only for plain launches whose M tiles are whole image rows of whole
+// patches (S * S and the tile height multiples of each other's parts: S = 32, 64, 128 ...) and whose XCD chunks are whole patches;
+// everything else keeps the natural order.  Where the order applies the all-halo tap rows are skipped at ANY tile count: with the
+// natural order skipping only paid from 4096 workgroups (+3 % time at 2048, +12 % at 1024: drs_common.hpp); with the full tiles
+// spread over the CUs first and the short ones after them it pays everywhere it was tried (in-process A/B against multiplying every
+// tap, forward + input gradient of the 7 layers: B = 64 -5.3 %, B = 32 -3.4 %, B = 16 -2 % (conv8 -8 %), B = 8 +-0).
 void conv_lpt_setup(ConvArgs& a, int BM, int mt, int nt, int W) {
   a.lpt_T = 0; a.lpt_ta = a.lpt_tb = a.lpt_P = 0;
-  if (W || !a.skip_halo || !g_conv_lpt) return;
+  if (W || !g_conv_lpt || drs_g_skip_halo_taps == 0) return;
   const int S2 = a.S * a.S, T = S2 % BM == 0 ? S2 / BM : 0, nblk = mt * nt;
   if (T < 2 || BM % a.S != 0 || nblk % 8 != 0 || (nblk / 8) % (T * nt) != 0) return;
   const int rows = BM / a.S;                                   // image rows per tile
@@ -1232,7 +1256,7 @@ void conv_lpt_setup(ConvArgs& a, int BM, int mt, int nt, int W) {
   while (tb > ta && !full(tb - 1)) --tb;
   bool ok = ta < tb;
   for (int t = ta; ok && t < tb; ++t) ok = full(t);
-  if (ok && (ta > 0 || tb < T)) { a.lpt_T = T; a.lpt_ta = ta; a.lpt_tb = tb; a.lpt_P = nblk / 8 / (T * nt); }
+  if (ok && (ta > 0 || tb < T)) { a.lpt_T = T; a.lpt_ta = ta; a.lpt_tb = tb; a.lpt_P = nblk / 8 / (T * nt); a.skip_halo = 1; }
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -1472,6 +1496,9 @@ int wgrad_setup(int B, int S, int k, int rate, int pad_before, int cin, int cout
   a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
   a.ablate = g_wgrad_ablate;
+#ifdef DRS_DEV
+  a.trace = g_conv_trace;
+#endif
   // the cut: by live pixels (every workgroup of the launch the same length, the dead chunks skipped at any size), or equal chunk
   // ranges where that does not apply; development switches: drs_debug_wgrad_balance(0) = the equal cut with the dead chunks
   // skipped from 2^19 pixels only, drs_debug_skip_taps(0) = same cut, the dead chunks multiplied (same sums: bitwise)
@@ -1514,6 +1541,7 @@ int drs_debug_conv_wide192(int v) { const int old = g_conv_wide192; if (v >= 0) 
 
 int drs_debug_conv_variant(int v) { const int old = g_conv_variant; if (v >= -1) g_conv_variant = v; return old; }
 
+size_t drs_conv_workspace_floats(int cout);
 int drs_debug_conv_lpt(int v) { const int old = g_conv_lpt; if (v >= 0) g_conv_lpt = v; return old; }
 /* the tile every logical workgroup index (after the XCD remap) of a plain forward launch of this shape would take: out[w] = tile;
    returns the number of workgroups, 0 when the launch keeps the natural order, negative on a rejected shape */
@@ -1526,7 +1554,8 @@ int drs_debug_conv_order(int B, int S, int k, int rate, int pad_before, int cin,
   const int bn = pick_conv_tile(cout, cin);
   if (bn < 64) return 0;
   const int mt = (int)((M + 127) / 128), nt = cout / bn;
-  conv_lpt_setup(a, 128, mt, nt, 0);
+  const int W = cin >= 32 ? sk_workgroups(mt * nt, k * k * (cin / 32), bn, drs_conv_workspace_floats(cout)) : 0;      // (a caller with the full workspace)
+  conv_lpt_setup(a, 128, mt, nt, W);
   if (!a.lpt_T) return 0;
   for (int w = 0; w < mt * nt && w < cap; ++w) out[w] = lpt_tile(w, a.lpt_T, a.lpt_ta, a.lpt_tb, a.lpt_P, nt);
   return mt * nt;
@@ -1546,6 +1575,24 @@ size_t drs_conv_workspace_floats(int cout) {
   const int bn = pick_conv_tile(cout, 32);
   return bn >= 64 ? 2ull * (size_t)sk_max_w() * 128 * (size_t)bn : 0;
 }
+
+// does the forward launch of this shape (a caller with the full workspace) leave out the filter-tap rows that meet only the zero halo?
+// (bench.py prices the executed share of the algorithmic flops with it; the rule lives here and nowhere else)
+int drs_conv_halo_skip(int B, int S, int k, int rate, int pad_before, int cin, int cout) {
+  const long long M = (long long)B * S * S;
+  if (M <= 0 || M >= (1 << 24) || cout % 32 || cin < 32 || cin % 32 || k < 1 || rate < 1) return 0;
+  ConvArgs a;
+  a.S = S; a.M = (int)M; a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout;
+  a.skip_halo = drs_skip_halo_taps_fwd(M, cout);
+  const int bn = pick_conv_tile(cout, cin);
+  if (bn < 64) return a.skip_halo;
+  const int mt = (int)((M + 127) / 128), nt = cout / bn;
+  const int W = sk_workgroups(mt * nt, k * k * (cin / 32), bn, drs_conv_workspace_floats(cout));
+  if (W) return 0;                                        // stream-K: every tile has the same number of K-steps
+  conv_lpt_setup(a, 128, mt, nt, 0);
+  return a.skip_halo;
+}
+
 
 int drs_conv_forward_ws(const float* in, int B, int S, int P, int ld_in, int coff_in, const float* w, const float* bias,
                         int k, int rate, int pad_before, int cin, int cout, float* out, int ld_out, int coff_out,

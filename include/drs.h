@@ -52,6 +52,10 @@ int drs_conv_mtile(int cout);
  * completed from partial sums in the workspace in a fixed order (bitwise reproducible; sums associate differently from
  * drs_conv_forward's).  This is the path of the per-rank batches of data parallelism (16 patches of 25..85 pixels a side). */
 size_t drs_conv_workspace_floats(int cout);
+/* 1 if drs_conv_forward_ws (full workspace) leaves out, for this shape, the filter-tap rows that meet only the zero halo for a whole
+ * tile of 128 pixels (exact zeros: results do not change): plain launches of >= 4096 tiles, and any plain launch whose tiles are whole
+ * image rows of whole patches (S = 32, 64, 128: those start their full tiles first, the skipping ones last); never a stream-K launch */
+int drs_conv_halo_skip(int B, int S, int k, int rate, int pad_before, int cin, int cout);
 int drs_conv_forward_ws(const float* in, int B, int S, int P, int ld_in, int coff_in, const float* w, const float* bias,
                         int k, int rate, int pad_before, int cin, int cout, float* out, int ld_out, int coff_out,
                         int accumulate, float* stats_partial, float* workspace, size_t workspace_floats, void* stream);

@@ -167,7 +167,8 @@ def _conv_order(B, S, k, rate, pad, cin, cout):
 
 
 @pytest.mark.parametrize("B,S,k,rate,cin,cout", [(128, 64, 3, 8, 256, 256), (128, 64, 3, 5, 128, 192), (128, 64, 5, 2, 64, 64), (128, 64, 4, 3, 64, 128),
-                                                 (64, 64, 3, 6, 256, 256), (512, 32, 3, 4, 128, 256), (32, 128, 3, 8, 256, 256)])
+                                                 (64, 64, 3, 6, 256, 256), (512, 32, 3, 4, 128, 256), (32, 128, 3, 8, 256, 256),
+                                                 (16, 64, 3, 8, 256, 256), (32, 64, 3, 5, 128, 192)])      # one- and two-round launches too
 def test_full_tiles_first_order_is_a_bijection_that_ends_with_the_short_tiles(B, S, k, rate, cin, cout):
     pad = (k - 1) * rate // 2
     n, order = _conv_order(B, S, k, rate, pad, cin, cout)
@@ -196,7 +197,7 @@ def test_full_tiles_first_order_is_a_bijection_that_ends_with_the_short_tiles(B,
         assert m_full == sorted(m_full)                                             # the full tiles keep their natural (patch-major) order
 
 
-@pytest.mark.parametrize("B,S,k,rate,cin,cout", [(16, 64, 3, 8, 256, 256),       # fewer than 4096 tiles: no halo-tap skipping, natural order
+@pytest.mark.parametrize("B,S,k,rate,cin,cout", [(18, 64, 3, 8, 256, 256),       # 1152 tiles for 1024 places: a stream-K launch (equal K ranges, nothing skipped)
                                                  (128, 65, 3, 8, 256, 256),      # tiles do not hold whole image rows
                                                  (128, 64, 1, 1, 256, 256)])     # nothing to skip: every tile is full
 def test_full_tiles_first_order_is_off_where_it_does_not_apply(B, S, k, rate, cin, cout):

@@ -10,7 +10,7 @@ from drs_amd.nets import Plan
 DEV = "cuda:0"
 
 
-def main(B=128, S=64, rounds=6):
+def main(B=128, S=64, rounds=6, force_skip=0):
     L_ = _lib.load()
     plan = Plan("dilated_grsl_rate8", 5, 6)
     st = torch.cuda.current_stream(DEV).cuda_stream
@@ -33,10 +33,12 @@ def main(B=128, S=64, rounds=6):
                                           L.cin_k, z.data_ptr(), L.cin_k, 0, 0, None, st)}
         row = "%-6s" % L.name
         for d, f in fns.items():
-            best = {0: 1e9, 1: 1e9}
+            best = {0: 1e9, 1: 1e9, 2: 1e9}
             for r in range(rounds):
-                for v in (0, 1):
-                    L_.drs_debug_conv_lpt(v)
+                for v in ((0, 1, 2) if force_skip else (0, 1)):
+                    L_.drs_debug_conv_lpt(1 if v == 1 else 0)
+                    if force_skip:
+                        L_.drs_debug_skip_taps(0 if v == 2 else 2)      # arm 2: every tap multiplied (what small launches do today)
                     for rep in range(3):
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record(); f(); e1.record()
@@ -44,12 +46,15 @@ def main(B=128, S=64, rounds=6):
                         if rep:
                             best[v] = min(best[v], e0.elapsed_time(e1))
             row += "  %s natural %.3f ms | full-first %.3f ms (%+.1f %%)" % (d, best[0], best[1], 100 * (best[1] / best[0] - 1))
+            if force_skip:
+                row += " | no skipping %.3f ms" % best[2]
             tot[(d, 0)] += best[0]; tot[(d, 1)] += best[1]
         print(row, flush=True)
     L_.drs_debug_conv_lpt(1)
+    L_.drs_debug_skip_taps(1)
     print("total  fwd %.3f -> %.3f ms   dgrad %.3f -> %.3f ms" % (tot[("fwd", 0)], tot[("fwd", 1)], tot[("dgrad", 0)], tot[("dgrad", 1)]))
 
 
 if __name__ == "__main__":
     kw = dict(a.split("=") for a in sys.argv[1:])
-    main(int(kw.get("B", 128)), int(kw.get("S", 64)), int(kw.get("rounds", 6)))
+    main(int(kw.get("B", 128)), int(kw.get("S", 64)), int(kw.get("rounds", 6)), int(kw.get("force_skip", 0)))

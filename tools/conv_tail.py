@@ -11,7 +11,7 @@ from drs_amd.nets import Plan
 DEV = "cuda:0"
 
 
-def main(B=128, S=64, layers="3,8", skip=1, lpt=1):
+def main(B=128, S=64, layers="3,8", skip=1, lpt=1, which="fwd"):
     L_ = _lib.load()
     L_.drs_debug_skip_taps(skip)
     L_.drs_debug_conv_lpt(lpt)
@@ -32,6 +32,13 @@ def main(B=128, S=64, layers="3,8", skip=1, lpt=1):
         trace = torch.zeros(nwg * 2, dtype=torch.int64, device=DEV)
         f = lambda: _lib.call("drs_conv_forward", x.data_ptr(), B, S, P, L.cin_k, 0, w.data_ptr(), bias.data_ptr(), L.k, L.rate, L.pad_b, L.cin_k,
                               L.cout, z.data_ptr(), L.cout, 0, 0, stats.data_ptr(), st)
+        if which == "wgrad":
+            g = torch.randn(B * (S + 2 * P) ** 2 * L.cout, device=DEV)
+            ns = _lib.query("drs_conv_wgrad_splits", B, S, L.k, L.cin_k, L.cout)
+            slab = torch.zeros(ns * L.k * L.k * L.cin_k * L.cout, device=DEV)
+            gw = torch.zeros(L.k * L.k * L.cin_k * L.cout, device=DEV)
+            f = lambda: _lib.call("drs_conv_wgrad", x.data_ptr(), B, S, P, L.cin_k, 0, g.data_ptr(), P, L.cout, 0, L.k, L.rate, L.pad_b, L.cin_k,
+                                  L.cin_k, L.cout, slab.data_ptr(), gw.data_ptr(), st)
         for _ in range(3):
             f()
         torch.cuda.synchronize()
@@ -66,4 +73,4 @@ def main(B=128, S=64, layers="3,8", skip=1, lpt=1):
 
 if __name__ == "__main__":
     kw = dict(a.split("=") for a in sys.argv[1:])
-    main(int(kw.get("B", 128)), int(kw.get("S", 64)), kw.get("layers", "3,8"), int(kw.get("skip", 1)), int(kw.get("lpt", 1)))
+    main(int(kw.get("B", 128)), int(kw.get("S", 64)), kw.get("layers", "3,8"), int(kw.get("skip", 1)), int(kw.get("lpt", 1)), kw.get("which", "fwd"))
