@@ -48,6 +48,25 @@ struct ConvArgs {
 #endif
 };
 
+// Wave priority by REMAINING work (r04).  The SIMD arbiter serves its oldest ready wave first, so the workgroups that share a CU do
+// not advance together: stamps of every workgroup's start and end (tools/wgrad_spread.py) show the equal-length workgroups of a
+// filter-gradient launch ending over +-13 % of their duration, all of it INSIDE a CU (CU means agree to 1 %), and the last
+// workgroup of a CU running alone at the end of a launch.  A wave that is further along lowers its own priority (3 in its first
+// quarter ... 0 in its last), the ones behind get the matrix pipe first and catch up, and the co-resident workgroups of the last
+// round end together (spread 13 -> 5 %).  In-process A/B over the filter gradients of conv3..conv8 at B = 128: 15.21 -> 15.03 ms
+// (conv1 / conv2 on the 64-wide register-staged form: -3.6 / -2.4 %); the reverse order (the one ahead keeps the pipe) 15.31,
+// classes crowded towards the end 15.17, two levels 15.17.  Only from 2^18 pixels (wgrad_setup).  NOT in the forward / input-gradient kernel: its many short workgroups
+// gain 0.3-0.7 % on the 128-wide tiles and LOSE 4-7 % on the 192-wide ones (three workgroups per CU).
+__device__ __forceinline__ void set_prio_by_progress(int done, int total, int& quarter) {
+  const int q = __builtin_amdgcn_readfirstlane((done * 4) / total);
+  if (q == quarter) return;
+  quarter = q;
+  if (q <= 0) __builtin_amdgcn_s_setprio(3);
+  else if (q == 1) __builtin_amdgcn_s_setprio(2);
+  else if (q == 2) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+}
+
 // Launch order "full tiles first" of a plain launch: logical workgroup index (after the XCD remap: every XCD owns one contiguous
 // chunk of `P` whole patches) -> tile.  Inside a chunk first the tiles [ta, tb) of every patch (they multiply every tap row), patch
 // by patch in natural order, then the tiles that skip halo tap rows (the top / bottom ones of every patch).  A bijection on
@@ -567,6 +586,7 @@ struct WgradArgs {
   int ntr, nto;
   int skip_halo;             // the walk jumps over the dead chunks (0: it multiplies their zeros -- same sums, bitwise)
   int live_cut;              // the live ranges shape the cut (plan) whether or not the walk skips
+  int prio;                  // waves lower their priority as they advance (set_prio_by_progress)
   int ablate;                // timing experiments only (libdrs_hip_dev.so): 1 = every tap reads the un-shifted pixels (wrong sums)
   float rcpS, rcpSS;
   WgradPlan plan;
@@ -821,7 +841,9 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
     lstore(cA);
     __syncthreads();
     const int xr = wr * WTR + li, gc = wc * WTO + li;
+    int quart = -1;
     for (int it = 0; cA < cend; ++it) {
+      if (a.prio) set_prio_by_progress(cA - cbeg, cend - cbeg, quart);
       if (cB < cend) gload((it + 1) & 1);         // table slot filled one iteration ago
       stepped = w.advance();                      // ... and on C, whose table goes into the slot last read one iteration ago
       fill_tables(it & 1, stepped);
@@ -1060,7 +1082,9 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA has landed; the barrier then publishes everybody's
     __syncthreads();
     zero_tail(cA, 0, 0);
+    int quart = -1;
     for (int it = 0; cA < cend; ++it) {
+      if (a.prio) set_prio_by_progress(cA - cbeg, cend - cbeg, quart);
       issue(xbA, gbA, it & 1, 1, 1);             // second half of A -> stage 1, lands while stage 0 is multiplied
       compute(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1496,6 +1520,10 @@ int wgrad_setup(int B, int S, int k, int rate, int pad_before, int cin, int cout
   a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
   a.ablate = g_wgrad_ablate;
+  // priority by remaining work: only where the filter gradient has the chip to itself.  Below 2^18 pixels the step engine runs it on a
+  // stream of its own BESIDE the batch-norm-backward -> input-gradient chain (engine.hip), and raised priorities there take the matrix
+  // pipe from the chain that the step waits for (B = 16: 6.87 -> 6.94 ms with them on)
+  a.prio = (g_wgrad_ablate != 3 && M >= (1LL << 18)) ? 1 : 0;
 #ifdef DRS_DEV
   a.trace = g_conv_trace;
 #endif
