@@ -1366,7 +1366,11 @@ int pick_wgrad_rows(int rows) {
 int pick_wgrad_cols(int tr, int cout) { return (tr == 128 && cout % 192 == 0 && cout % 128 != 0 && g_wgrad_variant != 0) ? 192 : pick_tile(cout); }
 
 int g_wgrad_balance = 1;     // development switch (drs_debug_wgrad_balance): 0 = equal chunk ranges (and the old rule for skipping), 1 = cut by live pixels
-int g_wgrad_len = 96;       // development switch (drs_debug_wgrad_len): chunks per workgroup small launches aim at
+int g_wgrad_len = 0;        // development switch (drs_debug_wgrad_len): chunks per workgroup the launches below the `big` class aim at (0 = by the pixel count, below)
+// r03 tuned 96 at the per-rank batches; with the waves' priority by remaining work (from 2^18 pixels) the workgroups of a launch end
+// together and longer ones pay: in-process A/B over conv2..conv8, B = 128: 96 -> 15.89 ms, 128 -> 15.78, 160 -> 15.79, 192 -> 15.80,
+// 256 -> 16.08; B = 64: 8.09 / 8.08 / 8.19 (96 / 128 / 192); B = 16: 2.21 / 2.31 / 2.40
+inline int wgrad_len(int nchunks) { return g_wgrad_len ? g_wgrad_len : (nchunks >= (1 << 14) ? 128 : 96); }
 int g_wgrad_minchunks = 8;  // development switch (drs_debug_wgrad_minchunks): fewest 32-pixel chunks a split may have
 int g_wgrad_target_big = 0;  // development switch: workgroups aimed at on launches with many tiles and pixels under the live cut (0 = default)
 
@@ -1380,7 +1384,7 @@ int wgrad_target(long long work, int ntile, int nchunks, bool balanced, int occ)
   // >= 96 chunks each, down to one round of 512 (sweeps at B = 16 / 32 in profiles/r02/wgrad_ablation.txt).  Launches with many
   // tiles and pixels: with equal chunk ranges and the dead chunks skipped the workgroups differ in length by up to a quarter and
   // two rounds quantise the gain away, so twice as many (measured at B = 128: conv6 3.48 -> 3.01 ms, conv8 5.19 -> 4.85).
-  long long fit = work / g_wgrad_len;
+  long long fit = work / wgrad_len(nchunks);
   fit = fit < 512 ? 512 : (fit > g_wgrad_target ? g_wgrad_target : fit);
   const bool big = ntile >= 24 && nchunks >= 8192;
   if (!balanced) return big ? 2 * g_wgrad_target : (int)fit;
@@ -1401,7 +1405,7 @@ int wgrad_target(long long work, int ntile, int nchunks, bool balanced, int occ)
       const double t = (W0 + i * o) / eff[i];
       if (t < bt) { bt = t; n = i; }
     }
-    int r = (int)(W0 / n / (double)g_wgrad_len + 0.5);
+    int r = (int)(W0 / n / (double)wgrad_len(nchunks) + 0.5);
     r = r < 1 ? 1 : r;
     const long long t = 256LL * n * r;
     return (int)(t > 4096 ? 4096 : t);
@@ -1555,7 +1559,7 @@ int drs_debug_wgrad_target(int v) { const int old = g_wgrad_target; if (v > 0) g
 
 int drs_debug_wgrad_balance(int v) { const int old = g_wgrad_balance; if (v >= 0) g_wgrad_balance = v; return old; }
 
-int drs_debug_wgrad_len(int v) { const int old = g_wgrad_len; if (v > 0) g_wgrad_len = v; return old; }
+int drs_debug_wgrad_len(int v) { const int old = g_wgrad_len; if (v >= 0) g_wgrad_len = v; return old; }
 
 int drs_debug_wgrad_minchunks(int v) { const int old = g_wgrad_minchunks; if (v > 0) g_wgrad_minchunks = v; return old; }
 

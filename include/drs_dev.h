@@ -24,7 +24,7 @@ int drs_debug_wgrad_variant(int v);      /* filter gradient: 0 register-staged, 
 int drs_debug_wgrad_balance(int v);      /* 1 cut the pixel dimension by live pixels (default), 0 equal chunk ranges */
 int drs_debug_wgrad_target(int v);       /* workgroups the pixel split aims at (default 2048) */
 int drs_debug_wgrad_target_big(int v);   /* the same on launches with many tiles and pixels (0 = default rule) */
-int drs_debug_wgrad_len(int v);          /* chunks per workgroup small launches aim at (default 96) */
+int drs_debug_wgrad_len(int v);          /* chunks per workgroup the launches below the `big` class aim at (0 = default: 96, from 2^19 pixels 128) */
 int drs_debug_wgrad_minchunks(int v);    /* fewest 32-pixel chunks a split of the pixel dimension may have (default 8) */
 int drs_debug_wgrad_ablate(int v);       /* 1 = timing experiment (WRONG sums): every filter tap reads the un-shifted pixels (perfect X re-use); 3 = no wave priority by remaining work (same sums) */
 int drs_debug_wgrad_model(int v);        /* 1 per-CU cost model for the workgroup count of launches below the `big` class (default), 0 the r02 table */

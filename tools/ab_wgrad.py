@@ -21,7 +21,7 @@ def apply(lib, arm):
     lib.drs_debug_wgrad_target(kv.get("t", 2048))
     lib.drs_debug_wgrad_target_big(kv.get("g", 0))
     lib.drs_debug_wgrad_variant(kv.get("v", -1))
-    lib.drs_debug_wgrad_len(kv.get("l", 96))
+    lib.drs_debug_wgrad_len(kv.get("l", 0))
     lib.drs_debug_wgrad_minchunks(kv.get("m", 8))
     lib.drs_debug_wgrad_model(kv.get("o", 1))
     lib.drs_debug_wgrad_ablate(kv.get("a", 0))

@@ -50,6 +50,12 @@ def main(B=16, S=64, steps=20, arith="f32", comm_kind="none"):
 
 if __name__ == "__main__":
     kw = dict(a.split("=") for a in sys.argv[1:])
+    if "slide" in kw or "minrows" in kw:        # A/B of the sliding elementwise kernels' launch geometry inside the step: the whole net on the dev library
+        from drs_amd import _lib
+        d = _lib.dev()
+        _lib._lib = d.lib
+        if "slide" in kw: d.drs_debug_slide_blocks(int(kw["slide"]))
+        if "minrows" in kw: d.drs_debug_slide_minrows(int(kw["minrows"]))
     main(int(kw.get("B", 16)), int(kw.get("S", 64)), int(kw.get("steps", 20)), kw.get("arith", "f32"), kw.get("comm", "none"))
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
