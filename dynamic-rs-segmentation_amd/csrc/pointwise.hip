@@ -272,7 +272,9 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ ga, int ld_ga, in
 // running sums of the rows above / at / below the window row that arrives).
 // block = TX columns x (C/4) channel quads; grid.x = column blocks, grid.y = (image, row strip).
 struct SlideCfg { int TX, ncol, nstrips, rps; };
-static int g_slide_blocks = 2048, g_slide_minrows = 8;     // (development switches: drs_debug_slide_*)
+// (development switches: drs_debug_slide_*.  Workgroup target 2048 -> 5120 in r04: in-step sweep at B = 128 over 1280 .. 7680 --
+//  the forward kernel does not care (1.19-1.21 ms for the 8 layers), the backward one 1.85 -> 1.75 ms: profiles/r04/slide_blocks_sweep.txt)
+static int g_slide_blocks = 5120, g_slide_minrows = 8;
 static bool slide_ok(int C) { return C / 4 <= 128; }        // two columns or more per workgroup (the neighbours go through LDS)
 static SlideCfg slide_cfg(int B, int S, int C) {
   SlideCfg c;

@@ -28,7 +28,7 @@ int drs_debug_wgrad_len(int v);          /* chunks per workgroup the launches be
 int drs_debug_wgrad_minchunks(int v);    /* fewest 32-pixel chunks a split of the pixel dimension may have (default 8) */
 int drs_debug_wgrad_ablate(int v);       /* 1 = timing experiment (WRONG sums): every filter tap reads the un-shifted pixels (perfect X re-use); 3 = no wave priority by remaining work (same sums) */
 int drs_debug_wgrad_model(int v);        /* 1 per-CU cost model for the workgroup count of launches below the `big` class (default), 0 the r02 table */
-int drs_debug_slide_blocks(int v);       /* sliding elementwise kernels: workgroups the row-strip split aims at (default 2048) */
+int drs_debug_slide_blocks(int v);       /* sliding elementwise kernels: workgroups the row-strip split aims at (default 5120) */
 int drs_debug_slide_minrows(int v);      /* ... and the fewest rows of a strip in that first split (default 8) */
 int drs_debug_cls_variant(int v);        /* classifier block: 1 MFMA from 4 classes up, LDS-DMA form up to C = 256 (default), 2 register MFMA form always, 3 LDS-DMA form where it fits, 0 vector-ALU always */
 int drs_debug_variant(int v);            /* split-bf16 forward kernels: 0 register-staged, 1 LDS-DMA (default) */
