@@ -10,8 +10,7 @@ DRS_FORCE_COLLECTIVES=1 python bench.py --steps 40 --no-cpu-baseline --no-opt-in
 bash tools/profile_round.sh $1 > $O/profile_round.log 2>&1; echo "profile rc=$?"
 cd $R
 python tools/bench_configs.py > $O/configs_3_5.log 2>&1; echo "configs rc=$?"
-{ echo "== tools/ab_lpt.py (B = 128): natural order against full tiles first, halo skipping on in both"; python tools/ab_lpt.py 2>&1 | grep -v amdgpu;
-  for B in 64 32 16 8; do echo "== tools/ab_lpt.py B=$B force_skip=1: skipping with either order against multiplying every tap"; python tools/ab_lpt.py B=$B force_skip=1 rounds=4 2>&1 | grep -v amdgpu; done; } > $O/launch_order_ab.txt 2>&1
+{ for B in 128 64 32 16 8; do echo "== tools/ab_lpt.py B=$B (old: natural order, skipping from 4096 workgroups; new: full tiles first, skipping wherever the order applies; all: every tap multiplied)"; python tools/ab_lpt.py B=$B rounds=4 2>&1 | grep -v amdgpu; done; } > $O/launch_order_ab.txt 2>&1
 { echo "== tools/conv_tail.py lpt=0 (natural order)"; python tools/conv_tail.py layers=2,3,4,5,6,7,8 lpt=0 2>&1 | grep -v amdgpu; echo "== tools/conv_tail.py lpt=1 (full tiles first)"; python tools/conv_tail.py layers=2,3,4,5,6,7,8 lpt=1 2>&1 | grep -v amdgpu;
   echo "== tools/conv_tail.py which=wgrad"; python tools/conv_tail.py which=wgrad layers=2,3,4,5,6,7,8 2>&1 | grep -v amdgpu; } > $O/conv_tail.txt 2>&1
 { echo "== tools/ab_wgrad.py arms=a3,a0 (a3 = no wave priority by remaining work, a0 = default)"; python tools/ab_wgrad.py arms=a3,a0 rounds=5 2>&1 | grep -v amdgpu;
