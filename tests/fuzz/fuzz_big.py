@@ -44,13 +44,16 @@ def wgrad_identity(k, rate, cin, cout, B, S, seed):
     return abs(a - b) / scale, torch.isfinite(gw).all().item()
 
 
-def main(n=40, seed=0):
+def main(n=40, seed=0, sides=""):
+    """sides=32,64,96,128: draw the side from this list instead of 25..100 (the patch sides whose tiles are whole image rows take the
+    full-tiles-first launch order with halo-tap skipping at every batch: r04)"""
     rng = np.random.default_rng(seed)
     nbad = 0
+    side_list = [int(v) for v in sides.split(",")] if sides else None
     for i in range(n):
         k, rate, cin, cout = SHAPES[int(rng.integers(0, len(SHAPES)))]
-        B = int(rng.choice([16, 32, 64, 128]))
-        S = int(rng.integers(25, 101))
+        B = int(rng.choice([8, 16, 32, 64, 128])) if side_list else int(rng.choice([16, 32, 64, 128]))
+        S = int(rng.choice(side_list)) if side_list else int(rng.integers(25, 101))
         while B * S * S * (cin + cout) * 4 * 3 > 6e9:            # keep the operands of one case within a few GB
             B //= 2
         args = (k, rate, cin, cout, B, S)
@@ -73,4 +76,4 @@ def main(n=40, seed=0):
 
 if __name__ == "__main__":
     kw = dict(a.split("=") for a in sys.argv[1:])
-    main(int(kw.get("n", 40)), int(kw.get("seed", 0)))
+    main(int(kw.get("n", 40)), int(kw.get("seed", 0)), kw.get("sides", ""))
