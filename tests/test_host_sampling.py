@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol():
     # pure size queries are host code and callable without a GPU
     assert _lib.query("drs_conv_mtile", 256) == 128 and _lib.query("drs_conv_mtile", 64) == 128 and _lib.query("drs_conv_mtile", 32) == 256
     assert _lib.query("drs_bn_backward_rows", 2, 16, 64, 0) == 16 and _lib.query("drs_bn_backward_rows", 128, 64, 64, 0) == 2048
-    assert _lib.query("drs_bn_backward_rows", 128, 64, 256, 1) == 128 * 16      # 4 columns per workgroup, one strip
+    assert _lib.query("drs_bn_backward_rows", 128, 64, 256, 1) == 128 * 16 * 4  # 4 columns per workgroup, four strips of 16 rows (5120 workgroups aimed at)
     assert _lib.query("drs_conv_wgrad_splits", 64, 64, 3, 256, 256) >= 1
 
 
