@@ -3,6 +3,9 @@
   config 3: dilated_grsl_rate8 training, patch size drawn per step by `uniform` over [25, 85] (isprs:1727-1737), batch 128
   config 5: dilated_grsl_rate8 sliding-window inference of a 6000x6000x5 mosaic at 64x64 windows, stride 32 (isprs:1241-1284)
     python tools/bench_configs.py [arith=f32|bf16x3|bf16x6] [mosaic=6000] [steps=40]
+    python tools/bench_configs.py which=124      configs 1, 2 and 4 (parity-test cases of BASELINE.json, timed here for the record):
+  config 1: dilated_icpr_original (Dilated6) at 25x25x3, batch 16; config 2: dilated_grsl (Dilated6Pooling) at 64x64x5, batch 64;
+  config 4: dilated_icpr_rate6_densely (DenseDilated6), `multinomial` over {25, 50, 75, 100}, 4 bands, 2 classes, batch 128
 """
 import os
 import sys
@@ -69,6 +72,52 @@ def main(arith="f32", mosaic=6000, steps=40):
     assert tuple(pred.shape) == (mosaic, mosaic)
 
 
+def train_rate(net_type, ch, K, B, tile_side, draw, steps, label):
+    dev = "cuda:0"
+    tile, lab = make_tile(tile_side, tile_side, ch, K, seed=1234)
+    pool = P.TilePool([tile], [lab], dev, dtype=np.float64)
+    mean, std = tile[:, :, :3].mean(axis=(0, 1)).tolist(), tile[:, :, :3].std(axis=(0, 1)).tolist()
+    np.random.seed(11)
+    sizes = [draw() for _ in range(steps + 5)]
+    s_max = max(sizes)
+    net = DilatedNet(net_type, ch, K, 0.005, b_max=B, s_max=s_max, device=dev, seed=42)
+    inst = grid_instances(tile_side, tile_side, s_max, 25, max(B * 64, 2 * B), seed=0)
+
+    def step(i):
+        s = sizes[i]
+        o = (i * B) % max(1, len(inst) - B)
+        rows = inst[o:o + B]
+        aug = P.draw_augmentation(rows, s, ch, noise="device")
+        P.crop_to_net(net, pool, rows, s, mean, std, aug)
+        return net.train_step(B, s, 0.01)
+    for i in range(5):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(5, steps + 5):
+        step(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    px = sum(B * s * s for s in sizes[5:])
+    flops = 3 * 2 * net.plan.mac_per_pixel() * px
+    print("%s: %s, batch %d, %d steps (mean side %.1f): %.0f patches/s, %.1f Mpx/s trained, %.2f ms/step, %.1f TFLOP/s (%.2f of the fp32 roof)"
+          % (label, net_type, B, steps, np.mean(sizes[5:]), B * steps / dt, px / dt / 1e6, 1e3 * dt / steps, flops / dt / 1e12, flops / dt / 157.3e12),
+          flush=True)
+    del net, pool
+    torch.cuda.empty_cache()
+
+
+def main_124(steps):
+    train_rate("dilated_icpr_original", 3, 6, 16, 256, lambda: 25, steps * 5, "config 1")
+    train_rate("dilated_grsl", 5, 6, 64, 2048, lambda: 64, steps, "config 2")
+    values = [25, 50, 75, 100]
+    probs = P.define_multinomial_probs(values)
+    train_rate("dilated_icpr_rate6_densely", 4, 2, 128, 500, lambda: P.draw_patch_size("multinomial", values, probs)[0], steps, "config 4")
+
+
 if __name__ == "__main__":
     kw = dict(a.split("=") for a in sys.argv[1:])
+    if kw.get("which") == "124":
+        main_124(int(kw.get("steps", 40)))
+        sys.exit(0)
     main(kw.get("arith", "f32"), int(kw.get("mosaic", 6000)), int(kw.get("steps", 40)))
