@@ -142,10 +142,17 @@ def supervise(argv):
         reason = "%s attempt: %s" % (label, reason)
         sys.stderr.write("bench.py supervisor (rank %s): %s%s\n" % (os.environ.get("RANK", "?"), reason, "; falling back" if i + 1 < len(chain) else "; giving up"))
     if os.environ.get("RANK", "0") == "0":
-        sys.stdout.write(json.dumps({"metric": "training patches/sec dilated_grsl_rate8 64x64x5", "value": None, "unit": "patches/s",
-                                     "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "error": "every attempt failed; last: " + reason}) + "\n")
+        sys.stdout.write(failure_line("every attempt failed; last: " + reason))
         sys.stdout.flush()
+    else:
+        # the launcher tears every rank down as soon as ONE exits non-zero: let rank 0's line get out first
+        time.sleep(float(os.environ.get("DRS_BENCH_FAIL_LINGER_S", "5")))
     return 1
+
+
+def failure_line(error):
+    return json.dumps({"metric": "training patches/sec dilated_grsl_rate8 64x64x5", "value": None, "unit": "patches/s",
+                       "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "error": error}) + "\n"
 
 
 def plain_parent(args, argv):
@@ -161,7 +168,11 @@ def plain_parent(args, argv):
     lines = [ln for ln in out.splitlines() if ln.strip().startswith("{")]
     if lines:
         sys.stdout.write(lines[-1] + "\n")
-        sys.stdout.flush()
+    elif rc != 0:
+        # (the launcher can take rank 0 down before its failure line is out: there is still exactly one line, and it says what happened)
+        os.environ["WORLD_SIZE"] = str(args.gpus)
+        sys.stdout.write(failure_line("every attempt failed; the launcher exited with code %s before rank 0 reported" % rc))
+    sys.stdout.flush()
     return rc if rc is not None else 1
 
 

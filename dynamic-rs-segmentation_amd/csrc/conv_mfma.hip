@@ -770,33 +770,61 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   // S % 32 != 0: a chunk crosses image rows, so its 32 pixels get a table of byte offsets, written by the first 32 threads.
   // A thread follows ITS pixel (pb, py, px) through the walk: +32 pixels is a couple of compares; only a jump over dead rows
   // (once per image and tile) or a pixel past the end pays for the divisions.
-  int pb = 0, py = 0, px = 0;
+  // The thread carries the BYTE OFFSETS of its pixel in the two slabs along with (py, px): +32 pixels is three additions, a row
+  // wrap adds the slab's row jump, an image wrap its image jump -- compares, selects and additions only; the integer multiplies of
+  // the offset formula (quarter rate) are paid once per jump.  (r04: the fills cost 3.5-5 % of a launch at S % 32 != 0 -- one wave
+  // of four does them and the workgroup moves at its pace.)
+  int py = 0, px = 0;
+  uint32_t ox = 0, og = 0;
+  const uint32_t stepx = (uint32_t)(32 * a.ld_x) * 4u, stepg = (uint32_t)(32 * a.ld_g) * 4u;
+  const uint32_t rowjx = (uint32_t)((Sxp - a.S) * a.ld_x) * 4u, rowjg = (uint32_t)((Sgp - a.S) * a.ld_g) * 4u;
+  const uint32_t imgjx = (uint32_t)(Sxp * (Sxp - a.S) * a.ld_x) * 4u, imgjg = (uint32_t)(Sgp * (Sgp - a.S) * a.ld_g) * 4u;
   auto pixel_from_index = [&](int p) {
-    int rem;
+    int pb, rem;
     divmod24(p < a.M ? p : a.M - 1, w.S2, a.rcpSS, pb, rem);
     divmod24(rem, a.S, a.rcpS, py, px);
+    ox = (uint32_t)(((pb * Sxp + py + a.Px - a.pad) * Sxp + px + a.Px - a.pad) * a.ld_x) * 4u;
+    og = (uint32_t)(((pb * Sgp + py + a.Pg) * Sgp + px + a.Pg) * a.ld_g) * 4u;
   };
   if (!affine && t < BP) pixel_from_index(w.c * BP + t);
   auto fill_tables = [&](int slot, int stepped) {      // for chunk w.c; `stepped` = chunks the walk advanced since this thread's pixel was set
     if (affine || t >= BP || w.c >= cend) return;
     const int p = w.c * BP + t;
     if (stepped == 1 && p < a.M && a.S >= 11) {
-      px += 32;
+      px += 32; ox += stepx; og += stepg;
+      if (a.S >= 32) {                           // (uniform) at most one row wrap per 32 pixels
+        if (px >= a.S) { px -= a.S; ++py; ox += rowjx; og += rowjg; }
+      } else {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) if (px >= a.S) { px -= a.S; ++py; }
-      if (py >= a.S) { py -= a.S; ++pb; }
+        for (int k = 0; k < 3; ++k) if (px >= a.S) { px -= a.S; ++py; ox += rowjx; og += rowjg; }
+      }
+      if (py >= a.S) { py -= a.S; ox += imgjx; og += imgjg; }
     } else if (stepped != 0) {
       pixel_from_index(p);
     }
-    tabx[slot][t] = (uint32_t)(((pb * Sxp + py + a.Px - a.pad) * Sxp + px + a.Px - a.pad) * a.ld_x) * 4u;
-    tabg[slot][t] = (uint32_t)(((pb * Sgp + py + a.Pg) * Sgp + px + a.Pg) * a.ld_g) * 4u;
+    tabx[slot][t] = ox;
+    tabg[slot][t] = og;
   };
 
   const char* xbase = reinterpret_cast<const char*>(a.x);
   const char* gbase = reinterpret_cast<const char*>(a.g);
   f32x4 rx[NX], rg[NG];
   // global -> registers for the chunk the walk stands on (tables in `slot` when S % 32 != 0)
-  auto gload = [&](int slot) {
+  // (S % 32 != 0: the lane's byte offsets come out of the table a phase BEFORE the loads that use them -- fetch_offsets after the
+  // barrier that publishes the table, gload at the top of the next iteration -- so that no LDS round trip sits in front of the loads)
+  uint32_t nox[NX], nog[NG];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) nox[i] = 0u;
+#pragma unroll
+  for (int i = 0; i < NG; ++i) nog[i] = 0u;
+  auto fetch_offsets = [&](int slot) {
+    if (affine) return;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) nox[i] = tabx[slot][xpix + XPS * i] + xoff[i];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) nog[i] = tabg[slot][gpix + GPS * i] + goff[i];
+  };
+  auto gload = [&]() {
     if (affine) {
       const char* xb = xbase + (size_t)(uint32_t)(((w.b * Sxp + w.y + a.Px - a.pad) * Sxp + w.x0 + a.Px - a.pad) * a.ld_x) * 4u;
       const char* gb = gbase + (size_t)(uint32_t)(((w.b * Sgp + w.y + a.Pg) * Sgp + w.x0 + a.Pg) * a.ld_g) * 4u;
@@ -805,15 +833,10 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
 #pragma unroll
       for (int i = 0; i < NG; ++i) { uint32_t o = goff[i]; asm volatile("" : "+v"(o)); rg[i] = *reinterpret_cast<const f32x4*>(gb + o); }
     } else {
-      uint32_t ox[NX], og[NG];
 #pragma unroll
-      for (int i = 0; i < NX; ++i) ox[i] = tabx[slot][xpix + XPS * i] + xoff[i];
+      for (int i = 0; i < NX; ++i) rx[i] = *reinterpret_cast<const f32x4*>(xbase + nox[i]);
 #pragma unroll
-      for (int i = 0; i < NG; ++i) og[i] = tabg[slot][gpix + GPS * i] + goff[i];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) rx[i] = *reinterpret_cast<const f32x4*>(xbase + ox[i]);
-#pragma unroll
-      for (int i = 0; i < NG; ++i) rg[i] = *reinterpret_cast<const f32x4*>(gbase + og[i]);
+      for (int i = 0; i < NG; ++i) rg[i] = *reinterpret_cast<const f32x4*>(gbase + nog[i]);
     }
   };
   auto lstore = [&](int chunk) {
@@ -834,18 +857,23 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   if (cA < cend) {
     fill_tables(0, 0);
     __syncthreads();
-    gload(0);
+    fetch_offsets(0);
+    gload();
     int stepped = w.advance();                   // the walk now stands on B, the chunk to prefetch next
     int cB = w.c;
     fill_tables(1, stepped);
     lstore(cA);
     __syncthreads();
+    fetch_offsets(1);
     const int xr = wr * WTR + li, gc = wc * WTO + li;
     int quart = -1;
     for (int it = 0; cA < cend; ++it) {
       if (a.prio) set_prio_by_progress(cA - cbeg, cend - cbeg, quart);
-      if (cB < cend) gload((it + 1) & 1);         // table slot filled one iteration ago
-      stepped = w.advance();                      // ... and on C, whose table goes into the slot last read one iteration ago
+#ifdef DRS_DEV
+      if (a.ablate == 2) fetch_offsets((it + 1) & 1);      // A/B arm: the table reads right in front of the loads, as before r04
+#endif
+      if (cB < cend) gload();                     // B: its offsets were fetched after the last barrier
+      stepped = w.advance();                      // ... and on C, whose table goes into the slot read two barriers ago
       fill_tables(it & 1, stepped);
       {
         // fragments of pixel pair s+1 are read before the MFMAs of pair s are issued (two register sets used in turn)
@@ -872,6 +900,7 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
         }
       }
       __syncthreads();
+      fetch_offsets(it & 1);                      // C's table is published; the reads land under the stores below
       if (cB < cend) { lstore(cB); __syncthreads(); }
       cA = cB;
       cB = w.c;
@@ -936,7 +965,11 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   const int o0 = (tile % a.nto) * TO;
   const int rows_all = a.k * a.k * a.Cin;
   const int Sxp = a.S + 2 * a.Px, Sgp = a.S + 2 * a.Pg;
+#ifdef DRS_DEV
+  const bool affine = (a.S & 31) == 0 || a.ablate == 5;      // 5: timing experiment (WRONG sums): the S % 32 == 0 addressing at any S
+#else
   const bool affine = (a.S & 31) == 0;
+#endif
   // DMA lane roles: instruction i of this wave moves pieces 64 (wave + NW i) + lane of the linear image: piece f belongs to pixel
   // f / XQ, 16-byte column f % XQ.  (TR is a power of two, so the X column -- and with it the filter tap of the rows this lane
   // stages -- is the same for all of a lane's instructions; TO = 192 gives every instruction its own (pixel, column) pair.)
@@ -973,26 +1006,40 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   ChunkWalk w;
   w.init(cbeg, a.S, a.rcpS, a.rcpSS, live_lo, live_hi);
 
-  int pb = 0, py = 0, px = 0;
+  // The thread carries the BYTE OFFSETS of its pixel in the two slabs along with (py, px): +32 pixels is three additions, a row
+  // wrap adds the slab's row jump, an image wrap its image jump -- compares, selects and additions only; the integer multiplies of
+  // the offset formula (quarter rate) are paid once per jump.  (r04: the fills cost 3.5-5 % of a launch at S % 32 != 0 -- one wave
+  // of four does them and the workgroup moves at its pace.)
+  int py = 0, px = 0;
+  uint32_t ox = 0, og = 0;
+  const uint32_t stepx = (uint32_t)(32 * a.ld_x) * 4u, stepg = (uint32_t)(32 * a.ld_g) * 4u;
+  const uint32_t rowjx = (uint32_t)((Sxp - a.S) * a.ld_x) * 4u, rowjg = (uint32_t)((Sgp - a.S) * a.ld_g) * 4u;
+  const uint32_t imgjx = (uint32_t)(Sxp * (Sxp - a.S) * a.ld_x) * 4u, imgjg = (uint32_t)(Sgp * (Sgp - a.S) * a.ld_g) * 4u;
   auto pixel_from_index = [&](int p) {
-    int rem;
+    int pb, rem;
     divmod24(p < a.M ? p : a.M - 1, w.S2, a.rcpSS, pb, rem);
     divmod24(rem, a.S, a.rcpS, py, px);
+    ox = (uint32_t)(((pb * Sxp + py + a.Px - a.pad) * Sxp + px + a.Px - a.pad) * a.ld_x) * 4u;
+    og = (uint32_t)(((pb * Sgp + py + a.Pg) * Sgp + px + a.Pg) * a.ld_g) * 4u;
   };
   if (!affine && t < BP) pixel_from_index(w.c * BP + t);
   auto fill_tables = [&](int slot, int stepped) {
     if (affine || t >= BP || w.c >= cend) return;
     const int p = w.c * BP + t;
     if (stepped == 1 && p < a.M && a.S >= 11) {
-      px += 32;
+      px += 32; ox += stepx; og += stepg;
+      if (a.S >= 32) {                           // (uniform) at most one row wrap per 32 pixels
+        if (px >= a.S) { px -= a.S; ++py; ox += rowjx; og += rowjg; }
+      } else {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) if (px >= a.S) { px -= a.S; ++py; }
-      if (py >= a.S) { py -= a.S; ++pb; }
+        for (int k = 0; k < 3; ++k) if (px >= a.S) { px -= a.S; ++py; ox += rowjx; og += rowjg; }
+      }
+      if (py >= a.S) { py -= a.S; ox += imgjx; og += imgjg; }
     } else if (stepped != 0) {
       pixel_from_index(p);
     }
-    tabx[slot][t] = (uint32_t)(((pb * Sxp + py + a.Px - a.pad) * Sxp + px + a.Px - a.pad) * a.ld_x) * 4u;
-    tabg[slot][t] = (uint32_t)(((pb * Sgp + py + a.Pg) * Sgp + px + a.Pg) * a.ld_g) * 4u;
+    tabx[slot][t] = ox;
+    tabg[slot][t] = og;
   };
 
   const char* xbase = reinterpret_cast<const char*>(a.x);
@@ -1003,8 +1050,22 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
     xb = xbase + (size_t)(uint32_t)(((w.b * Sxp + w.y + a.Px - a.pad) * Sxp + w.x0 + a.Px - a.pad) * a.ld_x) * 4u;
     gb = gbase + (size_t)(uint32_t)(((w.b * Sgp + w.y + a.Pg) * Sgp + w.x0 + a.Pg) * a.ld_g) * 4u;
   };
-  // DMA of half `half` of a chunk (bases xb / gb, or table slot) into LDS stage `stage`
-  auto issue = [&](const char* xb, const char* gb, int slot, int half, int stage) {
+  // S % 32 != 0: a lane's byte offsets for the two halves of a chunk, table entry + lane constant, fetched into registers a phase
+  // BEFORE the DMA that uses them is issued (the table read used to sit in front of every issue: an LDS round trip on the critical
+  // path of each half, twice per chunk)
+  struct LaneOffsets { uint32_t x[2][IX], g[2][IG]; };
+  auto fetch_offsets = [&](int slot, LaneOffsets& o) {
+    if (affine) return;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int i = 0; i < IX; ++i) o.x[half][i] = tabx[slot][half * HP + xpix[i]] + xoff[i];
+#pragma unroll
+      for (int i = 0; i < IG; ++i) o.g[half][i] = tabg[slot][half * HP + gpix[i]] + goff[i];
+    }
+  };
+  // DMA of half `half` of a chunk (bases xb / gb, or the lane offsets `o`) into LDS stage `stage`
+  auto issue = [&](const char* xb, const char* gb, const LaneOffsets& o, int half, int stage) {
     float* sx = lds + stage * STAGE;
     float* sg = sx + XSTAGE;
     if (affine) {
@@ -1012,21 +1073,19 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
       const char* gh = gb + (size_t)(uint32_t)(half * HP * a.ld_g) * 4u;
 #pragma unroll
       for (int i = 0; i < IX; ++i) {
-        uint32_t o = xoff[i]; asm volatile("" : "+v"(o));
-        __builtin_amdgcn_global_load_lds(xh + o, (lds_ptr)(sx + (wave + NW * i) * 256), 16, 0, 0);
+        uint32_t v = xoff[i]; asm volatile("" : "+v"(v));
+        __builtin_amdgcn_global_load_lds(xh + v, (lds_ptr)(sx + (wave + NW * i) * 256), 16, 0, 0);
       }
 #pragma unroll
       for (int i = 0; i < IG; ++i) {
-        uint32_t o = goff[i]; asm volatile("" : "+v"(o));
-        __builtin_amdgcn_global_load_lds(gh + o, (lds_ptr)(sg + (wave + NW * i) * 256), 16, 0, 0);
+        uint32_t v = goff[i]; asm volatile("" : "+v"(v));
+        __builtin_amdgcn_global_load_lds(gh + v, (lds_ptr)(sg + (wave + NW * i) * 256), 16, 0, 0);
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < IX; ++i)
-        __builtin_amdgcn_global_load_lds(xbase + (tabx[slot][half * HP + xpix[i]] + xoff[i]), (lds_ptr)(sx + (wave + NW * i) * 256), 16, 0, 0);
+      for (int i = 0; i < IX; ++i) __builtin_amdgcn_global_load_lds(xbase + o.x[half][i], (lds_ptr)(sx + (wave + NW * i) * 256), 16, 0, 0);
 #pragma unroll
-      for (int i = 0; i < IG; ++i)
-        __builtin_amdgcn_global_load_lds(gbase + (tabg[slot][half * HP + gpix[i]] + goff[i]), (lds_ptr)(sg + (wave + NW * i) * 256), 16, 0, 0);
+      for (int i = 0; i < IG; ++i) __builtin_amdgcn_global_load_lds(gbase + o.g[half][i], (lds_ptr)(sg + (wave + NW * i) * 256), 16, 0, 0);
     }
   };
   // pixels past the end (only in the last chunk) were fetched from a clamped address: their G rows must read as zero.  Called AFTER
@@ -1071,10 +1130,19 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   int cA = w.c;
   if (cA < cend) {
     const char *xbA, *gbA, *xbB = xbase, *gbB = gbase;
+    LaneOffsets oA, oB;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int i = 0; i < IX; ++i) oA.x[half][i] = oB.x[half][i] = 0u;
+#pragma unroll
+      for (int i = 0; i < IG; ++i) oA.g[half][i] = oB.g[half][i] = 0u;
+    }
     chunk_bases(xbA, gbA);
     fill_tables(0, 0);
     if (!affine) __syncthreads();
-    issue(xbA, gbA, 0, 0, 0);                    // chunk A, first half -> stage 0
+    fetch_offsets(0, oA);
+    issue(xbA, gbA, oA, 0, 0);                   // chunk A, first half -> stage 0
     int stepped = w.advance();                   // the walk now stands on B
     int cB = w.c;
     chunk_bases(xbB, gbB);
@@ -1085,12 +1153,20 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
     int quart = -1;
     for (int it = 0; cA < cend; ++it) {
       if (a.prio) set_prio_by_progress(cA - cbeg, cend - cbeg, quart);
-      issue(xbA, gbA, it & 1, 1, 1);             // second half of A -> stage 1, lands while stage 0 is multiplied
+#ifdef DRS_DEV
+      const bool late = a.ablate == 2;           // A/B arm: the table reads where they used to be, right in front of each issue
+      if (late) fetch_offsets(it & 1, oA); else
+#endif
+      fetch_offsets((it + 1) & 1, oB);           // B's table was published by the last barrier; its entries are used after compute(0)
+      issue(xbA, gbA, oA, 1, 1);                 // second half of A -> stage 1, lands while stage 0 is multiplied
       compute(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       zero_tail(cA, 1, 1);
-      if (cB < cend) issue(xbB, gbB, (it + 1) & 1, 0, 0);      // first half of B -> stage 0 (every wave is done with it)
+#ifdef DRS_DEV
+      if (late) fetch_offsets((it + 1) & 1, oB);
+#endif
+      if (cB < cend) issue(xbB, gbB, oB, 0, 0);  // first half of B -> stage 0 (every wave is done with it)
       stepped = w.advance();                     // ... and on C, whose table goes into the slot A's table was in
       compute(1);
       fill_tables(it & 1, stepped);
@@ -1098,6 +1174,7 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
       __syncthreads();
       if (cB < cend) zero_tail(cB, 0, 0);
       cA = cB; xbA = xbB; gbA = gbB;
+      oA = oB;
       cB = w.c;
       chunk_bases(xbB, gbB);
     }

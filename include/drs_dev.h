@@ -26,7 +26,7 @@ int drs_debug_wgrad_target(int v);       /* workgroups the pixel split aims at (
 int drs_debug_wgrad_target_big(int v);   /* the same on launches with many tiles and pixels (0 = default rule) */
 int drs_debug_wgrad_len(int v);          /* chunks per workgroup the launches below the `big` class aim at (0 = default: 96, from 2^19 pixels 128) */
 int drs_debug_wgrad_minchunks(int v);    /* fewest 32-pixel chunks a split of the pixel dimension may have (default 8) */
-int drs_debug_wgrad_ablate(int v);       /* 1 = timing experiment (WRONG sums): every filter tap reads the un-shifted pixels (perfect X re-use); 3 = no wave priority by remaining work (same sums) */
+int drs_debug_wgrad_ablate(int v);       /* 1 = timing experiment (WRONG sums): every filter tap reads the un-shifted pixels (perfect X re-use); 2 = the S % 32 != 0 table reads of wgrad_dma_kernel right in front of each DMA issue, as before r04 (same sums); 3 = no wave priority by remaining work (same sums) */
 int drs_debug_wgrad_model(int v);        /* 1 per-CU cost model for the workgroup count of launches below the `big` class (default), 0 the r02 table */
 int drs_debug_slide_blocks(int v);       /* sliding elementwise kernels: workgroups the row-strip split aims at (default 5120) */
 int drs_debug_slide_minrows(int v);      /* ... and the fewest rows of a strip in that first split (default 8) */
