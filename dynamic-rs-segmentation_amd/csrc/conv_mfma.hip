@@ -705,7 +705,7 @@ struct ChunkWalk {
 // beyond the tensor exist only in the last chunk, which alone pays for the select.  Chunk order, tile geometry, slab layout
 // and the order of every sum are those of the first form of this kernel: results are bitwise the same
 // (profiles/r02/wgrad_ablation.txt has the A/B and the ablations).
-template <int TR, int TO>
+template <int TR, int TO, bool AFF>      // AFF: S % 32 == 0, as in wgrad_dma_kernel
 __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) void wgrad_kernel(const WgradArgs a) {
   constexpr int WR = TR >= 64 ? 2 : 1, WC = TO >= 64 ? 2 : 1;
   constexpr int NT = 64 * WR * WC;
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   const uint32_t xconst = (uint32_t)((u * a.rate * Sxp + v * a.rate) * a.ld_x + a.coff_x + c0) * 4u;
   const uint32_t gconst = (uint32_t)(a.coff_g + o0 + (t % GQ) * 4) * 4u;
   const int xpix = t / XQ, gpix = t / GQ;
-  const bool affine = (a.S & 31) == 0;
+  constexpr bool affine = AFF;
   uint32_t xoff[NX], goff[NG];                // S % 32 == 0: the whole per-thread part of the address
 #pragma unroll
   for (int i = 0; i < NX; ++i) xoff[i] = xconst + (affine ? (uint32_t)((xpix + XPS * i) * a.ld_x) * 4u : 0u);
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   auto lstore = [&](int chunk) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) *reinterpret_cast<f32x4*>(&Xs[(xpix + XPS * i) * LDX + (t % XQ) * 4]) = rx[i];
-    if (chunk == clast) {                       // pixels past the end were loaded from a clamped address: their G rows are zero
+    if (!AFF && chunk == clast) {               // pixels past the end were loaded from a clamped address: their G rows are zero (S % 32 == 0: no such chunk)
 #pragma unroll
       for (int i = 0; i < NG; ++i)
         *reinterpret_cast<f32x4*>(&Gs[(gpix + GPS * i) * LDG + (t % GQ) * 4]) =
@@ -931,7 +931,10 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
 // LDS bytes, so image rows are unpadded (TR / TO floats); the ds_read_b32 fragment reads of this kernel (32 consecutive floats
 // per lane group) are conflict-free on such rows.  Chunk walk, tile geometry, slab layout and the order of every sum are those
 // of wgrad_kernel: results are bitwise the same.
-template <int TR, int TO>
+// AFF: S % 32 == 0 (a chunk lies inside one image row: wave-uniform bases + loop-invariant lane offsets); !AFF: the table form.  Two
+// instantiations rather than a run-time flag: the table form keeps a lane's next offsets in registers ACROSS the multiply phases, and
+// the 128 x 192 tile has none to spare (161 VGPRs of 168; with the flag the S % 32 == 0 loop of the headline carried 3 spilled registers).
+template <int TR, int TO, bool AFF>
 __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) void wgrad_dma_kernel(const WgradArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass has no LDS-DMA builtin; it only needs the launch stub
   constexpr int WR = TR >= 64 ? 2 : 1, WC = TO >= 64 ? 2 : 1;
@@ -965,11 +968,7 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   const int o0 = (tile % a.nto) * TO;
   const int rows_all = a.k * a.k * a.Cin;
   const int Sxp = a.S + 2 * a.Px, Sgp = a.S + 2 * a.Pg;
-#ifdef DRS_DEV
-  const bool affine = (a.S & 31) == 0 || a.ablate == 5;      // 5: timing experiment (WRONG sums): the S % 32 == 0 addressing at any S
-#else
-  const bool affine = (a.S & 31) == 0;
-#endif
+  constexpr bool affine = AFF;
   // DMA lane roles: instruction i of this wave moves pieces 64 (wave + NW i) + lane of the linear image: piece f belongs to pixel
   // f / XQ, 16-byte column f % XQ.  (TR is a power of two, so the X column -- and with it the filter tap of the rows this lane
   // stages -- is the same for all of a lane's instructions; TO = 192 gives every instruction its own (pixel, column) pair.)
@@ -1094,7 +1093,7 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   // the zeros -- harmless-looking alone, a run-to-run difference as soon as another kernel shared the chip: tools/soak.py), and a
   // second barrier publishes the zeros before anybody multiplies.  `chunk` is uniform over the workgroup, so are the barriers.
   auto zero_tail = [&](int chunk, int half, int stage) {
-    if (chunk != clast) return;
+    if (AFF || chunk != clast) return;          // (S % 32 == 0: the pixel count is a multiple of 32, there is no such chunk)
     float* sg = lds + stage * STAGE + XSTAGE;
     for (int e = t; e < HP * TO; e += NT)
       if (chunk * BP + half * HP + e / TO >= a.M) sg[e] = 0.f;
@@ -1390,20 +1389,26 @@ int launch_conv(ConvArgs& a, float* ws, size_t ws_floats, hipStream_t st) {
 
 int g_wgrad_variant = -1;    // development switch (drs_debug_wgrad_variant): 0 = register-staged tiles, 1 = LDS-DMA double-buffered halves, -1 = per tile
 
+// the S % 32 == 0 form of wgrad_dma_kernel (development build, ablate 5: at any S -- a timing experiment with WRONG sums)
+inline bool wgrad_affine(const WgradArgs& a) { return (a.S & 31) == 0 || a.ablate == 5; }
+
 template <int TR, int TO>
 int launch_wgrad(const WgradArgs& a, int nwg, hipStream_t st) {
   constexpr int NT = 64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1);
   // in-process A/B at B = 128 (profiles/r02/wgrad_ablation.txt): the LDS-DMA form wins 3-6 % on the 128-wide tiles and loses 7-10 % on the
   // 64-wide ones (Cout = 64, 192), so each layer takes the form that is faster for its tile
   const bool dma = g_wgrad_variant < 0 ? TO == 128 : g_wgrad_variant == 1;
-  if (!dma) DRS_LAUNCH((wgrad_kernel<TR, TO>), dim3(nwg), dim3(NT), 0, st, a);
-  else DRS_LAUNCH((wgrad_dma_kernel<TR, TO>), dim3(nwg), dim3(NT), 0, st, a);
+  if (!dma && wgrad_affine(a)) DRS_LAUNCH((wgrad_kernel<TR, TO, true>), dim3(nwg), dim3(NT), 0, st, a);
+  else if (!dma) DRS_LAUNCH((wgrad_kernel<TR, TO, false>), dim3(nwg), dim3(NT), 0, st, a);
+  else if (wgrad_affine(a)) DRS_LAUNCH((wgrad_dma_kernel<TR, TO, true>), dim3(nwg), dim3(NT), 0, st, a);
+  else DRS_LAUNCH((wgrad_dma_kernel<TR, TO, false>), dim3(nwg), dim3(NT), 0, st, a);
   return DRS_LAUNCH_CHECK();
 }
 
 template <int TR, int TO>
 int launch_wgrad_dma_only(const WgradArgs& a, int nwg, hipStream_t st) {
-  DRS_LAUNCH((wgrad_dma_kernel<TR, TO>), dim3(nwg), dim3(256), 0, st, a);
+  if (wgrad_affine(a)) DRS_LAUNCH((wgrad_dma_kernel<TR, TO, true>), dim3(nwg), dim3(256), 0, st, a);
+  else DRS_LAUNCH((wgrad_dma_kernel<TR, TO, false>), dim3(nwg), dim3(256), 0, st, a);
   return DRS_LAUNCH_CHECK();
 }
 
