@@ -952,7 +952,10 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   __shared__ uint32_t tabx[2][BP], tabg[2][BP];
 
   const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
+  // (S % 32 == 0: the wave index as a scalar -- the LDS address of every DMA piece then is one too, instead of a v_or + v_readfirstlane
+  //  in front of each of the 8 DMA instructions of a chunk: the 8 launches at B = 128 15.10 -> 14.88 ms; the table form, whose loop is short
+  //  of scalar registers, loses 1 % with it)
+  const int lane = t & 63, wave = AFF ? __builtin_amdgcn_readfirstlane(t >> 6) : t >> 6;
   const int li = lane & 31, h = lane >> 5;
   const int wr = wave / WC, wc = wave % WC;
 
