@@ -1102,22 +1102,27 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
       if (chunk * BP + half * HP + e / TO >= a.M) sg[e] = 0.f;
     __syncthreads();
   };
-  const int xr = wr * WTR + li, gc = wc * WTO + li;
+  // Wave (wr, wc) multiplies the 32-row groups wr, wr + WR, ... and the 32-column groups wc, wc + WC, ...: the fragments of one MFMA
+  // step then lie 64 floats (256 B) apart in an LDS row, and a pair of them, every step of a stage and both stages are within the
+  // reach of ds_read2st64_b32's immediate offsets from ONE base register per operand (with groups 2 wr, 2 wr + 1 the pair was 128 B
+  // apart: 16 hoisted base registers for stage 0 and 16 v_add per half chunk for stage 1).
+  const int xr = wr * 32 + li, gc = wc * 32 + li;
+  constexpr int XG = 32 * WR, GG = 32 * WC;      // floats between a wave's consecutive row / column groups
   auto compute = [&](int stage) {
     const float* Xs = lds + stage * STAGE;
     const float* Gs = Xs + XSTAGE;
     float af[2][TMr], bf[2][TNo];
 #pragma unroll
-    for (int mi = 0; mi < TMr; ++mi) af[0][mi] = Xs[h * TR + xr + mi * 32];
+    for (int mi = 0; mi < TMr; ++mi) af[0][mi] = Xs[h * TR + xr + mi * XG];
 #pragma unroll
-    for (int ni = 0; ni < TNo; ++ni) bf[0][ni] = Gs[h * TO + gc + ni * 32];
+    for (int ni = 0; ni < TNo; ++ni) bf[0][ni] = Gs[h * TO + gc + ni * GG];
 #pragma unroll
     for (int s = 0; s < HP / 2; ++s) {
       if (s + 1 < HP / 2) {
 #pragma unroll
-        for (int mi = 0; mi < TMr; ++mi) af[(s + 1) & 1][mi] = Xs[(2 * s + 2 + h) * TR + xr + mi * 32];
+        for (int mi = 0; mi < TMr; ++mi) af[(s + 1) & 1][mi] = Xs[(2 * s + 2 + h) * TR + xr + mi * XG];
 #pragma unroll
-        for (int ni = 0; ni < TNo; ++ni) bf[(s + 1) & 1][ni] = Gs[(2 * s + 2 + h) * TO + gc + ni * 32];
+        for (int ni = 0; ni < TNo; ++ni) bf[(s + 1) & 1][ni] = Gs[(2 * s + 2 + h) * TO + gc + ni * GG];
         __builtin_amdgcn_sched_group_barrier(0x100, TMr + TNo, 0);
       }
 #pragma unroll
@@ -1189,8 +1194,8 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
     for (int ni = 0; ni < TNo; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wr * WTR + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int col = wc * WTO + ni * 32 + li;
+        const int row = mi * XG + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int col = ni * GG + wc * 32 + li;
         if (R0 + row < rows_all) dst[(size_t)row * a.Cout + col] = acc[mi][ni][r];
       }
 #ifdef DRS_DEV
