@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
   __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
 
   const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);      // (scalar: so is the LDS address of each DMA piece)
   const int li = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
   const int ntn = a.Cout / BN;
