@@ -316,8 +316,11 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
 #endif
   const int Sp = a.S + 2 * a.P;
   const int cpt = a.Cin / BK;
-  const char* inb = reinterpret_cast<const char*>(a.in);
   typedef __attribute__((address_space(3))) void* lds_ptr;
+  // raw buffer descriptors over the input slab and the filter (stride 0, no swizzle; every offset below is a byte offset INSIDE its
+  // tensor, < 2^32: the host checks the slab size)
+  const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 0xffffffff, 0x00020000);
   // fragment addresses (floats): A row r = arow + 32 mi, piece c = 2 q + h in slot c ^ ((r >> 2) & 3); B row k, column
   const int arow = wm * WTM + li, bcolw = wn * WTN + li;
   const int sw = (li >> 2) & 3;                 // (arow + 32 mi) >> 2 & 3 == (li >> 2) & 3: WTM and 32 are multiples of 16
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
     u_hi = __builtin_amdgcn_readfirstlane(u_hi);
     const int nks = (u_hi - u_lo) * a.k * cpt;
     if (!SK) ke = nks;
-    const char* wlive = reinterpret_cast<const char*>(a.w + (size_t)u_lo * a.k * a.Cin * a.Cout);
+    const uint32_t wlive_off = (uint32_t)(u_lo * a.k * a.Cin * a.Cout) * 4u;      // byte offset of the first live tap row's filter rows
     // (tap row, tap col, channel chunk) of the K-step being fetched; K-step j of a tile is (chunk, tap row, tap col) = (j / (rows k), ...)
     int lu = u_lo, lv = 0, lc = 0;
     if (SK && kb) {
@@ -391,21 +394,20 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
       lc = __builtin_amdgcn_readfirstlane(lc); lu = __builtin_amdgcn_readfirstlane(lu); lv = __builtin_amdgcn_readfirstlane(lv);
     }
 
+    // The DMA as BUFFER loads: address = descriptor base + the lane's loop-invariant byte offset (a VGPR that is never touched
+    // again) + the K-step's byte offset (an SGPR) -- no vector instruction per piece at all (the global form took a 64-bit address
+    // built per piece: one v_mov / v_lshl_add_u64 each, and every VALU instruction issued in this loop costs matrix-pipe time)
     auto issue = [&](int half, int stage) {
       float* sa = lds + stage * STAGE;
       float* sb = sa + ASTAGE;
-      const char* ab = inb + (size_t)(uint32_t)((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK + half * HK) * 4u;
-      const char* wb = wlive + (size_t)(uint32_t)((((lu - u_lo) * a.k + lv) * cpt + lc) * BK + half * HK) * (uint32_t)a.Cout * 4u;
+      const uint32_t ao = (uint32_t)((lu * a.rate * Sp + lv * a.rate) * a.ld_in + lc * BK + half * HK) * 4u;
+      const uint32_t wo = wlive_off + (uint32_t)((((lu - u_lo) * a.k + lv) * cpt + lc) * BK + half * HK) * (uint32_t)a.Cout * 4u;
 #pragma unroll
-      for (int i = 0; i < IA; ++i) {
-        uint32_t o = offA[i]; asm volatile("" : "+v"(o));
-        __builtin_amdgcn_global_load_lds(ab + o, (lds_ptr)(sa + (wave + 4 * i) * 256), 16, 0, 0);
-      }
+      for (int i = 0; i < IA; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_in, (lds_ptr)(sa + (wave + 4 * i) * 256), 16, (int)offA[i], (int)ao, 0, 0);
 #pragma unroll
-      for (int i = 0; i < IB; ++i) {
-        uint32_t o = offB[i]; asm volatile("" : "+v"(o));
-        __builtin_amdgcn_global_load_lds(wb + o, (lds_ptr)(sb + (wave + 4 * i) * 256), 16, 0, 0);
-      }
+      for (int i = 0; i < IB; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr)(sb + (wave + 4 * i) * 256), 16, (int)offB[i], (int)wo, 0, 0);
     };
     // K order (channel chunk, tap row, tap column): the k*k shifted reads of one 32-channel chunk follow each other, so the lines a
     // tap shares with the one before it (a column shift keeps 7/8 of a row) and with the neighbouring tiles' taps are still in L2
