@@ -96,9 +96,7 @@ __host__ __device__ __forceinline__ int sk_owner(int x, int U, int W) { return (
 
 // Epilogue shared by the forward / input-gradient kernels: bias, optional accumulate, store, and the tile's batch-norm statistics.
 // C/D map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  `scratch`: LDS no wave reads any more.
-// NI: wave wn holds the 32-column groups wn, wn + WN, ... (conv_dma_kernel: its B fragments then are ds_read2st64_b32 pairs off one
-// base register) instead of the WTN consecutive columns wn * WTN ...
-template <int BM, int BN, int WM, int WN, bool NI = false>
+template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], float* scratch, int m0, int n0) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -109,7 +107,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
   float bv[TN];
 #pragma unroll
   for (int ni = 0; ni < TN; ++ni) {
-    const int col = n0 + (NI ? ni * (32 * WN) + wn * 32 : wn * WTN + ni * 32) + li;
+    const int col = n0 + wn * WTN + ni * 32 + li;
     bv[ni] = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
@@ -130,7 +128,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
     // over the WM waves that share a column; one slab row per M tile
     const int rem = a.M - m0;
     tile_column_stats<TN, WM, BN>(
-        scratch, t, wm, h == 0, (float)(rem < BM ? rem : BM), [&](int ni) { return (NI ? ni * (32 * WN) + wn * 32 : wn * WTN + ni * 32) + li; },
+        scratch, t, wm, h == 0, (float)(rem < BM ? rem : BM), [&](int ni) { return wn * WTN + ni * 32 + li; },
         [](float s) { return s + __shfl_xor(s, 32); },
         [&](int ni, auto f) {
 #pragma unroll
@@ -324,7 +322,7 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
   const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, 0xffffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 0xffffffff, 0x00020000);
   // fragment addresses (floats): A row r = arow + 32 mi, piece c = 2 q + h in slot c ^ ((r >> 2) & 3); B row k, column
-  const int arow = wm * WTM + li, bcolw = wn * 32 + li;      // (B: the wave's column groups are wn, wn + WN, ...: conv_epilogue<.., NI>)
+  const int arow = wm * WTM + li, bcolw = wn * WTN + li;
   const int sw = (li >> 2) & 3;                 // (arow + 32 mi) >> 2 & 3 == (li >> 2) & 3: WTM and 32 are multiples of 16
 
   // the K-steps this workgroup multiplies: one whole tile (tile = wg), or -- stream-K -- the range [u, u_end) of the tile-major
@@ -427,14 +425,14 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi) af[0][mi] = *reinterpret_cast<const f32x4*>(&As[(arow + mi * 32) * HK + ((h ^ sw) * 4)]);
 #pragma unroll
-      for (int ni = 0; ni < TN; ++ni) bf[0][ni] = Bs[(h * 4) * BN + bcolw + ni * (32 * WN)];
+      for (int ni = 0; ni < TN; ++ni) bf[0][ni] = Bs[(h * 4) * BN + bcolw + ni * 32];
 #pragma unroll
       for (int st = 0; st < NST; ++st) {
         const int e = st & 3;
         if (st + 1 < NST) {
           const int q1 = (st + 1) >> 2, e1 = (st + 1) & 3;
 #pragma unroll
-          for (int ni = 0; ni < TN; ++ni) bf[(st + 1) & 1][ni] = Bs[(q1 * 8 + h * 4 + e1) * BN + bcolw + ni * (32 * WN)];
+          for (int ni = 0; ni < TN; ++ni) bf[(st + 1) & 1][ni] = Bs[(q1 * 8 + h * 4 + e1) * BN + bcolw + ni * 32];
           if (e1 == 0) {
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
@@ -468,7 +466,7 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
       __syncthreads();
     }
     if (!SK || (kb == 0 && ke == nks)) {
-      conv_epilogue<BM, BN, WM, WN, true>(a, acc, lds, m0, n0);
+      conv_epilogue<BM, BN, WM, WN>(a, acc, lds, m0, n0);
     } else {
       // partial sums of a tile this workgroup shares with others: a piece of the slab in accumulator order, four registers per
       // access ([fragment quad][lane][4]: 1-KB wave stores); a workgroup has at most two such segments, its first (piece 2 w)
@@ -559,7 +557,7 @@ __global__ __launch_bounds__(256) void conv_sk_fixup_kernel(const ConvArgs a) {
           for (int j = 0; j < 4; ++j) acc[mi][ni][4 * q + j] += v[j];
         }
   }
-  conv_epilogue<BM, BN, WM, WN, true>(a, acc, lds, m0, n0);
+  conv_epilogue<BM, BN, WM, WN>(a, acc, lds, m0, n0);
 }
 
 // ------------------------------------------------------------------------------------------------ wgrad
