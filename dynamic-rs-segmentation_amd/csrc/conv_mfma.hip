@@ -1462,7 +1462,9 @@ int g_wgrad_len = 0;        // development switch (drs_debug_wgrad_len): chunks 
 // r03 tuned 96 at the per-rank batches; with the waves' priority by remaining work (from 2^18 pixels) the workgroups of a launch end
 // together and longer ones pay: in-process A/B over conv2..conv8, B = 128: 96 -> 15.89 ms, 128 -> 15.78, 160 -> 15.79, 192 -> 15.80,
 // 256 -> 16.08; B = 64: 8.09 / 8.08 / 8.19 (96 / 128 / 192); B = 16: 2.21 / 2.31 / 2.40
-inline int wgrad_len(int nchunks) { return g_wgrad_len ? g_wgrad_len : (nchunks >= (1 << 14) ? 128 : 96); }
+// (r04, with the kernels' loops cleaned up: B = 128 128 -> 14.77 ms, 192 -> 14.43 (conv6's 1534 workgroups of two rounds become 767 of one:
+//  2.67 -> 2.35 ms), 256 -> 14.68; B = 128 at S = 75 / 85 and B = 64 at S = 100: 192 -0.4 .. -0.7 %; B = 64: 96 = 128, 192 +1.5 %)
+inline int wgrad_len(int nchunks) { return g_wgrad_len ? g_wgrad_len : (nchunks >= (1 << 14) ? 192 : 96); }
 int g_wgrad_minchunks = 8;  // development switch (drs_debug_wgrad_minchunks): fewest 32-pixel chunks a split may have
 int g_wgrad_target_big = 0;  // development switch: workgroups aimed at on launches with many tiles and pixels under the live cut (0 = default)
 
@@ -1471,12 +1473,13 @@ int g_wgrad_model = 1;       // development switch (drs_debug_wgrad_model): 1 = 
 
 // workgroups a filter-gradient launch of `work` chunk-tiles (32-pixel chunks x tiles) aims at; occ = workgroups of this tile
 // shape a CU holds (4; the 128 x 192 tile: 3)
-int wgrad_target(long long work, int ntile, int nchunks, bool balanced, int occ) {
+int wgrad_target(long long work, int ntile, int nchunks, bool balanced, int occ, int len = 0) {
+  if (len <= 0) len = wgrad_len(nchunks);
   // fill the 256 CUs evenly.  Small launches (the per-rank batches of data parallelism) want long workgroups more than many:
   // >= 96 chunks each, down to one round of 512 (sweeps at B = 16 / 32 in profiles/r02/wgrad_ablation.txt).  Launches with many
   // tiles and pixels: with equal chunk ranges and the dead chunks skipped the workgroups differ in length by up to a quarter and
   // two rounds quantise the gain away, so twice as many (measured at B = 128: conv6 3.48 -> 3.01 ms, conv8 5.19 -> 4.85).
-  long long fit = work / wgrad_len(nchunks);
+  long long fit = work / len;
   fit = fit < 512 ? 512 : (fit > g_wgrad_target ? g_wgrad_target : fit);
   const bool big = ntile >= 24 && nchunks >= 8192;
   if (!balanced) return big ? 2 * g_wgrad_target : (int)fit;
@@ -1497,7 +1500,7 @@ int wgrad_target(long long work, int ntile, int nchunks, bool balanced, int occ)
       const double t = (W0 + i * o) / eff[i];
       if (t < bt) { bt = t; n = i; }
     }
-    int r = (int)(W0 / n / (double)wgrad_len(nchunks) + 0.5);
+    int r = (int)(W0 / n / (double)len + 0.5);
     r = r < 1 ? 1 : r;
     const long long t = 256LL * n * r;
     return (int)(t > 4096 ? 4096 : t);
@@ -1510,12 +1513,12 @@ int wgrad_target(long long work, int ntile, int nchunks, bool balanced, int occ)
 }
 
 // equal chunk ranges: the number of splits.  Never less than g_wgrad_minchunks chunks per split.
-int wgrad_uniform_splits(int B, int S, int k, int cin, int cout) {
+int wgrad_uniform_splits(int B, int S, int k, int cin, int cout, int len = 0) {
   const long long M = (long long)B * S * S;
   const int tr = pick_wgrad_rows(k * k * cin), to = pick_wgrad_cols(tr, cout);
   const int ntile = ((k * k * cin + tr - 1) / tr) * (cout / to);
   const int nchunks = (int)((M + 31) / 32);
-  int want = wgrad_target((long long)nchunks * ntile, ntile, nchunks, false, 4) / ntile;
+  int want = wgrad_target((long long)nchunks * ntile, ntile, nchunks, false, 4, len) / ntile;
   int maxs = (nchunks + g_wgrad_minchunks - 1) / g_wgrad_minchunks;
   if (maxs < 1) maxs = 1;
   if (want > maxs) want = maxs;
@@ -1594,7 +1597,12 @@ bool wgrad_live_plan(int B, int S, int k, int rate, int pad, int cin, int cout, 
 }
 
 int wgrad_bound_splits(int B, int S, int k, int cin, int cout) {
-  const int u = wgrad_uniform_splits(B, S, k, cin, cout);
+  // (worked out with the SHORTEST workgroup length the rule ever takes, whatever this shape's own: the host sizes the slab at
+  //  (b_max, s_max) and every smaller step, whose launches may take the shorter length and so MORE splits, must fit into it:
+  //  tests/test_wgrad_cut.py::test_slab_sized_at_the_largest_step_serves_every_smaller_one)
+  const int shortest = g_wgrad_len && g_wgrad_len < 96 ? g_wgrad_len : 96;
+  const int ua = wgrad_uniform_splits(B, S, k, cin, cout), ub = wgrad_uniform_splits(B, S, k, cin, cout, shortest);
+  const int u = ua > ub ? ua : ub;
   int maxs = (int)(((long long)B * S * S + 32LL * g_wgrad_minchunks - 1) / (32LL * g_wgrad_minchunks));
   if (maxs < 1) maxs = 1;
   const int bound = u + u / 2 + 1;
