@@ -1407,7 +1407,9 @@ int launch_wgrad(const WgradArgs& a, int nwg, hipStream_t st) {
   constexpr int NT = 64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1);
   // in-process A/B at B = 128 (profiles/r02/wgrad_ablation.txt): the LDS-DMA form wins 3-6 % on the 128-wide tiles and loses 7-10 % on the
   // 64-wide ones (Cout = 64, 192), so each layer takes the form that is faster for its tile
-  const bool dma = g_wgrad_variant < 0 ? TO == 128 : g_wgrad_variant == 1;
+  // (r04, after the loop clean-ups of the LDS-DMA form: at S % 32 == 0 it now also wins on the 64-wide tiles -- conv2 at B = 128 0.830 -> 0.806 ms,
+  //  at B = 16 0.140 -> 0.132; the table form still loses 2 % there)
+  const bool dma = g_wgrad_variant < 0 ? (TO == 128 || (TO == 64 && wgrad_affine(a))) : g_wgrad_variant == 1;
   if (!dma && wgrad_affine(a)) DRS_LAUNCH((wgrad_kernel<TR, TO, true>), dim3(nwg), dim3(NT), 0, st, a);
   else if (!dma) DRS_LAUNCH((wgrad_kernel<TR, TO, false>), dim3(nwg), dim3(NT), 0, st, a);
   else if (wgrad_affine(a)) DRS_LAUNCH((wgrad_dma_kernel<TR, TO, true>), dim3(nwg), dim3(NT), 0, st, a);
