@@ -55,6 +55,9 @@ def mark(stage, rank=None):
     sys.stderr.flush()
 
 
+_CHILDREN = []           # process groups this (GPU-free) parent started and has not reaped yet
+
+
 def _kill_group(proc):
     import signal
     for sig, wait in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 10.0)):
@@ -69,13 +72,45 @@ def _kill_group(proc):
             continue
 
 
+def _die_with_parent():
+    """preexec of every child: SIGTERM when the parent goes away however it goes (a SIGKILLed parent runs no handler).  The child is a
+    session leader; a launcher child passes the signal on to its ranks, and those are supervisors with the handlers below."""
+    import ctypes
+    import signal
+    try:
+        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)       # PR_SET_PDEATHSIG
+    except Exception:
+        pass
+
+
+def _install_cleanup_handlers():
+    """SIGTERM / SIGINT / SIGHUP to a supervisor or to the plain parent: take the children's process groups down first (they run in
+    sessions of their own, so nothing else would: `timeout ... python bench.py --gpus 8`, Ctrl-C, or the launcher tearing the other
+    ranks down after one gave up would leave measuring processes on the GPUs -- a child hung in RCCL writes nothing and never sees
+    EPIPE), then exit non-zero."""
+    import signal
+
+    def handler(signum, frame):
+        for proc in list(_CHILDREN):
+            _kill_group(proc)
+        os._exit(128 + signum)
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        try:
+            signal.signal(sig, handler)
+        except (ValueError, OSError):
+            pass
+
+
 def _run_watched(cmd, env, limit_s, need_marks=True, rendezvous_slack=1.0):
     """start `cmd` as a fresh process group, relay its stderr (watching the markers) and collect its stdout.
-    Returns (rc or None if killed by the watchdog, stdout text, last marker stage).  `rendezvous_slack` multiplies the limit until the
-    process group is up: the ranks of a fall-back attempt arrive up to one watchdog period apart (each supervisor times out alone)."""
+    Returns (rc or None if killed by the watchdog, stdout text, last marker stage, the silence limit that applied last).
+    `rendezvous_slack` multiplies the limit until the process group is up: the ranks of a fall-back attempt arrive up to one watchdog
+    period apart (each supervisor times out alone).  However this function is left (return, exception, signal handler), the child's
+    process group does not outlive it."""
     import subprocess
     import threading
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True, preexec_fn=_die_with_parent)
+    _CHILDREN.append(proc)
     state = dict(last=time.time(), stage="started", out=[])
 
     def pump_err():
@@ -97,25 +132,73 @@ def _run_watched(cmd, env, limit_s, need_marks=True, rendezvous_slack=1.0):
     for t in th:
         t.start()
     killed = False
-    while True:
-        try:
-            proc.wait(timeout=1.0)
-            break
-        except subprocess.TimeoutExpired:
-            # until its imports are done a process may be paging the image in (minutes on a fresh box): the long limit; after that
-            # every stage is seconds long: the short one (rendezvous of a fall-back attempt: the ranks arrive up to a period apart)
-            stage_s = float(os.environ.get("DRS_BENCH_WATCHDOG_STAGE_S", "120"))
-            lim = limit_s if state["stage"] == "started" else min(limit_s, stage_s)
-            if state["stage"] in ("started", "imports done"):
-                lim *= rendezvous_slack
-            if need_marks and time.time() - state["last"] > lim:
-                sys.stderr.write("bench.py watchdog: no progress marker for %.0f s after stage '%s': killing the process group\n" % (lim, state["stage"]))
-                _kill_group(proc)
-                killed = True
+    lim = limit_s
+    try:
+        while True:
+            try:
+                proc.wait(timeout=1.0)
                 break
+            except subprocess.TimeoutExpired:
+                # until its imports are done a process may be paging the image in (minutes on a fresh box): the long limit; after that
+                # every stage is seconds long: the short one (rendezvous of a fall-back attempt: the ranks arrive up to a period apart)
+                stage_s = float(os.environ.get("DRS_BENCH_WATCHDOG_STAGE_S", "120"))
+                lim = limit_s if state["stage"] == "started" else min(limit_s, stage_s)
+                if state["stage"] in ("started", "imports done"):
+                    lim *= rendezvous_slack
+                if need_marks and time.time() - state["last"] > lim:
+                    sys.stderr.write("bench.py watchdog: no progress marker for %.0f s after stage '%s': killing the process group\n" % (lim, state["stage"]))
+                    killed = True
+                    break
+    finally:
+        # the leader may be gone while members of its group live on (a launcher's ranks): signal the GROUP whatever the leader's state
+        if killed or proc.poll() is None:
+            _kill_group(proc)
+        else:
+            import signal
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+        if proc in _CHILDREN:
+            _CHILDREN.remove(proc)
     for t in th:
         t.join(timeout=5.0)
-    return (None if killed else proc.returncode), "".join(state["out"]), state["stage"]
+    return (None if killed else proc.returncode), "".join(state["out"]), state["stage"], lim
+
+
+def _fallback_port(port0, i):
+    """rendezvous port of fall-back attempt i: every supervisor of the launch must arrive at the same one without talking to the others.
+    Rank 0's supervisor checks the derived port (port0 + 101 i), takes a free one if that is taken, and publishes its choice in a file
+    keyed by the launcher (the supervisors' common parent) that the other ranks wait for; without the file (another host's /tmp, a
+    read-only one) everybody falls back to the derived port."""
+    import socket
+    import tempfile
+    derived = port0 + 101 * i
+    path = os.path.join(tempfile.gettempdir(), "drs_bench_%d_%d_%d.port" % (os.getppid(), port0, i))
+    if os.environ.get("RANK", "0") == "0":
+        port = derived
+        try:
+            with socket.socket() as so:
+                so.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                so.bind(("127.0.0.1", derived))
+        except OSError:
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+        try:
+            with open(path + ".tmp", "w") as f:
+                f.write(str(port))
+            os.replace(path + ".tmp", path)
+        except OSError:
+            return derived
+        return port
+    t_end = time.time() + float(os.environ.get("DRS_BENCH_PORT_WAIT_S", "30"))
+    while time.time() < t_end:
+        try:
+            return int(open(path).read().strip())
+        except (OSError, ValueError):
+            time.sleep(0.2)
+    return derived
 
 
 def supervise(argv):
@@ -124,21 +207,22 @@ def supervise(argv):
     chain = [("default", {})] + [(k, FALLBACK_ENV[k]) for k in os.environ.get("DRS_BENCH_FALLBACKS", "torch,async").split(",") if k in FALLBACK_ENV]
     port0 = int(os.environ.get("MASTER_PORT", "29500"))
     reason = ""
+    _install_cleanup_handlers()
     for i, (label, extra) in enumerate(chain):
         env = dict(os.environ)
         env.update(extra)
         env.update(DRS_BENCH_CHILD="1", DRS_BENCH_ATTEMPT=label, DRS_BENCH_FALLBACK_REASON=reason)
         if i > 0:
             # a rendezvous of its own: the launcher's store still holds the keys of the attempt that was killed.  Rank 0's child hosts it.
-            env.update(MASTER_PORT=str(port0 + 101 * i), TORCHELASTIC_USE_AGENT_STORE="False")
-        rc, out, stage = _run_watched([sys.executable, os.path.abspath(__file__)] + argv, env, limit, rendezvous_slack=1.0 if i == 0 else 2.5)
+            env.update(MASTER_PORT=str(_fallback_port(port0, i)), TORCHELASTIC_USE_AGENT_STORE="False")
+        rc, out, stage, lim = _run_watched([sys.executable, os.path.abspath(__file__)] + argv, env, limit, rendezvous_slack=1.0 if i == 0 else 2.5)
         if rc == 0:
             # stdout carries the ONE JSON line (rank 0's) and nothing else: whatever a library printed to the child's descriptor 1 goes to stderr
             for ln in out.splitlines():
                 (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln + "\n")
             sys.stdout.flush()
             return 0
-        reason = ("timeout: silent for %.0f s after stage '%s'" % (limit, stage)) if rc is None else ("exit code %s after stage '%s'" % (rc, stage))
+        reason = ("timeout: silent for %.0f s after stage '%s'" % (lim, stage)) if rc is None else ("exit code %s after stage '%s'" % (rc, stage))
         reason = "%s attempt: %s" % (label, reason)
         sys.stderr.write("bench.py supervisor (rank %s): %s%s\n" % (os.environ.get("RANK", "?"), reason, "; falling back" if i + 1 < len(chain) else "; giving up"))
     if os.environ.get("RANK", "0") == "0":
@@ -164,7 +248,8 @@ def plain_parent(args, argv):
         port = so.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + argv
-    rc, out, _ = _run_watched(cmd, dict(os.environ), 0.0, need_marks=False)
+    _install_cleanup_handlers()
+    rc, out, _, _ = _run_watched(cmd, dict(os.environ), 0.0, need_marks=False)
     lines = [ln for ln in out.splitlines() if ln.strip().startswith("{")]
     if lines:
         sys.stdout.write(lines[-1] + "\n")

@@ -9,6 +9,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
@@ -65,3 +67,61 @@ def test_every_attempt_failing_is_reported_not_hung(tmp_path):
     assert rc != 0
     d = json.loads(lines[-1])
     assert d["value"] is None and "every attempt failed" in d["error"]
+
+
+def _alive_with_token(token):
+    """pids of live processes whose environment carries `token` (every process the launch started inherits it)"""
+    pids = []
+    for d in os.listdir("/proc"):
+        if not d.isdigit() or int(d) == os.getpid():
+            continue
+        try:
+            env = open("/proc/%s/environ" % d, "rb").read()
+            stat = open("/proc/%s/stat" % d).read()
+        except OSError:
+            continue
+        if token.encode() in env and ") Z " not in stat:
+            pids.append(int(d))
+    return pids
+
+
+@pytest.mark.parametrize("sig", ["TERM", "KILL"])
+def test_no_child_outlives_a_parent_that_is_killed_during_a_hang(tmp_path, sig):
+    """the measuring processes run in sessions of their own; `timeout ... python bench.py --gpus N`, Ctrl-C or the launcher
+    tearing the ranks down must not leave them on the GPUs.  SIGTERM: the handlers take the groups down; SIGKILL: PR_SET_PDEATHSIG does."""
+    import signal
+    import time
+    import uuid
+    token = "drs-token-" + uuid.uuid4().hex
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "DRS_BENCH_CHILD", "DRS_COMM", "DRS_RCCL_ASYNC"):
+        e.pop(k, None)
+    e.update(DRS_BENCH_SELFTEST="1", DRS_BENCH_FAKE_HANG="default", DRS_BENCH_WATCHDOG_S="600", DRS_BENCH_WATCHDOG_STAGE_S="600", DRS_TEST_TOKEN=token)
+    errf = open(str(tmp_path / "err.txt"), "wb")
+    p = subprocess.Popen([sys.executable, BENCH, "--gpus", "2"], cwd=str(tmp_path), env=e, stdout=subprocess.DEVNULL, stderr=errf)
+    try:
+        t_end = time.time() + 240
+        while time.time() < t_end:                         # both measuring children are up and hanging
+            if open(str(tmp_path / "err.txt"), "rb").read().count(b"stage=process group up") >= 2:
+                break
+            assert p.poll() is None, open(str(tmp_path / "err.txt")).read()
+            time.sleep(0.5)
+        else:
+            raise AssertionError("the children never reached the hang: " + open(str(tmp_path / "err.txt")).read())
+        assert len(_alive_with_token(token)) >= 5          # parent, launcher, two supervisors, two measuring processes (minus this one)
+        p.send_signal(signal.SIGTERM if sig == "TERM" else signal.SIGKILL)
+        p.wait(timeout=60)
+        assert p.returncode != 0
+        t_end = time.time() + 60
+        while time.time() < t_end and _alive_with_token(token):
+            time.sleep(0.5)
+        left = _alive_with_token(token)
+        assert not left, "processes that outlived the parent: %s" % [open("/proc/%d/cmdline" % q, "rb").read() for q in left]
+    finally:
+        for q in _alive_with_token(token):
+            try:
+                os.kill(q, signal.SIGKILL)
+            except OSError:
+                pass
+        if p.poll() is None:
+            p.kill()
