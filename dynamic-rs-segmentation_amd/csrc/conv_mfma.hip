@@ -38,8 +38,15 @@ struct ConvArgs {
   // stream-K (sk_W > 0; conv_dma_kernel only): the launch has sk_W workgroups and the K-steps of ALL tiles, in tile-major order
   // (sk_U = tiles * sk_nks of them), are cut into sk_W equal consecutive ranges; a tile that one range covers whole is finished
   // by that workgroup, the others leave their partial sums in sk_slab and conv_sk_fixup_kernel adds them in a fixed order
+  // Hybrid (r05): only the tiles [0, sk_T) are cut that way, into sk_W ranges (sk_U = sk_T * sk_nks); the other sk_tiles - sk_T tiles stay
+  // whole and are dealt out with stride sk_G = the launch's workgroup count (tile sk_T + w + j sk_G to workgroup w): the full rounds of a
+  // launch run whole tiles, only the remainder that would make a nearly empty last round is cut across all workgroups.  sk_T == sk_tiles,
+  // sk_G == sk_W is the pure stream-K launch of r03.  sk_order: which part a workgroup does first (0 its range, 1 its whole tiles,
+  // 2 alternating by workgroup slot)
   float* sk_slab;
   int sk_W, sk_nks, sk_U;
+  int sk_T, sk_tiles, sk_G, sk_order;
+  int prio;             // waves lower their priority as their workgroup advances (set_prio_by_progress)
   // launch order "long tiles first" (plain launches with halo-tap skipping, whole patches per XCD chunk): lpt_T = M tiles per patch
   // (0 = natural order), tiles [lpt_ta, lpt_tb) of a patch multiply every tap row, the others skip some; lpt_P = patches per XCD chunk
   int lpt_T, lpt_ta, lpt_tb, lpt_P;
@@ -327,24 +334,45 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
 
   // the K-steps this workgroup multiplies: one whole tile (tile = wg), or -- stream-K -- the range [u, u_end) of the tile-major
   // sequence, i.e. the tail of one tile, whole tiles, the head of another
-  int u = 0, u_end = 1;
+  // (hybrid: + the whole tiles sk_T + wg, sk_T + wg + sk_G, ...; the sk_W <= sk_G ranges are spread evenly over the workgroups: range j
+  //  goes to the first workgroup w with ceil(w sk_W / sk_G) == j)
+  int u = 0, u_end = 1, rng = 0, dp_next = 0;
+  bool dp_first = false;
   if (SK) {
-    u = __builtin_amdgcn_readfirstlane(sk_first_unit(wg, a.sk_U, a.sk_W));
-    u_end = __builtin_amdgcn_readfirstlane(sk_first_unit(wg + 1, a.sk_U, a.sk_W));
-    if (u >= u_end) return;
+    const int jb = (int)(((long long)wg * a.sk_W + a.sk_G - 1) / a.sk_G), je = (int)(((long long)(wg + 1) * a.sk_W + a.sk_G - 1) / a.sk_G);
+    rng = __builtin_amdgcn_readfirstlane(jb);
+    u = u_end = 0;
+    if (je > jb) {
+      u = __builtin_amdgcn_readfirstlane(sk_first_unit(jb, a.sk_U, a.sk_W));
+      u_end = __builtin_amdgcn_readfirstlane(sk_first_unit(jb + 1, a.sk_U, a.sk_W));
+    }
+    dp_next = a.sk_T + wg;
+    if (u >= u_end && dp_next >= a.sk_tiles) return;
+    dp_first = a.sk_order == 1 || (a.sk_order == 2 && ((blockIdx.x >> 8) & 1));
   }
   // the workgroups of a launch start in index order and the launch ends with its last round draining: let that round be the SHORT
   // tiles (r04, tools/conv_tail.py: the drain of conv8's forward launch 419 -> 216 us, idle workgroup slots 6.4 -> 3.5 % of the launch;
   // in-process A/B over the 14 forward / input-gradient launches at B = 128: -1.2 .. -5.5 % each, 29.7 -> 28.8 ms)
   const int tile0 = (!SK && a.lpt_T) ? __builtin_amdgcn_readfirstlane(lpt_tile(wg, a.lpt_T, a.lpt_ta, a.lpt_tb, a.lpt_P, ntn)) : wg;
   bool first_seg = true;
+  int quart = -1, done = 0, total = 1;
+  if (SK && a.prio) total = (u_end - u) + (dp_next < a.sk_tiles ? ((a.sk_tiles - 1 - dp_next) / a.sk_G + 1) * a.sk_nks : 0);
   for (;;) {
     int tile = tile0, kb = 0, ke = 0;
+    bool in_range = false;
     if (SK) {
-      tile = u / a.sk_nks;
-      kb = u - tile * a.sk_nks;
-      ke = kb + (u_end - u);
-      ke = ke < a.sk_nks ? ke : a.sk_nks;
+      in_range = u < u_end && !(dp_first && dp_next < a.sk_tiles);
+      if (in_range) {
+        tile = u / a.sk_nks;
+        kb = u - tile * a.sk_nks;
+        ke = kb + (u_end - u);
+        ke = ke < a.sk_nks ? ke : a.sk_nks;
+      } else {
+        tile = dp_next;
+        dp_next += a.sk_G;
+        kb = 0;
+        ke = a.sk_nks;
+      }
     }
     const int m0 = (tile / ntn) * BM;
     const int n0 = (tile % ntn) * BN;
@@ -454,7 +482,9 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (!SK && a.prio) total = nks;
     for (int ks = kb; ks < ke; ++ks) {
+      if (a.prio) set_prio_by_progress(SK ? done + (ks - kb) : ks, total, quart);
       issue(1, 1);                                  // second half of this K-step lands while the first is multiplied
       compute(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -471,7 +501,7 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
       // partial sums of a tile this workgroup shares with others: a piece of the slab in accumulator order, four registers per
       // access ([fragment quad][lane][4]: 1-KB wave stores); a workgroup has at most two such segments, its first (piece 2 w)
       // and its last (piece 2 w + 1)
-      float* piece = a.sk_slab + (size_t)(2 * wg + (first_seg ? 0 : 1)) * (BM * BN) + (size_t)wave * (TM * TN * 16 * 64) + lane * 4;
+      float* piece = a.sk_slab + (size_t)(2 * rng + (first_seg ? 0 : 1)) * (BM * BN) + (size_t)wave * (TM * TN * 16 * 64) + lane * 4;
 #pragma unroll
       for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -482,9 +512,9 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
                 f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
     }
     if (!SK) break;
-    u += ke - kb;
-    if (u >= u_end) break;
-    first_seg = false;
+    done += ke - kb;
+    if (in_range) { u += ke - kb; first_seg = false; }
+    if (u >= u_end && dp_next >= a.sk_tiles) break;
     __syncthreads();                                // the epilogue's LDS scratch is free before the next segment's DMA lands
   }
 #ifdef DRS_DEV
@@ -1289,6 +1319,8 @@ unsigned long long* g_conv_trace = nullptr;      // development build (drs_debug
 #endif
 int g_conv_lpt = 1;          // development switch (drs_debug_conv_lpt): 1 = plain launches start their full tiles first, the halo-skipping ones last
 int g_conv_splitk = -1;      // development switch (drs_debug_conv_splitk): -1 = stream-K by the rule below, 0 = never, n >= 1: n workgroups
+int g_conv_sk_order = 1;     // development switch (drs_debug_conv_sk_order): a hybrid workgroup does 0 its range first, 1 its whole tiles first, 2 alternating by slot
+int g_conv_prio = -1;        // development switch (drs_debug_conv_prio): wave priority by remaining work in the forward / input-gradient kernel: -1 = by the rule in launch_conv_dma, 0 = never, 1 = always
 
 constexpr int SK_MAX_TILES = 4096;     // from here on the tiles fill the chip many times over (and the all-halo tap rows are skipped instead)
 
@@ -1305,41 +1337,58 @@ int cu_count() {
 }
 inline int sk_max_w() { return 3 * cu_count(); }      // most workgroups of a stream-K launch: 3 per CU
 
-// Stream-K launch geometry of the forward / input-gradient pass: 0 = one workgroup per tile.
+// Stream-K launch geometry of the forward / input-gradient pass: G == 0 = one workgroup per tile.
 // A launch of few tiles leaves CUs idle (B = 16, S = 25: 79 M tiles for 256 CUs) and ends with its longest K loop; a launch of a
 // few hundred tiles ends with a round that is nearly empty (B = 16, S = 65: 1058 tiles for 1024 places: 0.65 of the rate the same
 // kernel reaches at S = 75).  Cutting the K-steps of all tiles into W equal ranges, W a whole number of workgroups per CU, gives
 // every CU the same work whatever the tile count; the price is the partial-sum slab of the tiles that are cut (at most two
 // pieces per workgroup) and the fix-up launch.  Per-size table: profiles/r03/small_m.
-int sk_workgroups(int tiles, int nks, int bn, size_t ws_floats) {
-  if (g_conv_splitk == 0 || tiles >= SK_MAX_TILES || nks < 2) return 0;
-  const long long U = (long long)tiles * nks;
+// Hybrid (r05): a launch of MORE tiles than the G = 3 x CUs workgroups the chip holds of this form runs its full rounds as whole
+// tiles (tile T + w + j G on workgroup w: no piece, the fast epilogue) and cuts only the remaining T = tiles mod G tiles into W <= G
+// ranges -- every workgroup still does the same number of K-steps, the slab traffic and the fix-up launch shrink from `tiles` to T tiles.
+struct SkGeom { int G, W, T; };      // workgroups of the launch, ranges the first T tiles are cut into
+int g_conv_hybrid = 1;       // development switch (drs_debug_conv_hybrid): 1 = whole tiles for the full rounds, 0 = every tile cut (r03)
+SkGeom sk_geometry(int tiles, int nks, int bn, size_t ws_floats) {
+  const SkGeom plain = {0, 0, 0};
+  if (g_conv_splitk == 0 || tiles >= SK_MAX_TILES || nks < 2) return plain;
   const long long NCU = cu_count();
   long long cap = (long long)(ws_floats / (2ull * 128 * (size_t)bn));
   if (cap > sk_max_w()) cap = sk_max_w();
-  if (cap < 1) return 0;
-  long long W;
+  if (cap < 1) return plain;
+  const int MINU = 12;                                         // K-steps a range should at least have (prologue + epilogue cost ~2)
+  const int occ = 3;                                           // workgroups a CU holds of the stream-K form (136 / 168 VGPRs)
+  long long G, W, T = tiles;
   if (g_conv_splitk > 0) {
-    W = g_conv_splitk;
+    G = W = g_conv_splitk;
   } else {
     // one workgroup per tile loads the busiest CU with ceil(tiles / 256) tiles: where that is within 7 % of the mean the plain
     // launch is the faster one (no slab, no fix-up, 4 instead of 3 workgroups per CU); measured at B = 16, S = 25 .. 85
     // (profiles/r03/ab_streamk_b16.log): plain 0.85-0.87 of the fp32 roof at a perfect fit and proportionally less otherwise,
     // stream-K 0.78-0.85 at every tile count
     const long long per = (tiles + NCU - 1) / NCU;
-    if ((double)tiles >= 0.93 * (double)NCU * (double)per) return 0;
-    const int MINU = 12;                                       // K-steps a workgroup should at least have (prologue + epilogue cost ~2)
-    const int occ = 3;                                         // workgroups a CU holds of the stream-K form (136 / 168 VGPRs)
+    if ((double)tiles >= 0.93 * (double)NCU * (double)per) return plain;
+    const long long U = (long long)tiles * nks;
     long long per_cu = U / (NCU * MINU);
     per_cu = per_cu < 1 ? 1 : (per_cu > occ ? occ : per_cu);
-    W = NCU * per_cu;
-    if (U < NCU * MINU) W = U / MINU > 0 ? U / MINU : 1;
+    G = W = NCU * per_cu;
+    if (U < NCU * MINU) G = W = U / MINU > 0 ? U / MINU : 1;
   }
-  if (W > U) W = U;
+  if (g_conv_hybrid && tiles > G) {
+    T = tiles % G;
+    if (T == 0) return plain;                                  // (whole rounds of the 3-per-CU form: the 4-per-CU plain form does them better)
+    // (every workgroup takes a range however short: with fewer, longer ranges the workgroups that have one run that much longer than the
+    //  others -- B = 16, S = 85, conv3: 362 ranges of 12 K-steps on top of 32-step tiles, +8 % against 768 ranges of 5-6)
+    W = G;
+  }
+  if (W > T * nks) W = T * nks;
+  if (W > G) W = G;
   // the cut must follow from the SHAPE alone: a workspace too small for it gets the plain launch, not a smaller cut (the sums of a
   // convolution would otherwise associate differently from one caller's workspace to another's)
-  if (W > cap) return g_conv_splitk > 0 ? (int)cap : 0;
-  return (int)W;
+  if (W > cap) {
+    if (g_conv_splitk <= 0) return plain;
+    W = cap; if (G < W || T == tiles) G = W;
+  }
+  return SkGeom{(int)G, (int)W, (int)T};
 }
 
 // parameters of the "full tiles first" launch order (lpt_tile): only for plain launches whose M tiles are whole image rows of whole
@@ -1373,15 +1422,23 @@ template <int BM, int BN, int WM, int WN>
 int launch_conv_dma(ConvArgs& a, float* ws, size_t ws_floats, hipStream_t st) {
   const int mt = (a.M + BM - 1) / BM, nt = a.Cout / BN;
   const int nks = a.k * a.k * (a.Cin / BK);
-  const int W = ws && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 ? sk_workgroups(mt * nt, nks, BN, ws_floats) : 0;   // (16-byte piece accesses)
-  a.sk_W = W; a.sk_nks = nks; a.sk_U = mt * nt * nks; a.sk_slab = ws;
-  conv_lpt_setup(a, BM, mt, nt, W);
-  if (W) DRS_LAUNCH((conv_dma_kernel<BM, BN, WM, WN, true>), dim3(W), dim3(256), 0, st, a);
+  const SkGeom g = ws && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 ? sk_geometry(mt * nt, nks, BN, ws_floats) : SkGeom{0, 0, 0};   // (16-byte piece accesses)
+  const int W = g.W;
+  a.sk_W = W; a.sk_nks = nks; a.sk_U = g.T * nks; a.sk_slab = ws;
+  a.sk_T = g.T; a.sk_tiles = mt * nt; a.sk_G = g.G; a.sk_order = g_conv_sk_order;
+  // Wave priority by remaining work (set_prio_by_progress) in the stream-K / hybrid launches: their equal-length workgroups all start
+  // together and the SIMD arbiter lets the oldest run ahead, so the last of a CU finishes alone.  In-process A/B over the 14 forward /
+  // input-gradient launches at B = 16 (tools/ab_conv_sched.py, profiles/r05/conv_schedule_ab.txt): S = 85 7.18 -> 7.04 ms, 65: 4.38 ->
+  // 4.34, 55 -1 %, 35 -1 %, 25 +0.7 % (ranges of ~15 K-steps: nothing to catch up on) -- so from 20 K-steps per workgroup.  NOT in
+  // plain launches: -0.6 % on the one-round ones of B = 16, S = 64, but +2.4 % at B = 32 and B = 128 and +18 % on a 192-wide tile.
+  a.prio = g_conv_prio >= 0 ? g_conv_prio : (g.G && (long long)mt * nt * nks >= 20LL * g.G ? 1 : 0);
+  conv_lpt_setup(a, BM, mt, nt, g.G);
+  if (g.G) DRS_LAUNCH((conv_dma_kernel<BM, BN, WM, WN, true>), dim3(g.G), dim3(256), 0, st, a);
   else DRS_LAUNCH((conv_dma_kernel<BM, BN, WM, WN, false>), dim3(mt * nt), dim3(256), 0, st, a);
   int rc = DRS_LAUNCH_CHECK();
-  if (rc || !W) return rc;
+  if (rc || !g.G) return rc;
   if (a.sk_U % W == 0 && (a.sk_U / W) % nks == 0) return rc;        // every range is a whole number of tiles: nothing to add up
-  DRS_LAUNCH((conv_sk_fixup_kernel<BM, BN, WM, WN>), dim3(mt * nt), dim3(256), 0, st, a);
+  DRS_LAUNCH((conv_sk_fixup_kernel<BM, BN, WM, WN>), dim3(g.T), dim3(256), 0, st, a);
   return DRS_LAUNCH_CHECK();
 }
 
@@ -1688,7 +1745,7 @@ int drs_debug_conv_order(int B, int S, int k, int rate, int pad_before, int cin,
   const int bn = pick_conv_tile(cout, cin);
   if (bn < 64) return 0;
   const int mt = (int)((M + 127) / 128), nt = cout / bn;
-  const int W = cin >= 32 ? sk_workgroups(mt * nt, k * k * (cin / 32), bn, drs_conv_workspace_floats(cout)) : 0;      // (a caller with the full workspace)
+  const int W = cin >= 32 ? sk_geometry(mt * nt, k * k * (cin / 32), bn, drs_conv_workspace_floats(cout)).G : 0;      // (a caller with the full workspace)
   conv_lpt_setup(a, 128, mt, nt, W);
   if (!a.lpt_T) return 0;
   for (int w = 0; w < mt * nt && w < cap; ++w) out[w] = lpt_tile(w, a.lpt_T, a.lpt_ta, a.lpt_tb, a.lpt_P, nt);
@@ -1697,6 +1754,16 @@ int drs_debug_conv_order(int B, int S, int k, int rate, int pad_before, int cin,
 int drs_debug_conv_trace(void* dev_buffer) { g_conv_trace = (unsigned long long*)dev_buffer; return 0; }
 
 int drs_debug_conv_splitk(int v) { const int old = g_conv_splitk; if (v >= -1) g_conv_splitk = v; return old; }
+int drs_debug_conv_hybrid(int v) { const int old = g_conv_hybrid; if (v >= 0) g_conv_hybrid = v; return old; }
+int drs_debug_conv_sk_order(int v) { const int old = g_conv_sk_order; if (v >= 0) g_conv_sk_order = v; return old; }
+int drs_debug_conv_prio(int v) { const int old = g_conv_prio; if (v >= -1) g_conv_prio = v; return old; }
+/* the stream-K geometry drs_conv_forward_ws takes for a launch of `tiles` tiles of nks K-steps, N tile bn, with the full workspace:
+   out3 = (workgroups, ranges, tiles that are cut); returns the workgroup count (0 = one workgroup per tile) */
+int drs_debug_conv_sk_geometry(int tiles, int nks, int bn, int* out3) {
+  const SkGeom g = sk_geometry(tiles, nks, bn, 2ull * (size_t)sk_max_w() * 128 * (size_t)bn);
+  if (out3) { out3[0] = g.G; out3[1] = g.W; out3[2] = g.T; }
+  return g.G;
+}
 
 int drs_debug_wgrad_variant(int v) { const int old = g_wgrad_variant; if (v >= -1) g_wgrad_variant = v; return old; }
 
@@ -1721,7 +1788,7 @@ int drs_conv_halo_skip(int B, int S, int k, int rate, int pad_before, int cin, i
   const int bn = pick_conv_tile(cout, cin);
   if (bn < 64) return a.skip_halo;
   const int mt = (int)((M + 127) / 128), nt = cout / bn;
-  const int W = sk_workgroups(mt * nt, k * k * (cin / 32), bn, drs_conv_workspace_floats(cout));
+  const int W = sk_geometry(mt * nt, k * k * (cin / 32), bn, drs_conv_workspace_floats(cout)).G;
   if (W) return 0;                                        // stream-K: every tile has the same number of K-steps
   conv_lpt_setup(a, 128, mt, nt, 0);
   return a.skip_halo;
@@ -1745,7 +1812,8 @@ int drs_conv_forward_ws(const float* in, int B, int S, int P, int ld_in, int cof
   a.k = k; a.rate = rate; a.pad = pad_before; a.Cin = cin; a.Cout = cout; a.accumulate = accumulate;
   a.rcpS = 1.0f / (float)S; a.rcpSS = 1.0f / (float)(S * S);
   a.skip_halo = drs_skip_halo_taps_fwd(M, cout);
-  a.sk_slab = nullptr; a.sk_W = 0; a.sk_nks = 0; a.sk_U = 0;
+  a.sk_slab = nullptr; a.sk_W = 0; a.sk_nks = 0; a.sk_U = 0; a.sk_T = a.sk_tiles = a.sk_G = a.sk_order = 0; a.prio = 0;
+  a.lpt_T = a.lpt_ta = a.lpt_tb = a.lpt_P = 0;
 #ifdef DRS_DEV
   a.trace = g_conv_trace;
 #endif

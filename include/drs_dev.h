@@ -20,11 +20,15 @@ int drs_debug_conv_lpt(int v);           /* plain forward / input-gradient launc
 int drs_debug_conv_order(int B, int S, int k, int rate, int pad_before, int cin, int cout, int* out, int cap);   /* out[w] = tile of logical workgroup w of that plain launch; returns the workgroup count, 0 = natural order */
 int drs_debug_conv_trace(void* dev_buffer); /* forward / input gradient (LDS-DMA form): device buffer [workgroups][2] of u64 that receives every workgroup's (start, end) on the 100 MHz real-time clock; NULL = off */
 int drs_debug_conv_splitk(int v);        /* split-K of the forward / input-gradient pass: -1 by the cost model (default), 0 never, n >= 1 that many ranges */
+int drs_debug_conv_hybrid(int v);        /* stream-K launches of more tiles than workgroups: 1 whole tiles for the full rounds, only the remainder cut (default), 0 every tile cut (r03) */
+int drs_debug_conv_sk_order(int v);      /* a hybrid workgroup does 0 its range first, 1 its whole tiles first (default), 2 alternating by workgroup slot */
+int drs_debug_conv_prio(int v);          /* forward / input gradient: waves lower their priority as their workgroup advances: -1 by the rule (stream-K launches from 20 K-steps per workgroup; default), 0 never, 1 always */
+int drs_debug_conv_sk_geometry(int tiles, int nks, int bn, int* out3);   /* (workgroups, ranges, cut tiles) of a stream-K launch with the full workspace; returns workgroups, 0 = plain */
 int drs_debug_wgrad_variant(int v);      /* filter gradient: 0 register-staged, 1 LDS-DMA halves, -1 per tile (default) */
 int drs_debug_wgrad_balance(int v);      /* 1 cut the pixel dimension by live pixels (default), 0 equal chunk ranges */
 int drs_debug_wgrad_target(int v);       /* workgroups the pixel split aims at (default 2048) */
 int drs_debug_wgrad_target_big(int v);   /* the same on launches with many tiles and pixels (0 = default rule) */
-int drs_debug_wgrad_len(int v);          /* chunks per workgroup the launches below the `big` class aim at (0 = default: 96, from 2^19 pixels 128) */
+int drs_debug_wgrad_len(int v);          /* chunks per workgroup the launches below the `big` class aim at (0 = default: 96, from 2^14 chunks 192) */
 int drs_debug_wgrad_minchunks(int v);    /* fewest 32-pixel chunks a split of the pixel dimension may have (default 8) */
 int drs_debug_wgrad_ablate(int v);       /* 1 = timing experiment (WRONG sums): every filter tap reads the un-shifted pixels (perfect X re-use); 2 = the S % 32 != 0 table reads of wgrad_dma_kernel right in front of each DMA issue, as before r04 (same sums); 3 = no wave priority by remaining work (same sums) */
 int drs_debug_wgrad_model(int v);        /* 1 per-CU cost model for the workgroup count of launches below the `big` class (default), 0 the r02 table */

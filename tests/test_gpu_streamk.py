@@ -77,6 +77,23 @@ def test_streamk_every_cut_matches_oracle(k, rate, cin, cout, B, S):
                      None, ws.data_ptr(), nws, st)
             torch.cuda.synchronize()
             assert rel_err(out.cpu().numpy()[:, 32:].reshape(B, S, S, cout), 2 * ref - bias.astype(np.float64)) < 1e-5, W
+            # r05: the forms of the launch that change no sum -- whole tiles for the full rounds (hybrid) with the range first / the whole
+            # tiles first / alternating, wave priority on or off -- agree bit for bit with each other; the r03 form that cuts every tile
+            # (hybrid off) associates differently and is held to the oracle
+            forms = {}
+            for hyb, order, prio in ((1, 0, 0), (1, 1, 1), (1, 2, 1), (0, 0, 1)):
+                lib.drs_debug_conv_hybrid(hyb); lib.drs_debug_conv_sk_order(order); lib.drs_debug_conv_prio(prio)
+                ws.fill_(float("nan"))
+                o3 = torch.full((M, cout + 32), -3.0, device=DEV)
+                s3 = torch.zeros(-(-M // mt) * cout * 2, device=DEV)
+                lib.call("drs_conv_forward_ws", xd.data_ptr(), B, S, P, cin, 0, wd.data_ptr(), bd.data_ptr(), k, rate, pb, cin, cout, o3.data_ptr(), cout + 32,
+                         32, 0, s3.data_ptr(), ws.data_ptr(), nws, st)
+                torch.cuda.synchronize()
+                assert rel_err(o3.cpu().numpy()[:, 32:].reshape(B, S, S, cout), ref) < 1e-5, (W, hyb, order, prio)
+                forms[(hyb, order, prio)] = (o3, s3)
+            lib.drs_debug_conv_hybrid(1); lib.drs_debug_conv_sk_order(1); lib.drs_debug_conv_prio(-1)
+            for key in ((1, 1, 1), (1, 2, 1)):
+                assert torch.equal(forms[key][0], forms[(1, 0, 0)][0]) and torch.equal(forms[key][1], forms[(1, 0, 0)][1]), (W, key)
             # repeatable bit for bit
             out2 = torch.full((M, cout + 32), -3.0, device=DEV)
             lib.call("drs_conv_forward_ws", xd.data_ptr(), B, S, P, cin, 0, wd.data_ptr(), bd.data_ptr(), k, rate, pb, cin, cout, out2.data_ptr(), cout + 32,
@@ -100,6 +117,30 @@ def test_streamk_every_cut_matches_oracle(k, rate, cin, cout, B, S):
         assert torch.equal(out, plain)
     finally:
         lib.drs_debug_conv_splitk(-1)
+        lib.drs_debug_conv_hybrid(1); lib.drs_debug_conv_sk_order(1); lib.drs_debug_conv_prio(-1)
+
+
+def test_hybrid_geometry_keeps_every_workgroup_equal():
+    """host side of the hybrid rule (sk_geometry): whole rounds of whole tiles + the remainder cut into one range per workgroup; no tile
+    lost or taken twice, K-steps per workgroup within one of each other plus at most one whole tile's round-off"""
+    import ctypes
+    from drs_amd import _lib
+    lib = _lib.dev()
+    g3 = (ctypes.c_int * 3)()
+    for bn in (64, 128, 192):
+        for tiles in list(range(1, 1200, 7)) + [767, 768, 769, 1058, 1408, 1808, 2047, 3000, 4095]:
+            for nks in (2, 16, 54, 72):
+                G = lib.drs_debug_conv_sk_geometry(tiles, nks, bn, g3)
+                if G == 0:
+                    continue
+                G, W, T = g3[0], g3[1], g3[2]
+                assert 1 <= W <= G <= 768 and 1 <= T <= tiles and W <= T * nks
+                assert W == min(G, T * nks)                          # a range for every workgroup (never an empty one)
+                if T < tiles:
+                    assert (tiles - T) % G == 0                      # whole rounds of whole tiles
+                U = T * nks
+                steps = [((w + 1) * U // W - w * U // W) for w in range(W)]
+                assert sum(steps) == U and max(steps) - min(steps) <= 1
 
 
 # conv8, conv3 (4x4, asymmetric padding), conv6 (one 192-wide tile), conv2 (64-wide tile) of Dilated8Pooling
