@@ -46,7 +46,8 @@ def load_numerics():
 
 # ------------------------------------------------------------------------------------------------ launch plumbing (no GPU, no torch)
 MARK = "DRS_BENCH_MARK"
-FALLBACK_ENV = {"torch": {"DRS_COMM": "torch"}, "async": {"DRS_COMM": "rccl", "DRS_RCCL_ASYNC": "1"}}
+FALLBACK_ENV = {"torch": {"DRS_COMM": "torch"}, "async": {"DRS_COMM": "rccl", "DRS_RCCL_ASYNC": "1"},
+                "buckets": {"DRS_COMM": "rccl", "DRS_RCCL_BUCKETS": "2", "DRS_RCCL_ASYNC": "0"}}
 
 
 def mark(stage, rank=None):
@@ -218,7 +219,10 @@ def supervise(argv):
         rc, out, stage, lim = _run_watched([sys.executable, os.path.abspath(__file__)] + argv, env, limit, rendezvous_slack=1.0 if i == 0 else 2.5)
         if rc == 0:
             # stdout carries the ONE JSON line (rank 0's) and nothing else: whatever a library printed to the child's descriptor 1 goes to stderr
-            for ln in out.splitlines():
+            lines = out.splitlines()
+            if label == "default" and os.environ.get("DRS_BENCH_SECOND_PASS", "1") != "0":
+                lines = _second_pass(argv, port0, lines)
+            for ln in lines:
                 (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln + "\n")
             sys.stdout.flush()
             return 0
@@ -232,6 +236,50 @@ def supervise(argv):
         # the launcher tears every rank down as soon as ONE exits non-zero: let rank 0's line get out first
         time.sleep(float(os.environ.get("DRS_BENCH_FAIL_LINGER_S", "5")))
     return 1
+
+
+def _second_pass(argv, port0, first_lines):
+    """After a default run that WORKED (library-side RCCL, inline form) every supervisor starts one more fresh measuring process with
+    DRS_RCCL_BUCKETS=2 -- the inline form with the gradient buffer as two overlapped all-reduces on a side stream -- so that the one
+    multi-GPU lease a round gets returns both numbers.  Its line goes INTO the first line (`extra.second_pass`); whatever happens to
+    it (a hang is cut after DRS_BENCH_SECOND_PASS_LIMIT_S of silence, default 120) the first line stands as it is.  The headline
+    `value` is never replaced."""
+    env = dict(os.environ)
+    env.update(FALLBACK_ENV["buckets"])
+    env.update(DRS_BENCH_CHILD="1", DRS_BENCH_ATTEMPT="buckets", DRS_BENCH_FALLBACK_REASON="", DRS_BENCH_IS_SECOND_PASS="1",
+               MASTER_PORT=str(_fallback_port(port0, 7)), TORCHELASTIC_USE_AGENT_STORE="False")
+    limit = float(os.environ.get("DRS_BENCH_SECOND_PASS_LIMIT_S", "120"))
+    rc, out, stage, lim = _run_watched([sys.executable, os.path.abspath(__file__)] + argv + ["--no-cpu-baseline", "--no-opt-in", "--no-size-table"],
+                                       env, limit, rendezvous_slack=1.5)
+    if os.environ.get("RANK", "0") != "0":
+        return first_lines
+    res = None
+    if rc == 0:
+        for ln in out.splitlines():
+            if ln.lstrip().startswith("{"):
+                try:
+                    d = json.loads(ln)
+                    res = {k: d.get(k) for k in ("value", "unit", "ms_per_step", "median_step_ms", "steps", "warmup", "config", "kernels", "final_loss")}
+                    res["per_rank_ms"] = (d.get("extra") or {}).get("per_rank_ms")
+                except ValueError:
+                    pass
+    if res is None:
+        res = {"error": ("timeout: silent for %.0f s after stage '%s'" % (lim, stage)) if rc is None else ("exit code %s after stage '%s'" % (rc, stage))}
+    res["note"] = "second timed pass of the same command with DRS_RCCL_BUCKETS=2 (a fresh process per rank); never the headline value"
+    merged = []
+    for ln in first_lines:
+        if ln.lstrip().startswith("{"):
+            try:
+                d = json.loads(ln)
+                d.setdefault("extra", {})
+                if d["extra"] is None:
+                    d["extra"] = {}
+                d["extra"]["second_pass"] = res
+                ln = json.dumps(d)
+            except ValueError:
+                pass
+        merged.append(ln)
+    return merged
 
 
 def failure_line(error):
@@ -291,7 +339,7 @@ def selftest_worker(args):
         os.write(json_fd, (json.dumps({"metric": "selftest", "value": 1.0, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "config": {"collectives": collectives_label("selftest"), "fallback_reason": os.environ.get("DRS_BENCH_FALLBACK_REASON") or None,
                                      "ranks_observed": int(ones.item()) if ones is not None else 1,
-                                     "env": {k: os.environ.get(k) for k in ("DRS_COMM", "DRS_RCCL_ASYNC", "MASTER_PORT")}}}) + "\n").encode())
+                                     "env": {k: os.environ.get(k) for k in ("DRS_COMM", "DRS_RCCL_ASYNC", "DRS_RCCL_BUCKETS", "MASTER_PORT")}}}) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
     return 0
@@ -467,7 +515,7 @@ def executed_fraction(plan, B, S):
     return live / tot
 
 
-def per_rank_size_table(dev, pool, mean, std, sizes=(25, 35, 45, 55, 65, 75, 85), B=16, steps=8):
+def per_rank_size_table(dev, pool, mean, std, sizes=(25, 35, 45, 55, 64, 65, 75, 85), B=16, steps=8):
     """what one rank of the 8-GPU run of BASELINE configs[2] sees (batch 128 / 8 = 16 patches, `uniform` over [25, 85],
     isprs:1727-1737): ms per step and the convolution families' share of the fp32 MFMA roof, per patch side (N = 1 only, outside
     the timed region).  `weighted_patches_per_s` = sizes drawn uniformly: patches / summed step time."""
@@ -475,7 +523,7 @@ def per_rank_size_table(dev, pool, mean, std, sizes=(25, 35, 45, 55, 65, 75, 85)
     from drs_amd import patches as P
     from drs_amd.synthetic import grid_instances
     net = DilatedNet(NET, CHANNELS, CLASSES, WD, b_max=B, s_max=max(sizes), device=dev, seed=42)
-    rows_out, tot = [], 0.0
+    rows_out, tot, headline = [], 0.0, None
     for S in sizes:
         inst = grid_instances(TILE, TILE, S, 25, 2048, seed=S)
 
@@ -503,12 +551,19 @@ def per_rank_size_table(dev, pool, mean, std, sizes=(25, 35, 45, 55, 65, 75, 85)
         fd = [summ[k] for k in ("conv_fwd", "conv_dgrad") if k in summ]
         fd_tf = sum(d["work"] for d in fd) / (sum(d["ms"] for d in fd) * 1e-3) / 1e12
         wg_tf = summ["conv_wgrad"]["work"] / (summ["conv_wgrad"]["ms"] * 1e-3) / 1e12
-        rows_out.append(dict(S=S, ms_per_step=round(dt * 1e3, 3), patches_per_s=round(B / dt, 1),
-                             fwd_dgrad_frac=round(fd_tf / PEAK_FP32_MFMA_TFLOPS, 3), wgrad_frac=round(wg_tf / PEAK_FP32_MFMA_TFLOPS, 3)))
+        row = dict(S=S, ms_per_step=round(dt * 1e3, 3), patches_per_s=round(B / dt, 1),
+                   fwd_dgrad_frac=round(fd_tf / PEAK_FP32_MFMA_TFLOPS, 3), wgrad_frac=round(wg_tf / PEAK_FP32_MFMA_TFLOPS, 3))
+        if S == PATCH:
+            # one rank of the 8-GPU run of the HEADLINE (128 / 8 patches of 64 x 64): every family's ms per step, so that the driver's
+            # 8-GPU line (whose own `kernels` are rank 0's at this batch) can be held against what one GPU alone does at that batch
+            headline = dict(row, kernels_ms={k: round(d["ms"] / 3, 4) for k, d in sorted(summ.items())},
+                            ideal_speedup_before_wire=None)
+            continue          # (not a size configs[2] draws from: not part of the weighted figure)
+        rows_out.append(row)
         tot += dt
     del net
     torch.cuda.empty_cache()
-    return dict(local_batch=B, rows=rows_out, weighted_patches_per_s=round(B * len(sizes) / tot, 1),
+    return dict(local_batch=B, rows=rows_out, weighted_patches_per_s=round(B * len(rows_out) / tot, 1), headline_shape=headline,
                 note="one rank's step at the per-rank batch of an 8-GPU run, no collectives; stream-K convolutions below 4096 tiles")
 
 
@@ -642,7 +697,15 @@ def main():
         kernels = {}
         for kind, d in sorted(summ.items()):
             avg_ms = d["ms"] / d["launches"]
-            if kind.startswith("conv_"):
+            if kind.startswith("allreduce_"):
+                # the step's collectives, timed on the stream each is issued on (engine.hip K_AR_*): `work` = bytes.  At N = 1 they only
+                # exist with DRS_FORCE_COLLECTIVES=1 (identities: what issuing them costs a rank); at N > 1 this is the wire + latency
+                # time the ranks really paid, the figure that says where a scaling loss went
+                per_step = d["launches"] // 3
+                kernels[kind] = dict(bound="xgmi", calls_per_step=per_step, avg_us=round(1e3 * avg_ms, 2), ms_per_step=round(d["ms"] / 3, 4),
+                                     bytes_per_call=int(d["work"] / d["launches"]),
+                                     algbw_gbs=round(d["work"] / (d["ms"] * 1e-3) / 1e9, 2))
+            elif kind.startswith("conv_"):
                 ach = d["work"] / (d["ms"] * 1e-3) / 1e12
                 kernels[kind] = dict(bound="mfma", launches_per_step=d["launches"] // 3, avg_ms=round(avg_ms, 4),
                                      achieved=round(ach, 2), peak=ar["peak"], unit="TFLOP/s", frac=round(ach / ar["peak"], 4))
@@ -760,6 +823,14 @@ def main():
                       "step_ms_events": dict(median=round(step_ms[len(step_ms) // 2], 3), min=round(step_ms[0], 3), max=round(step_ms[-1], 3),
                                              note="HIP events between consecutive steps on rank 0's launch stream; `value` stays steps / wall time")},
         }
+        if size_table and size_table.get("headline_shape"):
+            hs = size_table["headline_shape"]
+            hs["ideal_speedup_before_wire"] = round(line["ms_per_step"] / hs["ms_per_step"], 3)
+            hs["note"] = ("one rank's step of the 8-GPU run of this headline (16 patches of 64 x 64, no collectives) against the 1-GPU step "
+                          "above: what 8 ranks could reach before any wire time")
+        if world > 1 or forced:
+            line["extra"]["per_rank_kernels_note"] = ("`kernels` are rank 0's families at the per-rank batch %d, the allreduce_* rows its "
+                                                      "collectives (HIP events on the stream each is issued on)" % B_local)
         os.write(json_fd, (json.dumps(line) + "\n").encode())
         mark("json written")
     if comm:

@@ -79,6 +79,7 @@ SIGNATURES = {
     "drs_net_learning_rate": (_f, [_p, _f]),
     "drs_net_set_comm": (_i, [_p, _i, _i, _p, _p, _p]),
     "drs_rccl_available": (_i, []),
+    "drs_rccl_form": (_i, []),
     "drs_rccl_unique_id": (_i, [_p]),
     "drs_rccl_comm_create": (_i, [_i, _i, _p, C.POINTER(_p)]),
     "drs_rccl_comm_destroy": (_i, [_p]),

@@ -120,10 +120,13 @@ struct Var { std::string name; size_t off, n; int nd, shape[4]; int where; };   
 struct Buf { std::string name; size_t bytes; int dtype; void* ptr; };           // dtype: 0 f32, 1 f64, 2 u8, 3 i32
 enum { F32 = 0, F64 = 1, U8 = 2, I32 = 3 };
 
+// (the three all-reduce kinds: `work` = bytes; timed on the stream the sum is issued on, so that ONE multi-GPU run says where its
+//  step went -- 16 latency-bound sync-BN sums, the gradient buffer, the loss / confusion-matrix scalars)
 enum Kind { K_CONV_FWD, K_CONV_DGRAD, K_CONV_WGRAD, K_BN_FWD, K_BN_BWD_REDUCE, K_BN_BWD_APPLY, K_CLS, K_MOMENTUM, K_SE_FWD, K_SE_BWD,
-            K_AVG_FWD, K_AVG_BWD, K_NKIND };
+            K_AVG_FWD, K_AVG_BWD, K_AR_SYNCBN, K_AR_GRAD, K_AR_SCALARS, K_NKIND };
 const char* const kKindNames[K_NKIND] = {"conv_fwd", "conv_dgrad", "conv_wgrad", "bn_act_pool_fwd", "bn_bwd_reduce", "bn_bwd_apply",
-                                         "classifier_loss", "momentum_update", "se_fwd", "se_bwd", "avg_pool_fwd", "avg_pool_bwd"};
+                                         "classifier_loss", "momentum_update", "se_fwd", "se_bwd", "avg_pool_fwd", "avg_pool_bwd",
+                                         "allreduce_syncbn", "allreduce_grad", "allreduce_scalars"};
 struct TimeRec { int kind; double work; hipEvent_t e0, e1; };
 
 }  // namespace
@@ -155,6 +158,8 @@ struct drs_net {
   hipStream_t comm_stream, small_stream;
   bool own_comm_stream;
   bool rccl_inline;                         // (default) one communicator, every sum on the compute stream itself in program order; DRS_RCCL_ASYNC=1: side streams
+  bool rccl_buckets;                        // inline form + the gradient buffer as TWO all-reduces on comm_big's stream, the first under the rest of the backward pass (DRS_RCCL_BUCKETS=2)
+  hipEvent_t ev_bucket[3];                  // the three hand-overs of that form
   std::vector<hipEvent_t> comm_events;      // ring: [2 h] = data ready on the compute stream, [2 h + 1] = sum done on the side stream
   int comm_next, comm_ring, comm_in_flight; // ring size (from the number of blocks), asynchronous sums issued since the last wait_handles
   // backward pass of small steps: the filter gradients on a stream of their own beside the batch-norm-backward -> input-gradient
@@ -407,9 +412,16 @@ constexpr size_t SMALL_BYTES = 16384;     // sums up to here go to the small com
 // `big_only`: an asynchronous sum that must not touch the small communicator whatever its size (two-stream backward pass: the
 // small communicator is then driven from the compute stream alone, so every asynchronous sum goes to the big one's stream --
 // one communicator is never driven from two streams that no event orders)
-int all_reduce(drs_net* n, void* ptr, size_t count, int dtype, int async, hipStream_t st, int* handle, bool big_only = false) {
+int all_reduce_impl(drs_net* n, void* ptr, size_t count, int dtype, int async, hipStream_t st, int* handle, bool big_only);
+int all_reduce(drs_net* n, int kind, void* ptr, size_t count, int dtype, int async, hipStream_t st, int* handle, bool big_only = false) {
+  static const size_t esz[4] = {4, 8, 1, 4};
   if (handle) *handle = -1;
   if (!collectives(n)) return DRS_OK;
+  Timed t(n, st, kind, (double)(count * esz[dtype]));
+  return all_reduce_impl(n, ptr, count, dtype, async, st, handle, big_only);
+}
+
+int all_reduce_impl(drs_net* n, void* ptr, size_t count, int dtype, int async, hipStream_t st, int* handle, bool big_only) {
   if (n->rccl_small) {
     static const size_t esz[4] = {4, 8, 1, 4};
     if (n->rccl_inline) return drs_rccl_all_reduce_sum(n->rccl_small, ptr, count, dtype, st);
@@ -481,7 +493,7 @@ int forward_layers(drs_net* n, int B, int S, bool training, double count, hipStr
       DRS_TRY(drs_conv_stats_finish(partial, (int)M, drs_conv_mtile(L.cout), L.cout, count, mr, mm, mv, BN_DECAY, n->bessel, nullptr, st));
     } else if (training) {
       DRS_TRY(drs_conv_stats_reduce(partial, (int)M, drs_conv_mtile(L.cout), L.cout, sums, nullptr, st));
-      DRS_TRY(all_reduce(n, sums, 2 * (size_t)L.cout, F64, 0, st, nullptr));          // sync batch norm over the global batch
+      DRS_TRY(all_reduce(n, K_AR_SYNCBN, sums, 2 * (size_t)L.cout, F64, 0, st, nullptr));          // sync batch norm over the global batch
       // (a plain pooled block: the kernel that normalises works mean / rstd / moving averages out of the sums itself, below)
       fold_finish = L.pool == 1 && L.se < 0 && L.cout <= 512;
       if (!fold_finish) DRS_TRY(drs_bn_finish(sums, count, L.cout, mr, mm, mv, BN_DECAY, n->bessel, st));
@@ -553,7 +565,8 @@ int drs_net_create(const char* net_type, int channels, int num_classes, float we
     n->bessel = bessel_moving_var ? 1 : 0; n->lr_decay = lr_decay_factor; n->global_step = 0;
     n->world = 1; n->rank = 0; n->allreduce = nullptr; n->wait = nullptr; n->comm_user = nullptr; n->timing = false;
     n->rccl_small = n->rccl_big = nullptr; n->comm_stream = n->small_stream = nullptr; n->own_comm_stream = false; n->comm_next = 0;
-    n->rccl_inline = false; n->comm_ring = 0; n->comm_in_flight = 0;
+    n->rccl_inline = false; n->rccl_buckets = false; n->comm_ring = 0; n->comm_in_flight = 0;
+    for (auto& e : n->ev_bucket) e = nullptr;
     n->wg_stream = nullptr;
     { const char* e = std::getenv("DRS_TWO_STREAMS"); n->two_stream_mode = e ? std::atoi(e) : -1; }
     build_plan(n);
@@ -576,6 +589,8 @@ static void release_rccl(drs_net* n) {
   n->own_comm_stream = false;
   n->rccl_small = n->rccl_big = nullptr;
   n->rccl_inline = false;
+  n->rccl_buckets = false;
+  for (auto& e : n->ev_bucket) { if (e) (void)hipEventDestroy(e); e = nullptr; }
   n->comm_in_flight = 0;
 }
 
@@ -768,17 +783,39 @@ int drs_net_set_comm(drs_net_t* n, int world, int rank, drs_allreduce_fn allredu
 // hand-overs (~25 of them a step), which is about what overlapping 8 MB of gradient buckets and eight 2 KB sums could save on 8 GPUs.
 // DRS_RCCL_ASYNC=1 in the environment (read here) selects that form: backward sync-BN sums on a side stream under the filter
 // gradient of the block above, gradient buckets on comm_big's stream as the layers finish.
+// The form of the library-side collectives, read from the environment in ONE place (the host asks before it makes communicators, so
+// that it makes as many as the library will use and labels its run with what really runs): DRS_RCCL_ASYNC != 0 -> asynchronous
+// (two communicators); else DRS_RCCL_BUCKETS >= 2 -> inline + two overlapped gradient buckets (two communicators); else inline (one).
+int drs_rccl_form(void) {
+  const char* a = std::getenv("DRS_RCCL_ASYNC");
+  if (a && std::atoi(a) != 0) return DRS_RCCL_FORM_ASYNC;
+  const char* b = std::getenv("DRS_RCCL_BUCKETS");
+  if (b && std::atoi(b) >= 2) return DRS_RCCL_FORM_BUCKETS;
+  return DRS_RCCL_FORM_INLINE;
+}
+
 static int set_rccl_impl(drs_net_t* n, int world, int rank, void* comm_small, void* comm_big, void* comm_stream) {
   if (!n || world < 1 || rank < 0 || rank >= world) return DRS_ERR_ARG;
   const bool had = n->rccl_small != nullptr;
   release_rccl(n);
   if (!comm_small) { if (had) { n->world = 1; n->rank = 0; } return DRS_OK; }
   if (!drs_rccl_available()) return DRS_ERR_ARG;
-  { const char* e = std::getenv("DRS_RCCL_ASYNC"); n->rccl_inline = !(e && std::atoi(e) != 0); }
-  if (n->rccl_inline) comm_big = nullptr;
+  const int form = drs_rccl_form();
+  n->rccl_inline = form != DRS_RCCL_FORM_ASYNC;
+  n->rccl_buckets = form == DRS_RCCL_FORM_BUCKETS && comm_big != nullptr;
+  if (n->rccl_inline && !n->rccl_buckets) comm_big = nullptr;
   // asynchronous sums in flight between two waits: one per block (backward sync-BN) + one per two blocks (gradient buckets) + 4
   n->comm_ring = std::max(64, 2 * (int)n->layers.size() + 8);
   n->comm_in_flight = 0;
+  if (n->rccl_buckets) {      // one side stream for the two gradient buckets, three events
+    for (auto& e : n->ev_bucket)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return DRS_ERR_HIP;
+    if (comm_stream) { n->comm_stream = (hipStream_t)comm_stream; n->own_comm_stream = false; }
+    else {
+      if (hipStreamCreateWithFlags(&n->comm_stream, hipStreamNonBlocking) != hipSuccess) return DRS_ERR_HIP;
+      n->own_comm_stream = true;
+    }
+  }
   if (!n->rccl_inline) {      // (the inline form needs no stream and no event of its own)
     n->comm_events.resize(2 * (size_t)n->comm_ring);
     for (auto& e : n->comm_events)
@@ -872,6 +909,7 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
   const long long M = (long long)B * S * S;
   const double n_bn = (double)M * n->world;
   const double n_glob = global_pixels > 0 ? global_pixels : n_bn;
+  n->comm_in_flight = 0;      // (a step that failed midway must not leave the next one short of event slots)
   DRS_TRY(forward_layers(n, B, S, true, n_bn, st));
   float* params = n->p<float>("params");
   float* grads = n->p<float>("grads");
@@ -943,6 +981,24 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     if (!ok) return DRS_ERR_HIP;
   }
   hipStream_t ws = two ? n->wg_stream : st;       // the stream the filter gradients run on
+  // DRS_RCCL_BUCKETS=2 (opt-in until an 8-GPU A/B exists): the gradient buffer as two all-reduces on a side stream with a communicator
+  // of its own; everything else as in the inline form
+  const bool buckets = inline_comm && n->rccl_buckets && n->rccl_big;
+  bool bucket_sent = false;
+  size_t bucket_lo = 0;
+  int bucket_layer = 0;
+  if (buckets) {
+    size_t total = 0, acc = 0;
+    for (int i = 0; i < nL; ++i) total += (size_t)n->layers[i].k * n->layers[i].k * n->layers[i].cin * n->layers[i].cout;
+    for (int i = nL - 1; i >= 0; --i) {
+      acc += (size_t)n->layers[i].k * n->layers[i].k * n->layers[i].cin * n->layers[i].cout;
+      if (10 * acc >= 7 * total) { bucket_layer = i; break; }
+    }
+  }
+  auto bucket_sum = [&](float* ptr, size_t cnt) -> int {
+    Timed t(n, n->comm_stream, K_AR_GRAD, 4.0 * (double)cnt);
+    return drs_rccl_all_reduce_sum(n->rccl_big, ptr, cnt, F32, n->comm_stream);
+  };
 
   auto filter_gradient = [&](int i) -> int {
     const Layer& L = n->layers[i];
@@ -955,11 +1011,19 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     }
     if (collectives(n) && !inline_comm && i > 0 && (nL - i) % 2 == 0) {      // every second layer: one bucket
       int h;
-      DRS_TRY(all_reduce(n, grads + L.w_off, bucket_hi - L.w_off, F32, 1, ws, &h, two));
+      DRS_TRY(all_reduce(n, K_AR_GRAD, grads + L.w_off, bucket_hi - L.w_off, F32, 1, ws, &h, two));
       pending.push_back(h);
       bucket_hi = L.w_off;
     }
     if (two && hipEventRecord(n->ev_wg[i & 1], ws) != hipSuccess) return DRS_ERR_HIP;             // this gz slab may be rewritten
+    if (buckets && i == bucket_layer && i > 0) {
+      // first bucket: the kernels of blocks bucket_layer .. last (Dilated8Pooling: conv5 .. conv8, 76 % of the gradient bytes), summed on the
+      // big communicator's stream while blocks bucket_layer-1 .. 0 are still in their backward pass
+      if (hipEventRecord(n->ev_bucket[0], ws) != hipSuccess || hipStreamWaitEvent(n->comm_stream, n->ev_bucket[0], 0) != hipSuccess) return DRS_ERR_HIP;
+      DRS_TRY(bucket_sum(grads + L.w_off, n->cls_w - L.w_off));
+      bucket_sent = true;
+      bucket_lo = L.w_off;
+    }
     return DRS_OK;
   };
 
@@ -998,7 +1062,7 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     // (two streams: the filter gradient runs beside this chain anyway, so the sum goes on this stream itself -- no event hand-over
     // on the critical path, and the small communicator is then driven from this stream only, forward and backward)
     int h_bn;
-    DRS_TRY(all_reduce(n, sums, 2 * (size_t)L.cout, F64, two ? 0 : 1, st, &h_bn));
+    DRS_TRY(all_reduce(n, K_AR_SYNCBN, sums, 2 * (size_t)L.cout, F64, two ? 0 : 1, st, &h_bn));
     if (deferred >= 0) DRS_TRY(filter_gradient(deferred));
     DRS_TRY(wait_handles(n, {h_bn}, st));
     float* gz = gzb[two ? (i & 1) : 0];
@@ -1025,23 +1089,33 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     if (nL > 1 && hipStreamWaitEvent(st, n->ev_wg[1], 0) != hipSuccess) return DRS_ERR_HIP;
   }
   if (inline_comm) {      // one all-reduce of the whole flat gradient buffer, then the loss and the confusion matrix, in program order
-    DRS_TRY(all_reduce(n, grads, n->n_params, F32, 0, st, nullptr));
-    DRS_TRY(all_reduce(n, scalars, 1, F64, 0, st, nullptr));
-    DRS_TRY(all_reduce(n, conf, (size_t)n->K * n->K, I32, 0, st, nullptr));
+    if (buckets) {
+      // second bucket: the earlier layers' kernels and the classifier / SE / bias tail, behind the first on the big communicator's
+      // stream; then ONE wait.  Three event hand-overs a step in all (the asynchronous form of r03 had ~25).
+      if (hipEventRecord(n->ev_bucket[1], st) != hipSuccess || hipStreamWaitEvent(n->comm_stream, n->ev_bucket[1], 0) != hipSuccess) return DRS_ERR_HIP;
+      if (!bucket_sent) DRS_TRY(bucket_sum(grads, n->cls_w));
+      else if (bucket_lo > 0) DRS_TRY(bucket_sum(grads, bucket_lo));
+      DRS_TRY(bucket_sum(grads + n->cls_w, n->n_params - n->cls_w));
+      if (hipEventRecord(n->ev_bucket[2], n->comm_stream) != hipSuccess || hipStreamWaitEvent(st, n->ev_bucket[2], 0) != hipSuccess) return DRS_ERR_HIP;
+    } else {
+      DRS_TRY(all_reduce(n, K_AR_GRAD, grads, n->n_params, F32, 0, st, nullptr));
+    }
+    DRS_TRY(all_reduce(n, K_AR_SCALARS, scalars, 1, F64, 0, st, nullptr));
+    DRS_TRY(all_reduce(n, K_AR_SCALARS, conf, (size_t)n->K * n->K, I32, 0, st, nullptr));
   } else if (collectives(n)) {
     int h;
-    DRS_TRY(all_reduce(n, grads, bucket_hi, F32, 1, st, &h, two));                         // the remaining (earliest) layers
+    DRS_TRY(all_reduce(n, K_AR_GRAD, grads, bucket_hi, F32, 1, st, &h, two));                         // the remaining (earliest) layers
     pending.push_back(h);
-    DRS_TRY(all_reduce(n, grads + n->cls_w, n->n_params - n->cls_w, F32, 1, st, &h, two)); // classifier, SE layers and every bias (small)
+    DRS_TRY(all_reduce(n, K_AR_GRAD, grads + n->cls_w, n->n_params - n->cls_w, F32, 1, st, &h, two)); // classifier, SE layers and every bias (small)
     pending.push_back(h);
     // (library-side RCCL: one communicator is never driven from two streams that no event orders.  One-stream backward pass: the
     // backward phase's small sums all go through the small communicator's side stream, in order.  Two-stream backward pass: the
     // small communicator is driven from the compute stream alone -- the backward sync-BN sums above, these two -- and every
     // asynchronous sum, the small tail bucket included, went to the big communicator's stream: `big_only`.)
     const int side = (n->rccl_small && !two) ? 1 : 0;
-    DRS_TRY(all_reduce(n, scalars, 1, F64, side, st, &h));
+    DRS_TRY(all_reduce(n, K_AR_SCALARS, scalars, 1, F64, side, st, &h));
     pending.push_back(h);
-    DRS_TRY(all_reduce(n, conf, (size_t)n->K * n->K, I32, side, st, &h));
+    DRS_TRY(all_reduce(n, K_AR_SCALARS, conf, (size_t)n->K * n->K, I32, side, st, &h));
     pending.push_back(h);
     DRS_TRY(wait_handles(n, pending, st));
   }

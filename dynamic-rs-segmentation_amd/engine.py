@@ -17,6 +17,31 @@ from .net import DilatedNet, KernelTimer
 _DTYPES = {0: torch.float32, 1: torch.float64, 2: torch.uint8, 3: torch.int32}
 
 
+RCCL_FORM_LABELS = {1: "rccl (inline: one communicator on the compute stream)", 2: "rccl (asynchronous: DRS_RCCL_ASYNC)",
+                    3: "rccl (inline + two overlapped gradient buckets: DRS_RCCL_BUCKETS)"}
+
+
+def call_with_timeout(fn, seconds, what):
+    """run fn() in a helper thread; its result, or its exception re-raised here, or DrsError after `seconds` without a return (the
+    thread is left behind as a daemon: the call it is stuck in cannot be cancelled)"""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["value"] = fn()
+        except BaseException as e:       # handed to the caller's thread
+            box["error"] = e
+    t = threading.Thread(target=run, daemon=True, name="drs-timeout-call")
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        raise _lib.DrsError("%s did not return within %.0f s" % (what, seconds))
+    if "error" in box:
+        raise box["error"]
+    return box.get("value")
+
+
 class EngineTimer(KernelTimer):
     """bench.py's per-kernel-family figures, measured by the library (HIP events around its launches)."""
 
@@ -123,9 +148,11 @@ class EngineNet(DilatedNet):
             # the choice of path is itself collective: every rank takes the callback unless every rank holds two working communicators
             ok = self.comm.all_true(err is None)
             if ok:
+                # the form is the LIBRARY's reading of the environment (drs_rccl_form: one parser); the label says what really runs
+                form = getattr(self, "_rccl_form", 1 if len(self._rccl) == 1 else 2)
                 single = len(self._rccl) == 1
                 _lib.call("drs_net_set_rccl", self.h, self.comm.world, self.comm.rank, self._rccl[0], None if single else self._rccl[1], None)
-                self.collectives = "rccl (inline: one communicator on the compute stream)" if single else "rccl (asynchronous: DRS_RCCL_ASYNC)"
+                self.collectives = RCCL_FORM_LABELS[1 if single else form]
                 return
             if os.environ.get("DRS_COMM") == "rccl":
                 raise err or _lib.DrsError("library-side RCCL collectives failed on another rank")
@@ -135,9 +162,11 @@ class EngineNet(DilatedNet):
 
     def _install_rccl(self):
         import os
-        # one communicator, driven from the compute stream alone (the library's default, inline form); DRS_RCCL_ASYNC=1: a small
-        # (latency-bound sums) and a big (gradient buckets) one for the asynchronous form (the library reads the same variable)
-        ncomm = 2 if os.environ.get("DRS_RCCL_ASYNC", "0") not in ("", "0") else 1
+        # one communicator, driven from the compute stream alone (the library's default, inline form); DRS_RCCL_ASYNC=1 or
+        # DRS_RCCL_BUCKETS=2: a small (latency-bound sums) and a big (gradient buckets) one.  The library parses the variables
+        # (drs_rccl_form); this side only asks, so that host and library cannot read them differently.
+        self._rccl_form = int(_lib.query("drs_rccl_form"))
+        ncomm = 1 if self._rccl_form == 1 else 2
         ok, payload = True, []
         if self.comm.rank == 0:
             try:
@@ -153,9 +182,18 @@ class EngineNet(DilatedNet):
         ids = payload
         torch.cuda.set_device(self.dev)
         self._rccl = []
+        # ncclCommInitRank is collective: a rank that fails BEFORE it gets there (or inside it) leaves the others waiting in it for good,
+        # and nothing above this call would ever run again (outside bench.py no watchdog exists).  So the call runs in a helper thread
+        # under a rank-local limit; a rank whose call does not return in time raises here, reaches the collective "did it work
+        # everywhere?" question of _install_comm with a no, and every rank takes the callback path together.  (The thread that is
+        # still inside RCCL is a daemon: it goes with the process.)
+        limit = float(os.environ.get("DRS_RCCL_INIT_TIMEOUT_S", "90"))
         for raw in ids:
             h = C.c_void_p()
-            _lib.call("drs_rccl_comm_create", self.comm.world, self.comm.rank, (C.c_ubyte * 128).from_buffer_copy(raw), C.byref(h))
+            def create(raw=raw, h=h):
+                torch.cuda.set_device(self.dev)      # (the current device is per thread)
+                _lib.call("drs_rccl_comm_create", self.comm.world, self.comm.rank, (C.c_ubyte * 128).from_buffer_copy(raw), C.byref(h))
+            call_with_timeout(create, limit, "drs_rccl_comm_create (ncclCommInitRank, world %d, rank %d)" % (self.comm.world, self.comm.rank))
             self._rccl.append(h)
         # known-answer check of both communicators through the call the step engine issues, in each of its three types
         W, r = self.comm.world, self.comm.rank

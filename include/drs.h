@@ -339,6 +339,10 @@ int drs_net_set_comm(drs_net_t* net, int world, int rank, drs_allreduce_fn allre
  *   drs_rccl_comm_create / _destroy : ncclCommInitRank / ncclCommDestroy (collective over the ranks; the device must be current).
  *   drs_rccl_all_reduce : one in-place sum over the ranks on `stream` (dtype as in drs_net_buffer_info: 0 f32, 1 f64, 3 i32) -- the
  *                         call the step engine issues; the host uses it to check a new communicator before handing it over. */
+#define DRS_RCCL_FORM_INLINE 1    /* one communicator, every sum on the compute stream in program order (default) */
+#define DRS_RCCL_FORM_ASYNC 2     /* DRS_RCCL_ASYNC != 0: two communicators, side streams, an event hand-over per asynchronous sum (r03) */
+#define DRS_RCCL_FORM_BUCKETS 3   /* DRS_RCCL_BUCKETS >= 2: inline + the gradient buffer as two all-reduces on comm_big's stream, the first under the rest of the backward pass */
+int drs_rccl_form(void);          /* the form drs_net_set_rccl will take, from the environment (the one place that parses it); ASYNC and BUCKETS want comm_big */
 int drs_rccl_available(void);
 int drs_rccl_unique_id(unsigned char* id128);
 int drs_rccl_comm_create(int world, int rank, const unsigned char* id128, void** comm);

@@ -34,6 +34,24 @@ def test_plain_launch_starts_the_launcher_itself(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["ranks_observed"] == 2
     assert d["config"]["collectives"] == "selftest" and d["config"]["fallback_reason"] is None
     assert "stage=warm-up done" in err
+    # r05: a default run that worked is followed by ONE more fresh measuring process per rank with DRS_RCCL_BUCKETS=2; its line rides
+    # inside the first one and never replaces its value
+    sp = d["extra"]["second_pass"]
+    assert sp["config"]["env"]["DRS_RCCL_BUCKETS"] == "2" and sp["config"]["env"]["DRS_COMM"] == "rccl" and sp["config"]["ranks_observed"] == 2
+    assert sp["value"] == 1.0 and d["config"]["env"]["DRS_RCCL_BUCKETS"] is None
+
+
+def test_a_second_pass_that_dies_or_hangs_leaves_the_first_line_standing(tmp_path):
+    rc, lines, err = _run([sys.executable, BENCH, "--gpus", "2"], tmp_path, DRS_BENCH_FAKE_CRASH="buckets")
+    assert rc == 0, err
+    d = json.loads(lines[-1])
+    assert len(lines) == 1 and d["value"] == 1.0 and "exit code 7" in d["extra"]["second_pass"]["error"]
+    rc, lines, err = _run([sys.executable, BENCH, "--gpus", "2"], tmp_path, DRS_BENCH_FAKE_HANG="buckets", DRS_BENCH_SECOND_PASS_LIMIT_S="4")
+    assert rc == 0, err
+    d = json.loads(lines[-1])
+    assert len(lines) == 1 and d["value"] == 1.0 and "timeout" in d["extra"]["second_pass"]["error"]
+    rc, lines, err = _run([sys.executable, BENCH, "--gpus", "2"], tmp_path, DRS_BENCH_SECOND_PASS="0")
+    assert rc == 0 and "extra" not in json.loads(lines[-1])
 
 
 def test_under_the_launcher_every_rank_supervises_a_fresh_child(tmp_path):

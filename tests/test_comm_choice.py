@@ -97,3 +97,20 @@ def test_torch_choice_and_gloo_take_the_callback_without_asking(lib, monkeypatch
     net, calls = make_net(c)
     engine.EngineNet._install_comm(net)
     assert calls == ["callback"] and c.asked == []
+
+
+def test_a_collective_call_that_never_returns_becomes_an_error_on_this_rank():
+    """drs_rccl_comm_create is ncclCommInitRank: collective.  If another rank never gets there, this rank's call never returns; the
+    helper turns that into an exception after a rank-local limit so that _install_comm reaches its collective question and every rank
+    falls back together (`cli.main*` under torch.distributed.run would hang)."""
+    import threading
+    import time
+    assert engine.call_with_timeout(lambda: 7, 5.0, "quick") == 7
+    with pytest.raises(ZeroDivisionError):
+        engine.call_with_timeout(lambda: 1 // 0, 5.0, "raises")
+    gate = threading.Event()
+    t0 = time.time()
+    with pytest.raises(engine._lib.DrsError, match="did not return within"):
+        engine.call_with_timeout(gate.wait, 0.3, "stuck")
+    assert time.time() - t0 < 3.0
+    gate.set()

@@ -194,6 +194,55 @@ def test_rccl_collectives_at_world_one_leave_the_step_unchanged(tmp_path, mode):
     print("RCCL world-1 run vs no communicator: params bitwise equal = %s" % np.array_equal(r["params"], d.params.cpu().numpy()))
 
 
+def _rccl_forms_worker(rank, world, port, out):
+    """every form of the library-side collectives (drs_rccl_form: inline, asynchronous, inline + two overlapped gradient buckets) x the
+    one- and two-stream backward pass, in ONE process on the real backend at world 1 with every collective forced on"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", DRS_FORCE_COLLECTIVES="1", DRS_COMM="rccl")
+    import torch.distributed as dist
+    from drs_amd import _lib
+    from drs_amd.dist import TorchComm
+    from drs_amd.net import DilatedNet
+    torch.cuda.set_device(0)
+    comm = TorchComm("nccl")
+    x, y = _inputs()
+    res = {}
+    for form, env in (("inline", {}), ("async", {"DRS_RCCL_ASYNC": "1"}), ("buckets", {"DRS_RCCL_BUCKETS": "2"}), ("async_word", {"DRS_RCCL_ASYNC": "yes"})):
+        for two in ("0", "1"):
+            for k in ("DRS_RCCL_ASYNC", "DRS_RCCL_BUCKETS"):
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            os.environ["DRS_TWO_STREAMS"] = two
+            want = {"inline": 1, "async": 2, "buckets": 3, "async_word": 1}[form]        # atoi("yes") == 0: the LIBRARY's reading, and the label follows it
+            assert _lib.query("drs_rccl_form") == want
+            d = DilatedNet(NET, CH, K, 0.005, b_max=B, s_max=S, device="cuda:0", seed=3, comm=comm)
+            assert d.collectives.startswith({1: "rccl (inline:", 2: "rccl (asynchronous", 3: "rccl (inline + two overlapped"}[want]), d.collectives
+            for _ in range(3):
+                d.feed(x, y, S)
+                r = d.train_step(B, S, 0.01)
+            torch.cuda.synchronize()
+            res["%s_%s_params" % (form, two)] = d.params.cpu().numpy()
+            res["%s_%s_bn" % (form, two)] = d.bn.cpu().numpy()
+            res["%s_%s_conf" % (form, two)] = r["conf"].cpu().numpy()
+            res["%s_%s_loss" % (form, two)] = np.asarray(d.loss_value(r["loss_parts"]))
+            d.close()
+    np.savez(out, **res)
+    comm.barrier()
+    dist.destroy_process_group()
+
+
+def test_every_form_of_the_library_side_collectives_gives_the_inline_forms_bits(tmp_path):
+    """the asynchronous form is reachable only through DRS_RCCL_ASYNC and no test set it; r05 adds DRS_RCCL_BUCKETS.  Sums over
+    one rank are identities and every form issues the same kernels on the same operands, so variables, moving statistics, loss and
+    confusion matrix after three steps must be the inline form's bit for bit -- with the one- and the two-stream backward pass."""
+    out = str(tmp_path / "forms.npz")
+    mp.spawn(_rccl_forms_worker, args=(1, 29750 + os.getpid() % 1000, out), nprocs=1, join=True)
+    r = np.load(out)
+    for form in ("inline", "async", "buckets", "async_word"):
+        for two in ("0", "1"):
+            for what in ("params", "bn", "conf", "loss"):
+                np.testing.assert_array_equal(r["%s_%s_%s" % (form, two, what)], r["inline_0_%s" % what], err_msg="%s two_streams=%s %s" % (form, two, what))
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # data parallelism behind the reference's command line (isprs:1987-2138): two processes through cli.main, placed by the
 # launcher's environment (dist.from_env), against the single-process run.
