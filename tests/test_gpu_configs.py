@@ -230,7 +230,21 @@ def test_dense_classifier_448_channels_two_classes_at_size():
     assert torch.equal(conf.view(K, K).long(), want)
 
 
-def test_uniform_size_training_loop_config3(tmp_path, capsys):
+def _hold_a_drawn_size_step_to_the_oracle(spy, net_type, channels, K, wd, batch):
+    """one step of a sized loop at a DRAWN size against the CPU oracle on the very patches / variables it consumed
+    (as configs 1 and 2 have for their fixed size).  Of the recorded steps the one with the fewest pixels among the sides that are
+    not a multiple of 32 (the table forms of the filter gradient, stream-K forward launches) -- fp64 on the CPU, so the smallest."""
+    from test_gpu_single_fixed import _torch_step_loss
+    cands = [r for r in spy.steps if r["S"] % 32] or spy.steps
+    rec = min(cands, key=lambda r: r["S"])
+    assert rec["B"] == batch and rec["S"] >= 25
+    loss_ref = _torch_step_loss(rec, net_type, channels, K, wd)
+    assert abs(rec["loss"] - loss_ref) < 1e-4 * abs(loss_ref), (rec["S"], rec["loss"], loss_ref)
+    assert int(rec["conf"].sum()) == int(rec["acc_mask"][:rec["B"] * rec["S"] ** 2].sum().item())
+    return rec
+
+
+def test_uniform_size_training_loop_config3(tmp_path, capsys, monkeypatch):
     """BASELINE configs[2]: dilated_grsl_rate8, `uniform` over [25, 85], batch 128 (isprs:1727-1737: every integer size of
     the interval can be drawn; the score arrays are indexed by size - values[0], isprs:1757-1763)."""
     from drs_amd import loops, sampling as SP
@@ -247,6 +261,8 @@ def test_uniform_size_training_loop_config3(tmp_path, capsys):
     assert len(acc) == 61 and probs is None
     steps, B = 36, 128
     out = str(tmp_path) + "/"
+    from test_gpu_single_fixed import _Spy
+    spy = _Spy(monkeypatch, keep=8, decisions=False)
     net = loops.train([a[0]], [a[1]], dist, rot, [b[0]], [b[1]], tdist, ["b"], 0.01, B, steps, 0.005, [0.4] * 5, [0.2] * 5, "acc",
                       "uniform", values, acc, occ, chosen, probs, 20, out, 12, "dilated_grsl_rate8", "vaihingen", "none",
                       device=DEV, val_cache_dir=str(tmp_path))
@@ -266,9 +282,11 @@ def test_uniform_size_training_loop_config3(tmp_path, capsys):
     assert "Validation: Overall Accuracy=" in text
     best = int(text.split("Current patch size ")[1].split()[0])
     assert best == 25 + int(np.argmax(score / np.maximum(want, 1)))     # select_best_patch_size, isprs:549-608
+    rec = _hold_a_drawn_size_step_to_the_oracle(spy, "dilated_grsl_rate8", 5, 6, 0.005, B)
+    assert [r["S"] for r in spy.steps] == sizes[:8] and rec["S"] in sizes[:8]
 
 
-def test_dense_multinomial_loss_training_loop_config4(tmp_path, capsys):
+def test_dense_multinomial_loss_training_loop_config4(tmp_path, capsys, monkeypatch):
     """BASELINE configs[3] at its own sizes: DenseDilated6 (`dilated_icpr_rate6_densely`), `multinomial` over [25, 100] with the
     listed sizes {25, 50, 75, 100} at twice the base probability (isprs:61-71), update_type=loss (score += loss * epoch / 10,
     isprs:1757-1763), 4-band tiles, 2 classes, batch 32, 24 steps: every step scores its own size once, sizes above 64 are trained
@@ -287,6 +305,8 @@ def test_dense_multinomial_loss_training_loop_config4(tmp_path, capsys):
     assert len(acc) == 76 and abs(probs.sum() - 1) < 1e-12 and abs(probs[25] - 2 / 76) < 1e-12
     steps, B = 24, 32
     out = str(tmp_path) + "/"
+    from test_gpu_single_fixed import _Spy
+    spy = _Spy(monkeypatch, keep=6, decisions=False)
     net = loops.train([a[0]], [a[1]], dist, rot, [b[0]], [b[1]], tdist, ["b"], 0.01, B, steps, 0.001, [0.4] * 4, [0.2] * 4, "loss",
                       "multinomial", values, acc, occ, chosen, probs, 20, out, 8, "dilated_icpr_rate6_densely", "vaihingen", "none",
                       num_classes=2, device=DEV, val_cache_dir=str(tmp_path))
@@ -307,6 +327,8 @@ def test_dense_multinomial_loss_training_loop_config4(tmp_path, capsys):
     best = int(text.split("Current patch size ")[1].split()[0])
     mean = score / np.maximum(want, 1)
     assert mean[best - 25] == mean.min() == 0.0          # the smallest mean wins, and a size never drawn has mean 0 (isprs:552)
+    rec = _hold_a_drawn_size_step_to_the_oracle(spy, "dilated_icpr_rate6_densely", 4, 2, 0.001, B)
+    assert [r["S"] for r in spy.steps] == sizes[:6] and rec["S"] in sizes[:6]
 
 
 def test_dilated_grsl_config2_steps_are_reproducible_and_learn():

@@ -137,6 +137,77 @@ def test_two_rank_trajectory_follows_the_decision_aligned_oracle(tmp_path):
     assert int(fin["main_global_step"]) == DP_STEPS
 
 
+# one step at a REAL per-rank shape of the 8-GPU run: 16 patches per rank, a side that takes the stream-K
+# forward launches and the table form of the filter gradient, sync-BN through the callback with the finish folded into the
+# normalising kernel -- against the decision-aligned oracle on the global batch.
+RS_B, RS_S = 16, 55
+
+
+def _real_shape_inputs():
+    rng = np.random.default_rng(77)
+    return rng.normal(size=(2 * RS_B, RS_S, RS_S, CH)).astype(np.float32), rng.integers(0, K, size=(2 * RS_B, RS_S, RS_S))
+
+
+def _real_shape_worker(rank, world, port, root):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from drs_amd.dist import TorchComm, shard_slice
+    from drs_amd.net import DilatedNet
+    torch.cuda.set_device(0)
+    comm = TorchComm("gloo")
+    x, y = _real_shape_inputs()
+    sl = shard_slice(2 * RS_B, rank, world)
+    d = DilatedNet(NET, CH, K, 0.005, b_max=RS_B, s_max=RS_S, device="cuda:0", seed=3, comm=comm)
+    M = RS_B * RS_S * RS_S
+    d.feed(x[sl].reshape(RS_B, -1), y[sl].reshape(RS_B, -1), RS_S)
+    res = d.train_step(RS_B, RS_S, 0.01)
+    torch.cuda.synchronize()
+    dec = {}
+    for i, L in enumerate(d.plan.layers):
+        z = d.z[i][:M * L.cout].cpu().numpy().reshape(RS_B, RS_S, RS_S, L.cout)
+        mr = d.mean_rstd[i].cpu().numpy().reshape(L.cout, 2)
+        dec["pos%d" % i] = (z - mr[:, 0]) * mr[:, 1] > 0
+        dec["idx%d" % i] = d.idx[i][:M * L.cout].cpu().numpy().reshape(RS_B, RS_S, RS_S, L.cout)
+    np.savez(os.path.join(root, "rs_r%d.npz" % rank), loss=d.loss_value(res["loss_parts"]), conf=res["conf"].cpu().numpy(), **dec)
+    if rank == 0:
+        np.savez(os.path.join(root, "rs_final.npz"), **d.state_dict())
+    comm.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_at_a_real_per_rank_shape_follow_the_decision_aligned_oracle(tmp_path):
+    from oracle import tf_ops as T
+    from drs_amd import _lib
+    from drs_amd.net import DilatedNet
+    # the shape does take the paths it is here for (the product library's own rules)
+    assert RS_S % 32 != 0
+    assert _lib.query("drs_conv_halo_skip", RS_B, RS_S, 3, 8, 8, 256, 256) == 0          # conv8 forward: a stream-K launch (no halo skipping there)
+    root = str(tmp_path)
+    mp.spawn(_real_shape_worker, args=(2, 29850 + os.getpid() % 1000, root), nprocs=2, join=True)
+    ref = DilatedNet(NET, CH, K, 0.005, b_max=1, s_max=8, device="cuda:0", seed=3)        # the same initial variables (seed 3)
+    o = T.OracleNet(NET, CH, K, dtype=np.float64, seed=0)
+    for n in ref.variable_names():
+        o.p[n] = ref.get_variable(n).astype(np.float64)
+    x, y = _real_shape_inputs()
+    r = [np.load(os.path.join(root, "rs_r%d.npz" % q)) for q in range(2)]
+    nl = len(ref.plan.layers)
+    dec = [{"pos": np.concatenate([r[0]["pos%d" % i], r[1]["pos%d" % i]]), "idx": np.concatenate([r[0]["idx%d" % i], r[1]["idx%d" % i]])} for i in range(nl)]
+    lo, _ = o.train_step(x.astype(np.float64), y, 0.01, 0.005, decisions=dec)
+    assert float(r[0]["loss"]) == float(r[1]["loss"])
+    assert abs(float(r[0]["loss"]) - lo) < 1e-4 * abs(lo), (float(r[0]["loss"]), lo)
+    np.testing.assert_array_equal(r[0]["conf"], r[1]["conf"])
+    assert int(r[0]["conf"].sum()) == 2 * RS_B * RS_S * RS_S
+    fin = np.load(os.path.join(root, "rs_final.npz"))
+
+    def rel(a, b):
+        return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
+    for n in ref.plan.offsets:
+        assert rel(fin[n], o.p[n]) < 1e-4, n
+    for n in ref.variable_names():
+        if "moving" in n:
+            assert rel(fin[n], o.p[n]) < 1e-5, n
+
+
 def _rccl_worker(rank, world, port, out, mode):
     """ONE rank on the real backend ('nccl' = RCCL) with every collective of the step forced on (sums over one rank are identities):
     communicator bound to the device, asynchronous gradient buckets, sync-BN sums, stream waits -- the code an 8-GPU run executes."""

@@ -22,7 +22,7 @@ class _Spy(object):
     """wraps EngineNet.train_step: keeps, for every step, what the step consumed (input slab, labels, masks, variables before) and
     what it decided (ReLU signs, pool winners) and returned (loss) -- the material for a decision-aligned oracle step"""
 
-    def __init__(self, monkeypatch, keep=1):
+    def __init__(self, monkeypatch, keep=1, decisions=True):
         from drs_amd.engine import EngineNet
         self.steps, self.keep = [], keep
         real = EngineNet.train_step
@@ -40,7 +40,7 @@ class _Spy(object):
                 rec["conf"] = out["conf"].cpu().numpy().copy()
                 M = B * S * S
                 rec["dec"] = []
-                for i, L in enumerate(net.plan.layers):
+                for i, L in enumerate(net.plan.layers if decisions else []):      # (gigabytes per step at batch 128: only where they are used)
                     z = net.z[i][:M * L.cout].cpu().numpy().reshape(B, S, S, L.cout)
                     mr = net.mean_rstd[i].cpu().numpy().reshape(L.cout, 2)
                     d = {"pos": (z - mr[:, 0]) * mr[:, 1] > 0}
@@ -75,6 +75,25 @@ def _oracle_first_step(rec, net_type, channels, K, wd):
     x, y = _patches_of(rec, channels)
     loss, _ = o.train_step(x, y, rec["lr"], wd, decisions=rec["dec"])
     return loss, o
+
+
+def _torch_step_loss(rec, net_type, channels, K, wd):
+    """the loss of a recorded step from the CPU oracle's fp64 PyTorch restatement (oracle/torch_ref.py) on the very patches, labels and
+    variables the step consumed: forward pass in training mode + loss_def, free-running (its own ReLU signs and pool winners: near-tie
+    flips move a mean over >= 10^5 pixels by far less than the 1e-4 the callers allow)"""
+    from oracle.torch_ref import TorchNet
+    net = rec["net"]
+    x, y = _patches_of(rec, channels)
+    params = {}
+    flat, bn = rec["params"].cpu().numpy(), rec["bn"].cpu().numpy()
+    for name, (off, shape) in net.plan.offsets.items():
+        params[name] = flat[off:off + int(np.prod(shape))].reshape(shape).astype(np.float64)
+    for L in net.plan.layers:
+        b0 = net.plan.bn_offsets[L.name]
+        params[L.name + "/moving_mean"], params[L.name + "/moving_variance"] = bn[b0:b0 + L.cout], bn[b0 + L.cout:b0 + 2 * L.cout]
+    tn = TorchNet(net_type, channels, K, params=params, dtype=torch.float64)
+    with torch.no_grad():
+        return float(tn.loss(tn.forward(x, True), y, wd))
 
 
 def _setup_isprs(h, w, bands, seed, ref_crop=25, ref_stride=10, classes=6):
@@ -176,19 +195,9 @@ def test_config2_single_fixed_64_through_the_training_loop(tmp_path, capsys, mon
     # the first step's loss against the CPU oracle on the same 64 patches: the fp64 PyTorch-CPU restatement (oracle/torch_ref.py),
     # forward pass in training mode + loss_def -- free-running (its own ReLU signs and pool winners; near-tie flips move a mean over
     # 262 144 pixels by far less than the bound)
-    from oracle.torch_ref import TorchNet
     x, y = _patches_of(rec, CH)
     assert x.shape == (B, S, S, CH) and np.isfinite(x).all() and y.min() >= 0 and y.max() < K
-    params = {}
-    flat, bn = rec["params"].cpu().numpy(), rec["bn"].cpu().numpy()
-    for name, (off, shape) in net.plan.offsets.items():
-        params[name] = flat[off:off + int(np.prod(shape))].reshape(shape).astype(np.float64)
-    for L in net.plan.layers:
-        b0 = net.plan.bn_offsets[L.name]
-        params[L.name + "/moving_mean"], params[L.name + "/moving_variance"] = bn[b0:b0 + L.cout], bn[b0 + L.cout:b0 + 2 * L.cout]
-    tn = TorchNet(NET, CH, K, params=params, dtype=torch.float64)
-    with torch.no_grad():
-        loss_ref = float(tn.loss(tn.forward(x, True), y, WD))
+    loss_ref = _torch_step_loss(rec, NET, CH, K, WD)
     assert abs(rec["loss"] - loss_ref) < 1e-4 * abs(loss_ref), (rec["loss"], loss_ref)
     assert abs(losses[0] - loss_ref) < 1e-5 * abs(loss_ref) + 1e-6                           # what the loop printed IS that step's loss
     # bands 0..2 normalised, 3..4 not (isprs:74-81); the zero corners a rotation brings in are normalised with the rest, as in the reference
