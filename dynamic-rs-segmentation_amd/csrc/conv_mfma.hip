@@ -1324,16 +1324,19 @@ int g_conv_prio = -1;        // development switch (drs_debug_conv_prio): wave p
 
 constexpr int SK_MAX_TILES = 4096;     // from here on the tiles fill the chip many times over (and the all-halo tap rows are skipped instead)
 
-// compute units of the device the process runs on (MI355X: 256), asked once; the stream-K geometry is "a whole number of
-// workgroups per CU", so it follows the part instead of a literal
+// compute units of the CURRENT device (MI355X: 256), asked once per device; the stream-K geometry and the filter-gradient workgroup
+// counts are "a whole number of workgroups per CU", so they follow the part instead of a literal.  (A host without a GPU -- the CPU
+// tests that read the net tables back -- gets 256.  The query starts the HIP runtime on whatever device is current: hosts set their
+// device before they create a net, as engine.py does.)
 int cu_count() {
-  static const int n = [] {
-    int dev = 0;
+  static int cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
     hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess || p.multiProcessorCount < 1) return 256;
-    return p.multiProcessorCount;
-  }();
-  return n;
+    cached[dev] = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount >= 1) ? p.multiProcessorCount : 256;
+  }
+  return cached[dev];
 }
 inline int sk_max_w() { return 3 * cu_count(); }      // most workgroups of a stream-K launch: 3 per CU
 
@@ -1552,7 +1555,7 @@ int wgrad_target(long long work, int ntile, int nchunks, bool balanced, int occ,
     // workgroups reach (1: 0.75, 2: 0.88, 3: 0.93, 4: 0.95: the barrier bubbles of one are filled by the others).  Sweeps at
     // B = 16, S = 25 .. 85: profiles/r03/ab_wgrad_small.log.  Longer than g_wgrad_len chunks per workgroup: whole further rounds.
     static const double eff[5] = {1.0, 0.75, 0.88, 0.93, 0.95};
-    const double W0 = (double)work / 256.0, o = 6.0;
+    const double W0 = (double)work / (double)cu_count(), o = 6.0;
     int n = 1;
     double bt = 1e30;
     for (int i = 1; i <= occ && i <= 4; ++i) {
@@ -1561,7 +1564,7 @@ int wgrad_target(long long work, int ntile, int nchunks, bool balanced, int occ,
     }
     int r = (int)(W0 / n / (double)len + 0.5);
     r = r < 1 ? 1 : r;
-    const long long t = 256LL * n * r;
+    const long long t = (long long)cu_count() * n * r;
     return (int)(t > 4096 ? 4096 : t);
   }
   static const int steps[] = {512, 768, 1024, 2048, 3072, 4096};

@@ -120,10 +120,14 @@ class DilatedNet(object):
         self.arith, self.ns = arith, ARITH_TERMS[arith]
         # (the few-band first block stays on the exact-fp32 kernels in every arithmetic: its packed K-steps multiply 8 padded bands where the
         # split kernels would multiply 32 -- 0.13 against 0.34 ms forward, 0.19 against 0.50 ms filter gradient at B = 128)
+        self.dev = torch.device(device)
+        if self.dev.type == "cuda" and torch.cuda.is_available():
+            # the library sizes its stream-K workspace and cuts its launches by the CURRENT device's CU count (conv_mfma.hip cu_count):
+            # make this net's device current before the first library call that asks
+            torch.cuda.set_device(self.dev)
         self.plan = Plan(net_type, channels, num_classes, first_cin_pad=8)
         self.wd = float(weight_decay)
         self.b_max, self.s_max = int(b_max), int(s_max)
-        self.dev = torch.device(device)
         self.comm = comm if comm is not None else NoComm()
         self.bessel = 1 if bessel_moving_var else 0
         self.lr_decay_factor = lr_decay_factor      # 0.5 isprs:1686; 0.1 coffee:1228, contest:1021

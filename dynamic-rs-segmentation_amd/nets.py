@@ -3,7 +3,9 @@
 The net tables of the three scripts (the reference's builders, /root/reference/isprs_dilated_random.py:761-1086,
 coffee_dilated_random.py:665-841, contest_dilated_random.py:574-641; dispatch by `net_type`, isprs:1660-1680) live in ONE place
 of the product: csrc/engine.hip, behind `drs_net_create`.  This module holds no layer literal: `Plan` creates the library-side net
-(host-only: nothing touches the GPU), reads the blocks (`drs_net_layer_info`), the variable layout under TensorFlow's scope names
+(no kernel is launched and no device memory is touched; the library does ask the HIP runtime for the current device's CU count
+when it sizes the stream-K workspace -- `drs_conv_workspace_floats` -- so on a GPU host set the device before the first `Plan`; a
+host without a GPU gets the MI355X's 256), reads the blocks (`drs_net_layer_info`), the variable layout under TensorFlow's scope names
 (`drs_net_variable_info`), the squeeze-and-excitation blocks and the net-wide facts (`drs_net_info`) and presents them to the Python
 host code.  The independent statement of the same tables is oracle/nets.py (test infrastructure); tests/test_engine_plan.py holds
 the library to it for every net_type.
