@@ -715,7 +715,7 @@ struct ChunkWalk {
     if ((r1 + 31 >= lo && r1 < hi) || r1 + 31 >= S2 + lo) {
       ++c; r = r1; b = b1;
       x0 += 32;
-      if (x0 >= S) { x0 -= S; ++y; }
+      if (x0 >= S) { x0 -= S; ++y; }               // (S >= 32: at most one row wrap per chunk; smaller sides do not use y / x0)
       if (y >= S) y = 0;
       return 1;
     }
@@ -724,7 +724,9 @@ struct ChunkWalk {
     const int f = T & 31;                          // the chunk holding pixel T starts f pixels before it
     c = T >> 5;
     if (f <= lo) { b = tb; r = lo - f; } else { b = tb - 1; r = S2 + lo - f; }
-    y = ylo; x0 = 0;                               // (exact when S % 32 == 0: f == 0)
+    // pixel T is the first of image row ylo; the chunk starts f < 32 <= S pixels before it: at the row start (S % 32 == 0: always), or
+    // S - f into the row above -- the last row of the image before when ylo == 0
+    if (f == 0) { y = ylo; x0 = 0; } else { x0 = S - f; y = ylo - 1; if (y < 0) y = S - 1; }
     return c - c_old;
   }
 };
@@ -966,7 +968,7 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
 // AFF: S % 32 == 0 (a chunk lies inside one image row: wave-uniform bases + loop-invariant lane offsets); !AFF: the table form.  Two
 // instantiations rather than a run-time flag: the table form keeps a lane's next offsets in registers ACROSS the multiply phases, and
 // the 128 x 192 tile has none to spare (161 VGPRs of 168; with the flag the S % 32 == 0 loop of the headline carried 3 spilled registers).
-template <int TR, int TO, bool AFF>
+template <int TR, int TO, int MODE>
 __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) void wgrad_dma_kernel(const WgradArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass has no LDS-DMA builtin; it only needs the launch stub
   constexpr int WR = TR >= 64 ? 2 : 1, WC = TO >= 64 ? 2 : 1;
@@ -983,11 +985,13 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
   __shared__ uint32_t tabx[2][BP], tabg[2][BP];
 
+  constexpr bool AFF = MODE == 1;              // S % 32 == 0: a chunk lies inside one image row
+  constexpr bool SEG = MODE == 2;              // S >= 32, not a multiple: a chunk is at most two row segments (the table-free form, r05)
   const int t = threadIdx.x;
   // (S % 32 == 0: the wave index as a scalar -- the LDS address of every DMA piece then is one too, instead of a v_or + v_readfirstlane
   //  in front of each of the 8 DMA instructions of a chunk: the 8 launches at B = 128 15.10 -> 14.88 ms; the table form, whose loop is short
   //  of scalar registers, loses 1 % with it)
-  const int lane = t & 63, wave = AFF ? __builtin_amdgcn_readfirstlane(t >> 6) : t >> 6;
+  const int lane = t & 63, wave = (AFF || SEG) ? __builtin_amdgcn_readfirstlane(t >> 6) : t >> 6;
   const int li = lane & 31, h = lane >> 5;
   const int wr = wave / WC, wc = wave % WC;
 
@@ -1003,7 +1007,7 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   const int o0 = (tile % a.nto) * TO;
   const int rows_all = a.k * a.k * a.Cin;
   const int Sxp = a.S + 2 * a.Px, Sgp = a.S + 2 * a.Pg;
-  constexpr bool affine = AFF;
+  constexpr bool affine = AFF || SEG;         // wave-uniform chunk bases + loop-invariant lane offsets
   // DMA lane roles: instruction i of this wave moves pieces 64 (wave + NW i) + lane of the linear image: piece f belongs to pixel
   // f / XQ, 16-byte column f % XQ.  (TR is a power of two, so the X column -- and with it the filter tap of the rows this lane
   // stages -- is the same for all of a lane's instructions; TO = 192 gives every instruction its own (pixel, column) pair.)
@@ -1012,7 +1016,10 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   const int myRc = myR < rows_all ? myR : 0;
   const int tap = myRc / a.Cin, c0 = myRc % a.Cin;
   const int u = tap / a.k, v = tap % a.k;
-  const uint32_t xconst = (uint32_t)((a.ablate == 1 ? 0 : (u * a.rate * Sxp + v * a.rate)) * a.ld_x + a.coff_x + c0) * 4u;
+  // SEG: every lane offset carries a bias of 32 pixels' worth of bytes that the chunk bases take off again, so that the NEGATIVE jump of
+  // the ragged last chunk (below) never takes a 32-bit lane offset below zero
+  const uint32_t biasx = SEG ? (uint32_t)(32 * a.ld_x) * 4u : 0u, biasg = SEG ? (uint32_t)(32 * a.ld_g) * 4u : 0u;
+  const uint32_t xconst = (uint32_t)((a.ablate == 1 ? 0 : (u * a.rate * Sxp + v * a.rate)) * a.ld_x + a.coff_x + c0) * 4u + biasx;
   uint32_t xoff[IX], goff[IG];
   int xpix[IX], gpix[IG];
 #pragma unroll
@@ -1024,7 +1031,7 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   for (int i = 0; i < IG; ++i) {
     const int f = 64 * (wave + NW * i) + lane;
     gpix[i] = f / GQ;
-    goff[i] = (uint32_t)(a.coff_g + o0 + (f % GQ) * 4) * 4u + (affine ? (uint32_t)(gpix[i] * a.ld_g) * 4u : 0u);
+    goff[i] = (uint32_t)(a.coff_g + o0 + (f % GQ) * 4) * 4u + (affine ? (uint32_t)(gpix[i] * a.ld_g) * 4u : 0u) + biasg;
   }
 
   f32x16 acc[TMr][TNo];
@@ -1080,9 +1087,22 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
   const char* gbase = reinterpret_cast<const char*>(a.g);
   typedef __attribute__((address_space(3))) void* lds_ptr;
   // scalar bases of the chunk the walk stands on (S % 32 == 0), taken when the walk is there
-  auto chunk_bases = [&](const char*& xb, const char*& gb) {
+  // SEG: the chunk the walk stands on is the pixels x0 .. of image row y and, when the row ends inside it (after brk = S - x0 < 32
+  // pixels), the start of the next row -- in the slab `jump` bytes further on than linear addressing says (the two halos between the
+  // rows; after an image's last row also the halo rows between the images).  The ragged LAST chunk of the tensor ends with the last
+  // image's last row: its pixels past the end take a jump BACK by 32 pixels instead (any address inside the slab will do: their G rows
+  // are zeroed, zero_tail) -- the same mechanism, one more value of the jump.
+  struct Seg { int brk; int32_t jx, jg; };
+  auto chunk_bases = [&](const char*& xb, const char*& gb, Seg& sg) {
     xb = xbase + (size_t)(uint32_t)(((w.b * Sxp + w.y + a.Px - a.pad) * Sxp + w.x0 + a.Px - a.pad) * a.ld_x) * 4u;
     gb = gbase + (size_t)(uint32_t)(((w.b * Sgp + w.y + a.Pg) * Sgp + w.x0 + a.Pg) * a.ld_g) * 4u;
+    if (SEG) {
+      xb -= biasx; gb -= biasg;
+      sg.brk = a.S - w.x0;
+      const bool last = w.c == clast, img_end = w.y == a.S - 1;
+      sg.jx = last ? -(int32_t)biasx : (int32_t)(rowjx + (img_end ? imgjx : 0u));
+      sg.jg = last ? -(int32_t)biasg : (int32_t)(rowjg + (img_end ? imgjg : 0u));
+    }
   };
   // S % 32 != 0: a lane's byte offsets for the two halves of a chunk, table entry + lane constant, fetched into registers a phase
   // BEFORE the DMA that uses them is issued (the table read used to sit in front of every issue: an LDS round trip on the critical
@@ -1099,21 +1119,40 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
     }
   };
   // DMA of half `half` of a chunk (bases xb / gb, or the lane offsets `o`) into LDS stage `stage`
-  auto issue = [&](const char* xb, const char* gb, const LaneOffsets& o, int half, int stage) {
+  auto issue = [&](const char* xb, const char* gb, const Seg& seg, const LaneOffsets& o, int half, int stage) {
     float* sx = lds + stage * STAGE;
     float* sg = sx + XSTAGE;
     if (affine) {
       const char* xh = xb + (size_t)(uint32_t)(half * HP * a.ld_x) * 4u;
       const char* gh = gb + (size_t)(uint32_t)(half * HP * a.ld_g) * 4u;
-#pragma unroll
-      for (int i = 0; i < IX; ++i) {
-        uint32_t v = xoff[i]; asm volatile("" : "+v"(v));
-        __builtin_amdgcn_global_load_lds(xh + v, (lds_ptr)(sx + (wave + NW * i) * 256), 16, 0, 0);
+      int inner = HP;                            // SEG: first pixel of this half that lies past the row break (HP: none does)
+      if (SEG) {
+        const int hb = seg.brk - half * HP;
+        if (hb <= 0) { xh += (ptrdiff_t)seg.jx; gh += (ptrdiff_t)seg.jg; }      // the whole half lies past it: a scalar matter
+        else if (hb < HP) inner = hb;
       }
+      if (SEG && inner < HP) {                   // (wave-uniform) the break falls inside this half: a compare per lane and piece
 #pragma unroll
-      for (int i = 0; i < IG; ++i) {
-        uint32_t v = goff[i]; asm volatile("" : "+v"(v));
-        __builtin_amdgcn_global_load_lds(gh + v, (lds_ptr)(sg + (wave + NW * i) * 256), 16, 0, 0);
+        for (int i = 0; i < IX; ++i) {
+          uint32_t v = xoff[i] + (xpix[i] >= inner ? (uint32_t)seg.jx : 0u);
+          __builtin_amdgcn_global_load_lds(xh + v, (lds_ptr)(sx + (wave + NW * i) * 256), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < IG; ++i) {
+          uint32_t v = goff[i] + (gpix[i] >= inner ? (uint32_t)seg.jg : 0u);
+          __builtin_amdgcn_global_load_lds(gh + v, (lds_ptr)(sg + (wave + NW * i) * 256), 16, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < IX; ++i) {
+          uint32_t v = xoff[i]; asm volatile("" : "+v"(v));
+          __builtin_amdgcn_global_load_lds(xh + v, (lds_ptr)(sx + (wave + NW * i) * 256), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < IG; ++i) {
+          uint32_t v = goff[i]; asm volatile("" : "+v"(v));
+          __builtin_amdgcn_global_load_lds(gh + v, (lds_ptr)(sg + (wave + NW * i) * 256), 16, 0, 0);
+        }
       }
     } else {
 #pragma unroll
@@ -1177,14 +1216,15 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
 #pragma unroll
       for (int i = 0; i < IG; ++i) oA.g[half][i] = oB.g[half][i] = 0u;
     }
-    chunk_bases(xbA, gbA);
+    Seg sgA = {32, 0, 0}, sgB = {32, 0, 0};
+    chunk_bases(xbA, gbA, sgA);
     fill_tables(0, 0);
     if (!affine) __syncthreads();
     fetch_offsets(0, oA);
-    issue(xbA, gbA, oA, 0, 0);                   // chunk A, first half -> stage 0
+    issue(xbA, gbA, sgA, oA, 0, 0);              // chunk A, first half -> stage 0
     int stepped = w.advance();                   // the walk now stands on B
     int cB = w.c;
-    chunk_bases(xbB, gbB);
+    chunk_bases(xbB, gbB, sgB);
     fill_tables(1, stepped);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA has landed; the barrier then publishes everybody's
     __syncthreads();
@@ -1197,7 +1237,7 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
       if (late) fetch_offsets(it & 1, oA); else
 #endif
       fetch_offsets((it + 1) & 1, oB);           // B's table was published by the last barrier; its entries are used after compute(0)
-      issue(xbA, gbA, oA, 1, 1);                 // second half of A -> stage 1, lands while stage 0 is multiplied
+      issue(xbA, gbA, sgA, oA, 1, 1);            // second half of A -> stage 1, lands while stage 0 is multiplied
       compute(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -1205,17 +1245,17 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
 #ifdef DRS_DEV
       if (late) fetch_offsets((it + 1) & 1, oB);
 #endif
-      if (cB < cend) issue(xbB, gbB, oB, 0, 0);  // first half of B -> stage 0 (every wave is done with it)
+      if (cB < cend) issue(xbB, gbB, sgB, oB, 0, 0);  // first half of B -> stage 0 (every wave is done with it)
       stepped = w.advance();                     // ... and on C, whose table goes into the slot A's table was in
       compute(1);
       fill_tables(it & 1, stepped);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (cB < cend) zero_tail(cB, 0, 0);
-      cA = cB; xbA = xbB; gbA = gbB;
+      cA = cB; xbA = xbB; gbA = gbB; sgA = sgB;
       oA = oB;
       cB = w.c;
-      chunk_bases(xbB, gbB);
+      chunk_bases(xbB, gbB, sgB);
     }
   }
   const size_t rows_total = (size_t)a.k * a.k * a.Cin;
@@ -1461,6 +1501,14 @@ int g_wgrad_variant = -1;    // development switch (drs_debug_wgrad_variant): 0 
 
 // the S % 32 == 0 form of wgrad_dma_kernel (development build, ablate 5: at any S -- a timing experiment with WRONG sums)
 inline bool wgrad_affine(const WgradArgs& a) { return (a.S & 31) == 0 || a.ablate == 5; }
+// the table-free form of wgrad_dma_kernel for the other sides (r05): a 32-pixel chunk of a side >= 32 is at most two row segments.  The
+// lane offsets of that form are 32-bit byte offsets with a bias of 32 pixels: both slabs must leave that much room below 4 GiB
+int g_wgrad_seg = 1;         // development switch (drs_debug_wgrad_seg): 0 = the table form for every side that is not a multiple of 32
+inline bool wgrad_segments(const WgradArgs& a) {
+  const long long Sxp = a.S + 2 * a.Px, Sgp = a.S + 2 * a.Pg, B = a.M / ((long long)a.S * a.S);
+  const long long xb = (B * Sxp * Sxp + 64) * a.ld_x * 4, gb = (B * Sgp * Sgp + 64) * a.ld_g * 4;
+  return g_wgrad_seg && a.S >= 32 && !wgrad_affine(a) && xb < (1LL << 32) && gb < (1LL << 32);
+}
 
 template <int TR, int TO>
 int launch_wgrad(const WgradArgs& a, int nwg, hipStream_t st) {
@@ -1469,18 +1517,22 @@ int launch_wgrad(const WgradArgs& a, int nwg, hipStream_t st) {
   // 64-wide ones (Cout = 64, 192), so each layer takes the form that is faster for its tile
   // (r04, after the loop clean-ups of the LDS-DMA form: at S % 32 == 0 it now also wins on the 64-wide tiles -- conv2 at B = 128 0.830 -> 0.806 ms,
   //  at B = 16 0.140 -> 0.132; the table form still loses 2 % there)
-  const bool dma = g_wgrad_variant < 0 ? (TO == 128 || (TO == 64 && wgrad_affine(a))) : g_wgrad_variant == 1;
+  // (r05, row-segment addressing: on the 64-wide tiles it wins at the per-rank batches -- conv1 / conv2 at B = 16, S = 45 / 65 / 85: -4 .. -5 % --
+  //  and is a wash at B = 128 (S = 63 +1 %, 65 -4 %, 85 +2.5 %): taken below 2^18 pixels; profiles/r05/wgrad_segments_ab.txt)
+  const bool dma = g_wgrad_variant < 0 ? (TO == 128 || (TO == 64 && (wgrad_affine(a) || (wgrad_segments(a) && a.M < (1 << 18))))) : g_wgrad_variant == 1;
   if (!dma && wgrad_affine(a)) DRS_LAUNCH((wgrad_kernel<TR, TO, true>), dim3(nwg), dim3(NT), 0, st, a);
   else if (!dma) DRS_LAUNCH((wgrad_kernel<TR, TO, false>), dim3(nwg), dim3(NT), 0, st, a);
-  else if (wgrad_affine(a)) DRS_LAUNCH((wgrad_dma_kernel<TR, TO, true>), dim3(nwg), dim3(NT), 0, st, a);
-  else DRS_LAUNCH((wgrad_dma_kernel<TR, TO, false>), dim3(nwg), dim3(NT), 0, st, a);
+  else if (wgrad_affine(a)) DRS_LAUNCH((wgrad_dma_kernel<TR, TO, 1>), dim3(nwg), dim3(NT), 0, st, a);
+  else if (wgrad_segments(a)) DRS_LAUNCH((wgrad_dma_kernel<TR, TO, 2>), dim3(nwg), dim3(NT), 0, st, a);
+  else DRS_LAUNCH((wgrad_dma_kernel<TR, TO, 0>), dim3(nwg), dim3(NT), 0, st, a);
   return DRS_LAUNCH_CHECK();
 }
 
 template <int TR, int TO>
 int launch_wgrad_dma_only(const WgradArgs& a, int nwg, hipStream_t st) {
-  if (wgrad_affine(a)) DRS_LAUNCH((wgrad_dma_kernel<TR, TO, true>), dim3(nwg), dim3(256), 0, st, a);
-  else DRS_LAUNCH((wgrad_dma_kernel<TR, TO, false>), dim3(nwg), dim3(256), 0, st, a);
+  if (wgrad_affine(a)) DRS_LAUNCH((wgrad_dma_kernel<TR, TO, 1>), dim3(nwg), dim3(256), 0, st, a);
+  else if (wgrad_segments(a)) DRS_LAUNCH((wgrad_dma_kernel<TR, TO, 2>), dim3(nwg), dim3(256), 0, st, a);
+  else DRS_LAUNCH((wgrad_dma_kernel<TR, TO, 0>), dim3(nwg), dim3(256), 0, st, a);
   return DRS_LAUNCH_CHECK();
 }
 
@@ -1769,6 +1821,7 @@ int drs_debug_conv_sk_geometry(int tiles, int nks, int bn, int* out3) {
 }
 
 int drs_debug_wgrad_variant(int v) { const int old = g_wgrad_variant; if (v >= -1) g_wgrad_variant = v; return old; }
+int drs_debug_wgrad_seg(int v) { const int old = g_wgrad_seg; if (v >= 0) g_wgrad_seg = v; return old; }
 
 #endif
 

@@ -25,6 +25,7 @@ int drs_debug_conv_sk_order(int v);      /* a hybrid workgroup does 0 its range 
 int drs_debug_conv_prio(int v);          /* forward / input gradient: waves lower their priority as their workgroup advances: -1 by the rule (stream-K launches from 20 K-steps per workgroup; default), 0 never, 1 always */
 int drs_debug_conv_sk_geometry(int tiles, int nks, int bn, int* out3);   /* (workgroups, ranges, cut tiles) of a stream-K launch with the full workspace; returns workgroups, 0 = plain */
 int drs_debug_wgrad_variant(int v);      /* filter gradient: 0 register-staged, 1 LDS-DMA halves, -1 per tile (default) */
+int drs_debug_wgrad_seg(int v);          /* filter gradient, LDS-DMA form, sides >= 32 that are not a multiple of 32: 1 row-segment addressing without tables (default), 0 the table form */
 int drs_debug_wgrad_balance(int v);      /* 1 cut the pixel dimension by live pixels (default), 0 equal chunk ranges */
 int drs_debug_wgrad_target(int v);       /* workgroups the pixel split aims at (default 2048) */
 int drs_debug_wgrad_target_big(int v);   /* the same on launches with many tiles and pixels (0 = default rule) */

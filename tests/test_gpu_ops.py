@@ -531,7 +531,8 @@ def test_register_staged_and_lds_dma_kernel_forms_are_bitwise_equal(lib, k, rate
     assert rel_err(res[1][0].cpu().numpy().reshape(ref.shape), ref) < 1e-5
 
 
-@pytest.mark.parametrize("S,B", [(5, 3), (8, 5), (10, 2), (11, 3), (12, 2), (16, 3), (31, 1), (32, 2), (33, 1), (48, 1), (63, 1), (96, 1)])
+@pytest.mark.parametrize("S,B", [(5, 3), (8, 5), (10, 2), (11, 3), (12, 2), (16, 3), (31, 1), (32, 2), (33, 1), (48, 1), (63, 1), (96, 1),
+                                 (33, 3), (37, 3), (45, 2), (65, 2), (85, 1), (100, 1)])
 def test_filter_gradient_chunk_walk_over_patch_sides(lib, S, B):
     """The filter-gradient kernels walk 32-pixel chunks with a scalar state machine (ChunkWalk) and, when the patch side is not a
     multiple of 32, per-pixel offset tables that each thread advances incrementally (below 11 pixels a side: by division).  Every
@@ -552,15 +553,19 @@ def test_filter_gradient_chunk_walk_over_patch_sides(lib, S, B):
     try:
         for variant in (0, 1):
             for skip in (0, 2):
-                raw.drs_debug_wgrad_variant(variant)
-                raw.drs_debug_skip_taps(skip)
-                nsp = lib.query("drs_conv_wgrad_splits", B, S, k, cin, cout)
-                slab = torch.zeros(nsp * w.size, dtype=torch.float32, device=DEV)
-                gw = torch.full((w.size,), 7.0, dtype=torch.float32, device=DEV)
-                lib.call("drs_conv_wgrad", xd.data_ptr(), B, S, P, cin, 0, gd.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout, slab.data_ptr(),
-                         gw.data_ptr(), stream())
-                torch.cuda.synchronize()
-                outs.append(gw)
+                # (r05) the LDS-DMA form addresses sides >= 32 that are not a multiple of 32 by row SEGMENTS (scalar bases, a per-lane
+                # compare only in the half chunks a row ends in; the ragged last chunk by a jump back) or, switched off, by the r04 tables
+                for seg in ((0, 1) if variant == 1 else (1,)):
+                    raw.drs_debug_wgrad_variant(variant)
+                    raw.drs_debug_skip_taps(skip)
+                    raw.drs_debug_wgrad_seg(seg)
+                    nsp = lib.query("drs_conv_wgrad_splits", B, S, k, cin, cout)
+                    slab = torch.zeros(nsp * w.size, dtype=torch.float32, device=DEV)
+                    gw = torch.full((w.size,), 7.0, dtype=torch.float32, device=DEV)
+                    lib.call("drs_conv_wgrad", xd.data_ptr(), B, S, P, cin, 0, gd.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout, slab.data_ptr(),
+                             gw.data_ptr(), stream())
+                    torch.cuda.synchronize()
+                    outs.append(gw)
         # the cut of the pixel dimension: by live pixels (default, above) and in equal chunk ranges -- other partial sums, same gradient
         raw.drs_debug_wgrad_variant(-1)
         raw.drs_debug_skip_taps(1)
@@ -575,6 +580,7 @@ def test_filter_gradient_chunk_walk_over_patch_sides(lib, S, B):
         raw.drs_debug_wgrad_variant(-1)
         raw.drs_debug_skip_taps(1)
         raw.drs_debug_wgrad_balance(1)
+        raw.drs_debug_wgrad_seg(1)
     assert rel_err(outs[0].cpu().numpy().reshape(gw_ref.shape), gw_ref) < 1e-5
     for o in outs[1:]:
         assert torch.equal(outs[0], o)

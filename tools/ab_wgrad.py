@@ -4,7 +4,9 @@ one device, best-of per arm.  An arm is a string of development-switch settings:
 (drs_debug_wgrad_balance), t<N> workgroup target (drs_debug_wgrad_target), g<N> target of the many-tiles-and-pixels launches under
 the live cut (drs_debug_wgrad_target_big), v<0|1> kernel form (drs_debug_wgrad_variant; default per tile), l<N> chunks per workgroup that small launches aim at,
 m<N> fewest chunks a split may have (drs_debug_wgrad_minchunks), o<0|1> workgroup count by the r02 table / the per-CU cost model,
-a<0|1> timing experiment with WRONG sums: every tap reads the un-shifted pixels (what perfect re-use of X across tap rows would buy).
+a<0|1> timing experiment with WRONG sums: every tap reads the un-shifted pixels (what perfect re-use of X across tap rows would buy),
+s<0|1> sides >= 32 that are not a multiple of 32 in the LDS-DMA form: the r04 offset tables / row-segment addressing (drs_debug_wgrad_seg).
+S may be a list (S=63,64,65): one table per side with ms per 10^6 pixels, for comparing sides at equal pixels.
     python tools/ab_wgrad.py [B=128] [S=64] [arms=b0,b1,b1g2048] [layers=1,2,...] [rounds=4]"""
 import os, re, sys
 import torch
@@ -16,7 +18,7 @@ DEV = "cuda:0"
 
 
 def apply(lib, arm):
-    kv = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"([btgvlmoa])(\d+)", arm))
+    kv = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"([btgvlmoas])(\d+)", arm))
     lib.drs_debug_wgrad_balance(kv.get("b", 1))
     lib.drs_debug_wgrad_target(kv.get("t", 2048))
     lib.drs_debug_wgrad_target_big(kv.get("g", 0))
@@ -25,6 +27,7 @@ def apply(lib, arm):
     lib.drs_debug_wgrad_minchunks(kv.get("m", 8))
     lib.drs_debug_wgrad_model(kv.get("o", 1))
     lib.drs_debug_wgrad_ablate(kv.get("a", 0))
+    lib.drs_debug_wgrad_seg(kv.get("s", 1))
 
 
 def main(B=128, S=64, arms="b0,b1", rounds=4, layers=""):
@@ -64,10 +67,12 @@ def main(B=128, S=64, arms="b0,b1", rounds=4, layers=""):
         for a in arms:
             tot[a] += best[a]
         del slabs
-    print("total  " + "".join("  %s %7.3f ms |" % (a, tot[a]) for a in arms))
+    print("total  " + "".join("  %s %7.3f ms (%6.3f ms per Mpx) |" % (a, tot[a], tot[a] / (B * S * S / 1e6)) for a in arms), flush=True)
     apply(lib, "")
 
 
 if __name__ == "__main__":
     kw = dict(a.split("=") for a in sys.argv[1:])
-    main(int(kw.get("B", 128)), int(kw.get("S", 64)), kw.get("arms", "b0,b1"), int(kw.get("rounds", 4)), kw.get("layers", ""))
+    for S_ in kw.get("S", "64").split(","):
+        print("== B=%s S=%s" % (kw.get("B", 128), S_), flush=True)
+        main(int(kw.get("B", 128)), int(S_), kw.get("arms", "b0,b1"), int(kw.get("rounds", 4)), kw.get("layers", ""))
