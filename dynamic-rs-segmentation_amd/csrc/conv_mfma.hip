@@ -64,10 +64,17 @@ struct ConvArgs {
 // (conv1 / conv2 on the 64-wide register-staged form: -3.6 / -2.4 %); the reverse order (the one ahead keeps the pipe) 15.31,
 // classes crowded towards the end 15.17, two levels 15.17.  Only from 2^18 pixels (wgrad_setup).  NOT in the forward / input-gradient kernel: its many short workgroups
 // gain 0.3-0.7 % on the 128-wide tiles and LOSE 4-7 % on the 192-wide ones (three workgroups per CU).
-__device__ __forceinline__ void set_prio_by_progress(int done, int total, int& quarter) {
+// mode 1: levels 3, 2, 1, 0 by quarter; mode 2: 2, 1, 0, 0 (a launch that shares the chip with a chain the step waits for leaves the top level to it)
+__device__ __forceinline__ void set_prio_by_progress(int done, int total, int& quarter, int mode = 1) {
   const int q = __builtin_amdgcn_readfirstlane((done * 4) / total);
   if (q == quarter) return;
   quarter = q;
+  if (mode == 2) {
+    if (q <= 0) __builtin_amdgcn_s_setprio(2);
+    else if (q == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+    return;
+  }
   if (q <= 0) __builtin_amdgcn_s_setprio(3);
   else if (q == 1) __builtin_amdgcn_s_setprio(2);
   else if (q == 2) __builtin_amdgcn_s_setprio(1);
@@ -356,6 +363,7 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
   const int tile0 = (!SK && a.lpt_T) ? __builtin_amdgcn_readfirstlane(lpt_tile(wg, a.lpt_T, a.lpt_ta, a.lpt_tb, a.lpt_P, ntn)) : wg;
   bool first_seg = true;
   int quart = -1, done = 0, total = 1;
+  if (a.prio == 3) __builtin_amdgcn_s_setprio(3);      // the whole launch above a filter gradient that shares the chip (drs_tl_chain)
   if (SK && a.prio) total = (u_end - u) + (dp_next < a.sk_tiles ? ((a.sk_tiles - 1 - dp_next) / a.sk_G + 1) * a.sk_nks : 0);
   for (;;) {
     int tile = tile0, kb = 0, ke = 0;
@@ -484,7 +492,7 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvArgs a) {
     __syncthreads();
     if (!SK && a.prio) total = nks;
     for (int ks = kb; ks < ke; ++ks) {
-      if (a.prio) set_prio_by_progress(SK ? done + (ks - kb) : ks, total, quart);
+      if (a.prio == 1) set_prio_by_progress(SK ? done + (ks - kb) : ks, total, quart);
       issue(1, 1);                                  // second half of this K-step lands while the first is multiplied
       compute(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -532,6 +540,7 @@ __global__ __launch_bounds__(256) void conv_sk_fixup_kernel(const ConvArgs a) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   __shared__ float lds[2 * WM * BN];
+  if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
   const int tile = blockIdx.x;
   const int x0 = tile * a.sk_nks;
   const int w_first = sk_owner(x0, a.sk_U, a.sk_W), w_last = sk_owner(x0 + a.sk_nks - 1, a.sk_U, a.sk_W);
@@ -902,7 +911,7 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
     const int xr = wr * WTR + li, gc = wc * WTO + li;
     int quart = -1;
     for (int it = 0; cA < cend; ++it) {
-      if (a.prio) set_prio_by_progress(cA - cbeg, cend - cbeg, quart);
+      if (a.prio) set_prio_by_progress(cA - cbeg, cend - cbeg, quart, a.prio);
 #ifdef DRS_DEV
       if (a.ablate == 2) fetch_offsets((it + 1) & 1);      // A/B arm: the table reads right in front of the loads, as before r04
 #endif
@@ -1231,7 +1240,7 @@ __global__ __launch_bounds__(64 * (TR >= 64 ? 2 : 1) * (TO >= 64 ? 2 : 1), 3) vo
     zero_tail(cA, 0, 0);
     int quart = -1;
     for (int it = 0; cA < cend; ++it) {
-      if (a.prio) set_prio_by_progress(cA - cbeg, cend - cbeg, quart);
+      if (a.prio) set_prio_by_progress(cA - cbeg, cend - cbeg, quart, a.prio);
 #ifdef DRS_DEV
       const bool late = a.ablate == 2;           // A/B arm: the table reads where they used to be, right in front of each issue
       if (late) fetch_offsets(it & 1, oA); else
@@ -1475,6 +1484,9 @@ int launch_conv_dma(ConvArgs& a, float* ws, size_t ws_floats, hipStream_t st) {
   // 4.34, 55 -1 %, 35 -1 %, 25 +0.7 % (ranges of ~15 K-steps: nothing to catch up on) -- so from 20 K-steps per workgroup.  NOT in
   // plain launches: -0.6 % on the one-round ones of B = 16, S = 64, but +2.4 % at B = 32 and B = 128 and +18 % on a 192-wide tile.
   a.prio = g_conv_prio >= 0 ? g_conv_prio : (g.G && (long long)mt * nt * nks >= 20LL * g.G ? 1 : 0);
+  // a launch of the chain the step waits for, beside a filter gradient on a stream of its own (engine.hip sets drs_tl_chain around its
+  // two-stream backward pass): the whole launch at the top priority, no lowering by progress
+  if (g_conv_prio < 0 && drs_tl_chain && drs_g_chain_mode >= 1) a.prio = 3;
   conv_lpt_setup(a, BM, mt, nt, g.G);
   if (g.G) DRS_LAUNCH((conv_dma_kernel<BM, BN, WM, WN, true>), dim3(g.G), dim3(256), 0, st, a);
   else DRS_LAUNCH((conv_dma_kernel<BM, BN, WM, WN, false>), dim3(mt * nt), dim3(256), 0, st, a);
@@ -1547,6 +1559,8 @@ __attribute__((visibility("hidden"))) int drs_step_prep(const StepPrepArgs& a, h
 
 
 int drs_g_skip_halo_taps = 1;
+thread_local int drs_tl_chain = 0;
+int drs_g_chain_mode = 1;
 
 namespace {
 
@@ -1582,6 +1596,7 @@ inline int wgrad_len(int nchunks) { return g_wgrad_len ? g_wgrad_len : (nchunks 
 int g_wgrad_minchunks = 8;  // development switch (drs_debug_wgrad_minchunks): fewest 32-pixel chunks a split may have
 int g_wgrad_target_big = 0;  // development switch: workgroups aimed at on launches with many tiles and pixels under the live cut (0 = default)
 
+int g_wgrad_prio = -1;       // development switch (drs_debug_wgrad_prio): -1 = by the rule in wgrad_setup, 0 = never, 1 = levels 3..0, 2 = levels 2..0
 int g_wgrad_ablate = 0;      // development switch (drs_debug_wgrad_ablate): timing experiments with wrong sums
 int g_wgrad_model = 1;       // development switch (drs_debug_wgrad_model): 1 = per-CU cost model for launches below the `big` class, 0 = the r02 table
 
@@ -1741,7 +1756,7 @@ int wgrad_setup(int B, int S, int k, int rate, int pad_before, int cin, int cout
   // priority by remaining work: only where the filter gradient has the chip to itself.  Below 2^18 pixels the step engine runs it on a
   // stream of its own BESIDE the batch-norm-backward -> input-gradient chain (engine.hip), and raised priorities there take the matrix
   // pipe from the chain that the step waits for (B = 16: 6.87 -> 6.94 ms with them on)
-  a.prio = (g_wgrad_ablate != 3 && M >= (1LL << 18)) ? 1 : 0;
+  a.prio = g_wgrad_prio >= 0 ? g_wgrad_prio : ((g_wgrad_ablate != 3 && M >= (1LL << 18)) ? 1 : 0);
 #ifdef DRS_DEV
   a.trace = g_conv_trace;
 #endif
@@ -1779,6 +1794,8 @@ int drs_debug_wgrad_minchunks(int v) { const int old = g_wgrad_minchunks; if (v 
 
 int drs_debug_wgrad_model(int v) { const int old = g_wgrad_model; if (v >= 0) g_wgrad_model = v; return old; }
 
+int drs_debug_wgrad_prio(int v) { const int old = g_wgrad_prio; if (v >= -1) g_wgrad_prio = v; return old; }
+
 int drs_debug_wgrad_ablate(int v) { const int old = g_wgrad_ablate; if (v >= 0) g_wgrad_ablate = v; return old; }
 
 int drs_debug_wgrad_target_big(int v) { const int old = g_wgrad_target_big; if (v >= 0) g_wgrad_target_big = v; return old; }
@@ -1811,6 +1828,7 @@ int drs_debug_conv_trace(void* dev_buffer) { g_conv_trace = (unsigned long long*
 int drs_debug_conv_splitk(int v) { const int old = g_conv_splitk; if (v >= -1) g_conv_splitk = v; return old; }
 int drs_debug_conv_hybrid(int v) { const int old = g_conv_hybrid; if (v >= 0) g_conv_hybrid = v; return old; }
 int drs_debug_conv_sk_order(int v) { const int old = g_conv_sk_order; if (v >= 0) g_conv_sk_order = v; return old; }
+int drs_debug_chain_mode(int v) { const int old = drs_g_chain_mode; if (v >= 0) drs_g_chain_mode = v; return old; }
 int drs_debug_conv_prio(int v) { const int old = g_conv_prio; if (v >= -1) g_conv_prio = v; return old; }
 /* the stream-K geometry drs_conv_forward_ws takes for a launch of `tiles` tiles of nks K-steps, N tile bn, with the full workspace:
    out3 = (workgroups, ranges, tiles that are cut); returns the workgroup count (0 = one workgroup per tile) */

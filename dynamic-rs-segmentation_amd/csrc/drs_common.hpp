@@ -158,6 +158,14 @@ __device__ __forceinline__ void tile_column_stats(float* red, int t, int wm, boo
   }
 }
 
+// Host-side hint, set by the step engine around its two-stream backward pass (engine.hip): the launches this thread enqueues while it
+// is set belong to the chain the step waits for (batch-norm backward -> input gradient) and share the chip with a filter gradient on a
+// stream of its own; their waves then take the top priority (s_setprio 3).  A hint about scheduling only: never changes a result.
+// drs_g_chain_mode (development switch drs_debug_chain_mode): 0 = hint ignored, 1 = the convolution launches, 2 = + the batch-norm
+// backward launches.
+extern thread_local int drs_tl_chain;
+extern int drs_g_chain_mode;
+
 // development switch shared by the convolution kernels (drs_debug_skip_taps): 0 = multiply the all-halo taps / chunks too,
 // 1 = skip them where it pays, 2 = skip them always
 extern int drs_g_skip_halo_taps;

@@ -341,6 +341,7 @@ void list_buffers(drs_net* n) {
   }
   n->add_buf("conv_ws", conv_ws, F32);          // partial-sum slab of the stream-K convolution launches (forward: N = cout, input gradient: N = cin)
   n->add_buf("sums", 2 * (size_t)cmax, F64);
+  n->add_buf("bwd_means", 2 * (size_t)cmax, F32);      // (sum g, sum g xhat) / count as fp32: drs_bn_backward_apply_means' table (single rank)
   n->add_buf("colsum_scratch", drs_colsum_scratch_doubles(std::max(2 * cmax, n->c_last * n->K)), F64);
   n->add_buf("partial", std::max(rows_fwd * cmax * 2, part), F32);
   n->add_buf("gxh", M * cmax, F32);
@@ -962,6 +963,7 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
   float* gxh = n->p<float>("gxh");
   float* partial = n->p<float>("partial");
   double* sums = n->p<double>("sums");
+  float* bwd_means = n->p<float>("bwd_means");
 
   // Small steps (the per-rank batches of data parallelism) run every convolution launch as one round: the chip drains and refills
   // between two dependent kernels.  The filter gradient of block i+1 depends only on that block's gz, so it goes to a stream of its
@@ -981,6 +983,10 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     if (!ok) return DRS_ERR_HIP;
   }
   hipStream_t ws = two ? n->wg_stream : st;       // the stream the filter gradients run on
+  // two streams: what this thread enqueues on `st` from here to the end of the backward pass is the chain the step waits for, beside
+  // the filter gradients on `ws` (drs_common.hpp: its waves take the top priority; the filter gradient's launches clear the hint)
+  struct ChainHint { int old; explicit ChainHint(int v) : old(drs_tl_chain) { drs_tl_chain = v; } ~ChainHint() { drs_tl_chain = old; } };
+  ChainHint chain_hint(two ? 1 : 0);
   // DRS_RCCL_BUCKETS=2 (opt-in until an 8-GPU A/B exists): the gradient buffer as two all-reduces on a side stream with a communicator
   // of its own; everything else as in the inline form
   const bool buckets = inline_comm && n->rccl_buckets && n->rccl_big;
@@ -1003,6 +1009,7 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
   auto filter_gradient = [&](int i) -> int {
     const Layer& L = n->layers[i];
     const Slab& in = n->slabs[L.src];
+    ChainHint not_chain(0);
     if (two && hipStreamWaitEvent(ws, n->ev_gz[i & 1], 0) != hipSuccess) return DRS_ERR_HIP;      // block i's gz is written
     {
       Timed t(n, ws, K_CONV_WGRAD, 2.0 * M * L.k * L.k * L.cin * L.cout);
@@ -1056,7 +1063,11 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
       DRS_TRY(drs_bn_backward_reduce(gsrc, ldg, cg, z, mx ? n->p<unsigned char>("idx" + id) : nullptr, B, S, L.cout, mr, n->alpha, mx ? 1 : 0, gxh,
                                      partial, st));
     }
-    DRS_TRY(drs_stats_reduce(partial, drs_bn_backward_rows(B, S, L.cout, mx ? 1 : 0), L.cout, sums, nullptr, st));
+    // single rank: the sums need no all-reduce, so the reduction also leaves the two means the apply pass subtracts (as fp32, its own
+    // expressions: the same bits) and that pass does no fp64 division per workgroup
+    const bool means_form = !collectives(n);
+    if (means_form) DRS_TRY(drs_stats_reduce_means(partial, drs_bn_backward_rows(B, S, L.cout, mx ? 1 : 0), L.cout, n_bn, sums, bwd_means, st));
+    else DRS_TRY(drs_stats_reduce(partial, drs_bn_backward_rows(B, S, L.cout, mx ? 1 : 0), L.cout, sums, nullptr, st));
     // sync batch norm: the all-reduce of (sum g, sum g*xhat) runs on the collective's stream while this stream computes the
     // filter gradient of the block above
     // (two streams: the filter gradient runs beside this chain anyway, so the sum goes on this stream itself -- no event hand-over
@@ -1069,7 +1080,8 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     if (two && i + 2 < nL && hipStreamWaitEvent(st, n->ev_wg[i & 1], 0) != hipSuccess) return DRS_ERR_HIP;   // block i+2's filter gradient has read this slab
     {
       Timed t(n, st, K_BN_BWD_APPLY, M * L.cout * 12.0);
-      DRS_TRY(drs_bn_backward_apply(gxh, z, B, S, L.cout, mr, sums, n_bn, gz, L.halo, L.cout, 0, st));
+      if (means_form) DRS_TRY(drs_bn_backward_apply_means(gxh, z, B, S, L.cout, mr, bwd_means, gz, L.halo, L.cout, 0, st));
+      else DRS_TRY(drs_bn_backward_apply(gxh, z, B, S, L.cout, mr, sums, n_bn, gz, L.halo, L.cout, 0, st));
     }
     if (two && hipEventRecord(n->ev_gz[i & 1], st) != hipSuccess) return DRS_ERR_HIP;
     if (L.src != 0) {

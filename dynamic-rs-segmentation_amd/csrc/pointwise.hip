@@ -57,12 +57,16 @@ __global__ void colsum_l2_kernel(const double* __restrict__ scratch, int ncols, 
 // (sum g, sum g*xhat)).  With mean_rstd != null the workgroup also finishes the batch norm of its channels (bn_finish_kernel's
 // arithmetic): statistics reduction and finish are then ONE launch (single-rank case; under data parallelism the all-reduce of
 // `sums` sits between the two).
+// hp: the launch belongs to the chain a step waits for while another launch shares the chip (engine.hip, two-stream backward pass):
+// its waves take the top priority
+#define DRS_CHAIN_PRIO() do { if (hp) __builtin_amdgcn_s_setprio(3); } while (0)
 constexpr int STAT_CH = 2, STAT_LANES = 128;       // (4 x 64 measured 32 us at 4096 rows x 256 channels: latency-bound, so more row lanes and workgroups)
 template <bool CHAN>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ partial, int nrows, int C, int M, int mtile,
                                                        double* __restrict__ sums, double count, float* __restrict__ mean_rstd,
                                                        float* __restrict__ moving_mean, float* __restrict__ moving_var,
-                                                       float one_minus_decay, int bessel) {
+                                                       float one_minus_decay, int bessel, float* __restrict__ means, int hp) {
+  DRS_CHAIN_PRIO();
   __shared__ double sh[STAT_LANES][STAT_CH][2];
   const int ch = threadIdx.x & (STAT_CH - 1), rl = threadIdx.x / STAT_CH;
   const int c = blockIdx.x * STAT_CH + ch;
@@ -92,6 +96,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   if (rl != 0 || c >= C) return;
   const double s0 = sh[0][ch][0], s1 = sh[0][ch][1];
   if (sums) { sums[2 * c] = s0; sums[2 * c + 1] = s1; }
+  if (means) { means[2 * c] = (float)(s0 / count); means[2 * c + 1] = (float)(s1 / count); }     // bn_bwd_apply_kernel's coefficients, its expressions
   if (mean_rstd) {
     const double m = s0 / count;
     double var = s1 / count - m * m;
@@ -200,7 +205,8 @@ template <bool POOL>
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ ga, int ld_ga, int coff_ga, const float* __restrict__ z,
                                      const unsigned char* __restrict__ idx, int B, int S, int C,
                                      const float* __restrict__ mean_rstd, float alpha, float* __restrict__ gxh,
-                                     float* __restrict__ partial, int rows_per_block) {
+                                     float* __restrict__ partial, int rows_per_block, int hp) {
+  DRS_CHAIN_PRIO();
   extern __shared__ __attribute__((aligned(16))) float red[];   // [PT][C][2]
   const int CQ = C >> 2;
   const int cq = threadIdx.x % CQ, tp = threadIdx.x / CQ, PT = blockDim.x / CQ;
@@ -275,6 +281,7 @@ struct SlideCfg { int TX, ncol, nstrips, rps; };
 // (development switches: drs_debug_slide_*.  Workgroup target 2048 -> 5120 in r04: in-step sweep at B = 128 over 1280 .. 7680 --
 //  the forward kernel does not care (1.19-1.21 ms for the 8 layers), the backward one 1.85 -> 1.75 ms: profiles/r04/slide_blocks_sweep.txt)
 static int g_slide_blocks = 5120, g_slide_minrows = 8;
+static int g_slide_rowpad = 0;      // development switch (drs_debug_slide_rowpad; timing experiment): phantom pixels after every stored image row of z / idx / ga / gxh
 static bool slide_ok(int C) { return C / 4 <= 128; }        // two columns or more per workgroup (the neighbours go through LDS)
 static SlideCfg slide_cfg(int B, int S, int C) {
   SlideCfg c;
@@ -349,7 +356,7 @@ __device__ __forceinline__ void bn_finish4(const BnFinish& f, int c0, bool write
 
 __global__ __launch_bounds__(256) void bn_act_pool_fwd_slide_kernel(const float* __restrict__ z, int B, int S, int C,
                                                                     float* __restrict__ mean_rstd, float alpha, ActView out,
-                                                                    unsigned char* __restrict__ idx, int nstrips, int rps, const BnFinish fin) {
+                                                                    unsigned char* __restrict__ idx, int nstrips, int rps, const BnFinish fin, int SW) {   // SW: pixels per stored image row of z / idx (S; development arm: more)
   extern __shared__ __attribute__((aligned(16))) float xch[];                // [2][TX + 2][C]: the activations of a row
   const int CQ = C >> 2, TX = blockDim.x / CQ;                               // TX >= 2
   const int tx = threadIdx.x / CQ, cq = threadIdx.x - tx * CQ;
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_slide_kernel(const float*
   const bool edge_l = tx == 0, edge = edge_l || tx == TX - 1;
   const int xh = edge_l ? (x > 0 ? x - 1 : 0) : (x + 1 < S ? x + 1 : S - 1);
   const unsigned oc = (unsigned)((x * C + cq * 4) * 4), oh = edge ? (unsigned)((xh * C + cq * 4) * 4) : oc;   // (inner threads: their own column again, out of L1)
-  const size_t zrow = (size_t)S * C * 4;                                     // bytes per image row of z
+  const size_t zrow = (size_t)SW * C * 4;                                    // bytes per image row of z
   const char* zimg = reinterpret_cast<const char*>(z) + (size_t)b * S * zrow;
   f32x4* cells = reinterpret_cast<f32x4*>(xch);
   const int lc = (tx + 1) * CQ + cq, lh = (edge_l ? 0 : TX + 1) * CQ + cq, lslot = (TX + 2) * CQ;
@@ -388,7 +395,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_slide_kernel(const float*
   const size_t orow = (size_t)Sp * out.ld * 4;                               // bytes per padded row of the output view
   char* oimg = reinterpret_cast<char*>(out.base) + ((size_t)b * Sp + out.P) * orow;
   const unsigned oo = (unsigned)(((x + out.P) * out.ld + out.coff + cq * 4) * 4);
-  unsigned char* iimg = idx + (size_t)b * S * S * C;
+  unsigned char* iimg = idx + (size_t)b * S * SW * C;
   // row r: (max, position 0..2 of the first maximum in scan order) over its three horizontal neighbours into (mC, cC), the registers
   // of row r refilled with row r + 3; then output row r - 1 from rows r - 2, r - 1 (mA, mB) and r.  ONE path for every row -- a row
   // outside the image is computed from the clamped row and then overridden -- because the compiler answers a second path through
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_slide_kernel(const float*
     }
     if (y >= y0 && live) {
       *reinterpret_cast<f32x4*>(oimg + (size_t)y * orow + oo) = best;
-      if (idx) *reinterpret_cast<unsigned*>(iimg + (size_t)y * S * C + (oc >> 2)) = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
+      if (idx) *reinterpret_cast<unsigned*>(iimg + (size_t)y * SW * C + (oc >> 2)) = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
     }
   };
   f32x4 m0 = {NEG, NEG, NEG, NEG}, m1 = m0, m2 = m0;
@@ -449,7 +456,8 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_slide_kernel(const float*
 __global__ __launch_bounds__(256) void bn_bwd_reduce_slide_kernel(const float* __restrict__ ga, int ld_ga, int coff_ga,
                                                                   const float* __restrict__ z, const unsigned char* __restrict__ idx, int B,
                                                                   int S, int C, const float* __restrict__ mean_rstd, float alpha,
-                                                                  float* __restrict__ gxh, float* __restrict__ partial, int nstrips, int rps) {
+                                                                  float* __restrict__ gxh, float* __restrict__ partial, int nstrips, int rps, int SW, int hp) {
+  DRS_CHAIN_PRIO();
   // the exchange cells [2][TX + 2][CQ] x (gradient f32x4, position word), then (after the rows) the reduction image [TX][C][2]
   extern __shared__ __attribute__((aligned(16))) float red[];
   const int CQ = C >> 2;
@@ -474,7 +482,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_slide_kernel(const float* _
     const int xhc = xh < 0 ? 0 : (xh >= S ? S - 1 : xh);
     const unsigned oi = (unsigned)(x * C + cq * 4), oih = edge ? (unsigned)(xhc * C + cq * 4) : oi;      // bytes into a row of positions
     const unsigned og = (unsigned)((x * ld_ga + coff_ga + cq * 4) * 4), ogh = edge ? (unsigned)((xhc * ld_ga + coff_ga + cq * 4) * 4) : og;
-    const size_t irow = (size_t)S * C, grow = (size_t)S * ld_ga * 4, zrow = (size_t)S * C * 4;
+    const size_t irow = (size_t)SW * C, grow = (size_t)SW * ld_ga * 4, zrow = (size_t)SW * C * 4;
     const unsigned char* iimg = idx + (size_t)b * S * irow;
     const char* gimg = reinterpret_cast<const char*>(ga) + (size_t)b * S * grow;
     const char* zimg = reinterpret_cast<const char*>(z) + (size_t)b * S * zrow;
@@ -733,7 +741,8 @@ __global__ void se_fc_wgrad_kernel(const float* __restrict__ u, const float* __r
 // pass B: g_z = rstd * (g_xhat - mean(g_xhat) - xhat * mean(g_xhat * xhat)), written into a zero-haloed view
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ gxh, const float* __restrict__ z, int B, int S, int C,
                                     const float* __restrict__ mean_rstd, const double* __restrict__ sums, double count,
-                                    ActView out) {
+                                    ActView out, int hp) {
+  DRS_CHAIN_PRIO();
   // per-channel coefficients once per workgroup (they used to be 8 fp64 divisions and 96 bytes of loads per THREAD, for 48 bytes of
   // payload: the kernel was bound by that arithmetic, not by memory): [mu | rstd | sum g / N | sum g xhat / N][C], so that a
   // thread's four channels are one 16-byte LDS read per coefficient.  Same expressions, same rounding as before.
@@ -764,6 +773,41 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ gxh, const float* 
   const f32x4 rs = *reinterpret_cast<const f32x4*>(&coef[C + cq * 4]);
   const f32x4 m1 = *reinterpret_cast<const f32x4*>(&coef[2 * C + cq * 4]);
   const f32x4 m2 = *reinterpret_cast<const f32x4*>(&coef[3 * C + cq * 4]);
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float xh = (zv[j] - mu[j]) * rs[j];
+    o[j] = rs[j] * (gv[j] - m1[j] - xh * m2[j]);
+  }
+  view_store4(out, dst, o);
+}
+
+// The same with the two means handed in as fp32 (drs_stats_reduce_means works them out where it finishes the sums: single rank, the
+// sums need no all-reduce): no fp64 division, no LDS and no barrier in the 204 800 one-row workgroups of a 128-patch launch -- a
+// thread's coefficient loads (64 bytes out of L1) go out together with its payload loads.  Same expressions on the same fp32
+// values: the same bits.
+__global__ void bn_bwd_apply_means_kernel(const float* __restrict__ gxh, const float* __restrict__ z, int B, int S, int C,
+                                          const float* __restrict__ mean_rstd, const float* __restrict__ means, ActView out, int hp) {
+  DRS_CHAIN_PRIO();
+  const int CQ = C >> 2;
+  const int Sp = S + 2 * out.P;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= Sp * CQ) return;
+  const int xx = e / CQ, cq = e - xx * CQ;
+  const int b = blockIdx.y / Sp, yy = blockIdx.y - b * Sp;
+  const size_t dst = ((size_t)(b * Sp + yy) * Sp + xx) * out.ld + out.coff + cq * 4;
+  const int y = yy - out.P, x = xx - out.P;
+  if (y < 0 || y >= S || x < 0 || x >= S) {
+    view_store4(out, dst, f32x4{0.f, 0.f, 0.f, 0.f});
+    return;
+  }
+  const size_t pix = ((size_t)b * S + y) * S + x;
+  const f32x4 gv = *reinterpret_cast<const f32x4*>(gxh + pix * C + cq * 4);
+  const f32x4 zv = *reinterpret_cast<const f32x4*>(z + pix * C + cq * 4);
+  const f32x4 mr0 = *reinterpret_cast<const f32x4*>(mean_rstd + cq * 8), mr1 = *reinterpret_cast<const f32x4*>(mean_rstd + cq * 8 + 4);
+  const f32x4 mm0 = *reinterpret_cast<const f32x4*>(means + cq * 8), mm1 = *reinterpret_cast<const f32x4*>(means + cq * 8 + 4);
+  const float mu[4] = {mr0[0], mr0[2], mr1[0], mr1[2]}, rs[4] = {mr0[1], mr0[3], mr1[1], mr1[3]};
+  const float m1[4] = {mm0[0], mm0[2], mm1[0], mm1[2]}, m2[4] = {mm0[1], mm0[3], mm1[1], mm1[3]};
   f32x4 o;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -1461,6 +1505,8 @@ __global__ void confusion_kernel(const unsigned char* __restrict__ labels, const
   }
 }
 
+inline int chain_hp() { return (drs_tl_chain && drs_g_chain_mode >= 2) ? 1 : 0; }
+
 inline ActView mkview(float* base, int S, int P, int ld, int coff) {
   ActView v; v.base = base; v.S = S; v.P = P; v.ld = ld; v.coff = coff; v.terms = nullptr; v.nt = 0; return v;
 }
@@ -1475,7 +1521,14 @@ int drs_stats_reduce(const float* partial, int nrows, int C, double* sums, doubl
   (void)scratch;      // kept in the signature: earlier revisions reduced in two launches through it
   if (!partial || !sums || nrows < 1 || C < 1) return DRS_ERR_ARG;
   DRS_LAUNCH(bn_stats_kernel<false>, dim3((C + STAT_CH - 1) / STAT_CH), dim3(256), 0, (hipStream_t)stream, partial, nrows, C, 0, 1, sums,
-             1.0, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f, 0);
+             1.0, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f, 0, (float*)nullptr, chain_hp());
+  return DRS_LAUNCH_CHECK();
+}
+
+int drs_stats_reduce_means(const float* partial, int nrows, int C, double count, double* sums, float* means, void* stream) {
+  if (!partial || !means || nrows < 1 || C < 1 || count < 1.0) return DRS_ERR_ARG;
+  DRS_LAUNCH(bn_stats_kernel<false>, dim3((C + STAT_CH - 1) / STAT_CH), dim3(256), 0, (hipStream_t)stream, partial, nrows, C, 0, 1, sums,
+             count, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f, 0, means, chain_hp());
   return DRS_LAUNCH_CHECK();
 }
 
@@ -1483,7 +1536,7 @@ int drs_conv_stats_reduce(const float* partial, int M, int mtile, int C, double*
   (void)scratch;
   if (!partial || !sums || M < 1 || mtile < 1 || C < 1) return DRS_ERR_ARG;
   DRS_LAUNCH(bn_stats_kernel<true>, dim3((C + STAT_CH - 1) / STAT_CH), dim3(256), 0, (hipStream_t)stream, partial, (M + mtile - 1) / mtile, C,
-             M, mtile, sums, 1.0, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f, 0);
+             M, mtile, sums, 1.0, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f, 0, (float*)nullptr, chain_hp());
   return DRS_LAUNCH_CHECK();
 }
 
@@ -1491,7 +1544,7 @@ int drs_conv_stats_finish(const float* partial, int M, int mtile, int C, double 
                           float* moving_var, double decay, int bessel, double* sums, void* stream) {
   if (!partial || !mean_rstd || M < 1 || mtile < 1 || C < 1 || count < 1.0) return DRS_ERR_ARG;
   DRS_LAUNCH(bn_stats_kernel<true>, dim3((C + STAT_CH - 1) / STAT_CH), dim3(256), 0, (hipStream_t)stream, partial, (M + mtile - 1) / mtile, C,
-             M, mtile, sums, count, mean_rstd, moving_mean, moving_var, (float)(1.0 - decay), bessel);
+             M, mtile, sums, count, mean_rstd, moving_mean, moving_var, (float)(1.0 - decay), bessel, (float*)nullptr, chain_hp());
   return DRS_LAUNCH_CHECK();
 }
 
@@ -1530,7 +1583,7 @@ static int bn_act_pool_forward_impl(const float* z, int B, int S, int C, const f
     const size_t shm = (size_t)2 * (c.TX + 2) * C * sizeof(float);
     const BnFinish none = {nullptr, 1.0, nullptr, nullptr, 0.f, 0};
     DRS_LAUNCH(bn_act_pool_fwd_slide_kernel, dim3(c.ncol, B * c.nstrips), dim3(c.TX * (C / 4)), shm, (hipStream_t)stream, z, B, S, C,
-               const_cast<float*>(mean_rstd), alpha, v, argmax, c.nstrips, c.rps, fin ? *fin : none);
+               const_cast<float*>(mean_rstd), alpha, v, argmax, c.nstrips, c.rps, fin ? *fin : none, S + g_slide_rowpad);
   } else if (pool)
     DRS_LAUNCH(bn_act_pool_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, z, B, S, C, mean_rstd, alpha, v, argmax);
   else
@@ -1590,7 +1643,7 @@ int drs_bn_backward_reduce(const float* ga, int ld_ga, int coff_ga, const float*
     const size_t xchg = (size_t)2 * (c.TX + 2) * CQ * 20, redu = (size_t)c.TX * C * 2 * sizeof(float);
     const size_t shm = xchg > redu ? xchg : redu;
     DRS_LAUNCH(bn_bwd_reduce_slide_kernel, dim3(c.ncol, B * c.nstrips), dim3(c.TX * CQ), shm, (hipStream_t)stream, ga, ld_ga, coff_ga, z,
-               argmax, B, S, C, mean_rstd, alpha, gxhat, partial, c.nstrips, c.rps);
+               argmax, B, S, C, mean_rstd, alpha, gxhat, partial, c.nstrips, c.rps, S + g_slide_rowpad, chain_hp());
     return DRS_LAUNCH_CHECK();
   }
   const int PT = 256 / CQ;
@@ -1599,10 +1652,10 @@ int drs_bn_backward_reduce(const float* ga, int ld_ga, int coff_ga, const float*
   const size_t shm = (size_t)PT * C * 2 * sizeof(float);
   if (pool)       // wider than 512 channels: one column per workgroup, no neighbour to exchange with -- the gathering form
     DRS_LAUNCH(bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(CQ * PT), shm, (hipStream_t)stream, ga, ld_ga, coff_ga, z,
-               argmax, B, S, C, mean_rstd, alpha, gxhat, partial, rpb);
+               argmax, B, S, C, mean_rstd, alpha, gxhat, partial, rpb, chain_hp());
   else
     DRS_LAUNCH(bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(CQ * PT), shm, (hipStream_t)stream, ga, ld_ga, coff_ga, z,
-               argmax, B, S, C, mean_rstd, alpha, gxhat, partial, rpb);
+               argmax, B, S, C, mean_rstd, alpha, gxhat, partial, rpb, chain_hp());
   return DRS_LAUNCH_CHECK();
 }
 
@@ -1618,7 +1671,7 @@ static int bn_backward_apply_impl(const float* gxhat, const float* z, int B, int
   ActView v = mkview(gz, S, P_out, ld_out, coff_out);
   v.terms = terms; v.nt = terms ? nterms : 0;
   DRS_LAUNCH(bn_bwd_apply_kernel, grid, dim3(256), (size_t)4 * C * sizeof(float), (hipStream_t)stream, gxhat, z, B, S, C, mean_rstd, sums,
-             count, v);
+             count, v, chain_hp());
   return DRS_LAUNCH_CHECK();
 }
 
@@ -1626,6 +1679,17 @@ int drs_bn_backward_apply(const float* gxhat, const float* z, int B, int S, int 
                           double count, float* gz, int P_out, int ld_out, int coff_out, void* stream) {
   if (!gz) return DRS_ERR_ARG;
   return bn_backward_apply_impl(gxhat, z, B, S, C, mean_rstd, sums, count, gz, P_out, ld_out, coff_out, nullptr, 0, stream);
+}
+
+int drs_bn_backward_apply_means(const float* gxhat, const float* z, int B, int S, int C, const float* mean_rstd, const float* means,
+                                float* gz, int P_out, int ld_out, int coff_out, void* stream) {
+  if (!gxhat || !z || !mean_rstd || !means || !gz || C % 4 || C > 1024) return DRS_ERR_ARG;
+  const int Sp = S + 2 * P_out;
+  if ((long long)B * Sp > 65535) return DRS_ERR_ARG;
+  const int per_row = Sp * (C / 4);
+  DRS_LAUNCH(bn_bwd_apply_means_kernel, dim3((per_row + 255) / 256, B * Sp), dim3(256), 0, (hipStream_t)stream, gxhat, z, B, S, C, mean_rstd,
+             means, mkview(gz, S, P_out, ld_out, coff_out), chain_hp());
+  return DRS_LAUNCH_CHECK();
 }
 
 int drs_bn_backward_apply_terms(const float* gxhat, const float* z, int B, int S, int C, const float* mean_rstd,
@@ -1647,6 +1711,7 @@ int g_cls_variant = 1;       // development switch (drs_debug_cls_variant): 1 = 
 
 #ifdef DRS_DEV
 int drs_debug_slide_blocks(int v) { const int old = g_slide_blocks; if (v >= 0) g_slide_blocks = v; return old; }
+int drs_debug_slide_rowpad(int v) { const int old = g_slide_rowpad; if (v >= 0) g_slide_rowpad = v; return old; }
 int drs_debug_slide_minrows(int v) { const int old = g_slide_minrows; if (v >= 1) g_slide_minrows = v; return old; }
 int drs_debug_cls_variant(int v) { const int old = g_cls_variant; if (v >= 0) g_cls_variant = v; return old; }
 #endif

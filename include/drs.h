@@ -120,6 +120,9 @@ int drs_conv_wgrad_split(const unsigned short* x, int B, int S, int Px, int ld_x
  * drs_bn_eval_coeffs: is_training=False branch: mean_rstd from the moving statistics. */
 int drs_colsum_scratch_doubles(int ncols);
 int drs_stats_reduce(const float* partial, int nrows, int C, double* sums, double* scratch, void* stream);
+/* drs_stats_reduce that also leaves means[C][2] = (float)(sums / count): what drs_bn_backward_apply_means takes (single rank: the
+ * sums need no all-reduce between the two); sums may be NULL */
+int drs_stats_reduce_means(const float* partial, int nrows, int C, double count, double* sums, float* means, void* stream);
 int drs_conv_stats_reduce(const float* partial, int M, int mtile, int C, double* sums, double* scratch, void* stream);
 int drs_conv_stats_finish(const float* partial, int M, int mtile, int C, double count, float* mean_rstd, float* moving_mean,
                           float* moving_var, double decay, int bessel, double* sums, void* stream);
@@ -157,6 +160,9 @@ int drs_bn_backward_reduce(const float* ga, int ld_ga, int coff_ga, const float*
 int drs_bn_backward_apply(const float* gxhat, const float* z, int B, int S, int C, const float* mean_rstd,
                           const double* sums, double count, float* gz, int P_out, int ld_out, int coff_out,
                           void* stream);
+/* drs_bn_backward_apply with the two means as fp32 from drs_stats_reduce_means (the same bits; no fp64 division per workgroup) */
+int drs_bn_backward_apply_means(const float* gxhat, const float* z, int B, int S, int C, const float* mean_rstd,
+                                const float* means, float* gz, int P_out, int ld_out, int coff_out, void* stream);
 /* the same, also (gz != NULL) or only (gz == NULL) writing the split-bf16 terms of the haloed gradient */
 int drs_bn_backward_apply_terms(const float* gxhat, const float* z, int B, int S, int C, const float* mean_rstd,
                                 const double* sums, double count, float* gz, int P_out, int ld_out, int coff_out,

@@ -31,10 +31,13 @@ int drs_debug_wgrad_target(int v);       /* workgroups the pixel split aims at (
 int drs_debug_wgrad_target_big(int v);   /* the same on launches with many tiles and pixels (0 = default rule) */
 int drs_debug_wgrad_len(int v);          /* chunks per workgroup the launches below the `big` class aim at (0 = default: 96, from 2^14 chunks 192) */
 int drs_debug_wgrad_minchunks(int v);    /* fewest 32-pixel chunks a split of the pixel dimension may have (default 8) */
+int drs_debug_wgrad_prio(int v);         /* filter gradient, wave priority by remaining work: -1 by the rule (default), 0 never, 1 levels 3..0, 2 levels 2..0 */
 int drs_debug_wgrad_ablate(int v);       /* 1 = timing experiment (WRONG sums): every filter tap reads the un-shifted pixels (perfect X re-use); 2 = the S % 32 != 0 table reads of wgrad_dma_kernel right in front of each DMA issue, as before r04 (same sums); 3 = no wave priority by remaining work (same sums) */
 int drs_debug_wgrad_model(int v);        /* 1 per-CU cost model for the workgroup count of launches below the `big` class (default), 0 the r02 table */
 int drs_debug_slide_blocks(int v);       /* sliding elementwise kernels: workgroups the row-strip split aims at (default 5120) */
 int drs_debug_slide_minrows(int v);      /* ... and the fewest rows of a strip in that first split (default 8) */
+int drs_debug_chain_mode(int v);         /* two-stream backward pass, the launches of the chain the step waits for at the top wave priority: 0 none, 1 the input-gradient launches (+ stream-K fix-up), 2 + the batch-norm backward launches */
+int drs_debug_slide_rowpad(int v);       /* TIMING EXPERIMENT (the callers must size z / idx / ga / gxh for it): phantom pixels after every stored image row in the two sliding elementwise kernels */
 int drs_debug_cls_variant(int v);        /* classifier block: 1 MFMA from 4 classes up, LDS-DMA form up to C = 256 (default), 2 register MFMA form always, 3 LDS-DMA form where it fits, 0 vector-ALU always */
 int drs_debug_variant(int v);            /* split-bf16 forward kernels: 0 register-staged, 1 LDS-DMA (default) */
 /* the workgroups drs_conv_wgrad would launch for a shape, worked out on the host by the kernels' own assignment code:

@@ -303,6 +303,15 @@ def test_bn_act_pool_forward_backward(lib, C, pool, alpha, B, S, P):
     assert rel_err(got, gz_ref) < 5e-5
     full[:, Pg:Pg + S, Pg:Pg + S] = 0
     assert np.all(full == 0)
+    # the means form (single rank: the reduction leaves the two fp32 means, the apply pass does no fp64 division): the same bits
+    bs2 = torch.zeros(C * 2, dtype=torch.float64, device=DEV)
+    means = torch.zeros(C * 2, dtype=torch.float32, device=DEV)
+    lib.call("drs_stats_reduce_means", partial.data_ptr(), rows, C, float(M), bs2.data_ptr(), means.data_ptr(), stream())
+    gz2 = torch.full((B * (S + 2 * Pg) ** 2 * C,), 9.0, dtype=torch.float32, device=DEV)
+    lib.call("drs_bn_backward_apply_means", gxh.data_ptr(), zd.data_ptr(), B, S, C, mr.data_ptr(), means.data_ptr(), gz2.data_ptr(), Pg, C, 0, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(bs2, bs) and torch.equal(gz2, gz)
+    assert np.array_equal(means.cpu().numpy(), (bs.cpu().numpy() / float(M)).astype(np.float32))     # (numpy: an IEEE division, as the kernel's)
 
 
 @pytest.mark.parametrize("C,alpha,B,S,P", [(64, 0.1, 2, 9, 4), (256, 0.1, 3, 25, 8), (192, 0.0, 1, 12, 0), (448, 0.0, 1, 7, 3), (32, 0.1, 2, 5, 2)])

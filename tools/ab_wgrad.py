@@ -18,7 +18,7 @@ DEV = "cuda:0"
 
 
 def apply(lib, arm):
-    kv = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"([btgvlmoas])(\d+)", arm))
+    kv = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"([btgvlmoasp])(\d+)", arm))
     lib.drs_debug_wgrad_balance(kv.get("b", 1))
     lib.drs_debug_wgrad_target(kv.get("t", 2048))
     lib.drs_debug_wgrad_target_big(kv.get("g", 0))
@@ -28,6 +28,7 @@ def apply(lib, arm):
     lib.drs_debug_wgrad_model(kv.get("o", 1))
     lib.drs_debug_wgrad_ablate(kv.get("a", 0))
     lib.drs_debug_wgrad_seg(kv.get("s", 1))
+    lib.drs_debug_wgrad_prio(kv.get("p", -1))      # p<0|1|2>: wave priority by remaining work never / levels 3..0 / levels 2..0 (default: by the rule)
 
 
 def main(B=128, S=64, arms="b0,b1", rounds=4, layers=""):

@@ -31,26 +31,29 @@ def timeit(fn, reps=20):
     return float(np.median(ts))
 
 
-def main(B, S, Cs, P, blocks=None, minrows=None):
+def main(B, S, Cs, P, blocks=None, minrows=None, rowpad=0):
     global _lib
-    if blocks is not None or minrows is not None:
+    if blocks is not None or minrows is not None or rowpad:
         _lib = _lib.dev()
         if blocks is not None:
             _lib.drs_debug_slide_blocks(blocks)
         if minrows is not None:
             _lib.drs_debug_slide_minrows(minrows)
-        print("slide blocks target %s, min rows %s" % (blocks, minrows))
+        if rowpad:
+            _lib.drs_debug_slide_rowpad(rowpad)      # timing experiment: the sliding kernels walk rows of S + rowpad pixels (apply stays linear)
+        print("slide blocks target %s, min rows %s, row pad %d" % (blocks, minrows, rowpad))
     st = torch.cuda.current_stream(DEV).cuda_stream
     M = B * S * S
+    MP = B * S * (S + rowpad)
     tot = {"fwd": 0.0, "reduce": 0.0, "apply": 0.0}
     for C in Cs:
-        z = torch.randn(M, C, device=DEV)
+        z = torch.randn(MP, C, device=DEV)
         mr = torch.stack([torch.zeros(C, device=DEV), torch.ones(C, device=DEV)], 1).contiguous()
         Sp = S + 2 * P
         out = torch.zeros(B * Sp * Sp * C, device=DEV)
-        idx = torch.zeros(M * C, dtype=torch.uint8, device=DEV)
-        ga = torch.randn(M, C, device=DEV)
-        gxh = torch.empty(M, C, device=DEV)
+        idx = torch.zeros(MP * C, dtype=torch.uint8, device=DEV)
+        ga = torch.randn(MP, C, device=DEV)
+        gxh = torch.empty(MP, C, device=DEV)
         rows = _lib.query("drs_bn_backward_rows", B, S, C, 1)
         partial = torch.zeros(rows * C * 2, device=DEV)
         sums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
@@ -72,4 +75,4 @@ def main(B, S, Cs, P, blocks=None, minrows=None):
 if __name__ == "__main__":
     kw = dict(a.split("=") for a in sys.argv[1:])
     main(int(kw.get("B", 128)), int(kw.get("S", 64)), [int(v) for v in kw.get("C", "64,64,128,128,192,192,256,256").split(",")], int(kw.get("P", 8)),
-         int(kw["blocks"]) if "blocks" in kw else None, int(kw["minrows"]) if "minrows" in kw else None)
+         int(kw["blocks"]) if "blocks" in kw else None, int(kw["minrows"]) if "minrows" in kw else None, int(kw.get("rowpad", 0)))
