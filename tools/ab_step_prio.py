@@ -3,7 +3,8 @@
 An arm is a string of settings: t<-1|0|1> two-stream backward pass (DRS_TWO_STREAMS: a net per value; 9 = the rule),
 w<0|1|2|9> filter gradient's wave priority by remaining work (drs_debug_wgrad_prio; 9 = the rule), c<0|1|3|9> forward /
 input-gradient kernel (drs_debug_conv_prio; 3 = every launch at the top level; 9 = the rule),
-e<0|1|2> the chain of the two-stream backward pass at the top level (drs_debug_chain_mode: 1 input-gradient launches, 2 + batch-norm backward).
+e<0|1|2> the chain of the two-stream backward pass at the top level (drs_debug_chain_mode: 1 input-gradient launches (default), 2 + batch-norm backward),
+a<0|1> TIMING EXPERIMENT with wrong sums: the filter gradient reads the un-shifted pixels for every tap (what perfect re-use of X would buy).
     python tools/ab_step_prio.py [B=16] [S=64,65] [arms=t9w9c9,t9w2c9,...] [steps=20] [rounds=4]"""
 import os, re, sys, time
 import numpy as np
@@ -18,9 +19,9 @@ from drs_amd.synthetic import make_tile, grid_instances
 
 
 def parse(arm):
-    kv = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"([twce])(-?\d+)", arm))
+    kv = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"([twcea])(-?\d+)", arm))
     f = lambda k: -1 if kv.get(k, 9) == 9 else kv[k]
-    return f("t"), f("w"), f("c"), kv.get("e", 0)
+    return f("t"), f("w"), f("c"), kv.get("e", 1), kv.get("a", 0)
 
 
 def main(B=16, Ss=(64,), arms=("t9w9c9",), steps=20, rounds=4):
@@ -42,11 +43,12 @@ def main(B=16, Ss=(64,), arms=("t9w9c9",), steps=20, rounds=4):
         best = {a: [] for a in arms}
         for r in range(rounds + 1):
             for a in arms:
-                t, w, c, e = parse(a)
+                t, w, c, e, ab = parse(a)
                 net = nets[t]
                 d.drs_debug_wgrad_prio(w)
                 d.drs_debug_conv_prio(c)
                 d.drs_debug_chain_mode(e)
+                d.drs_debug_wgrad_ablate(ab)
                 np.random.seed(0)
                 def step(i):
                     rows = inst[(i * B) % 4000:(i * B) % 4000 + B]
@@ -65,7 +67,8 @@ def main(B=16, Ss=(64,), arms=("t9w9c9",), steps=20, rounds=4):
         print("B=%d S=%d  " % (B, S) + "   ".join("%s %.3f (min %.3f)" % (a, float(np.median(v)), min(v)) for a, v in best.items()), flush=True)
     d.drs_debug_wgrad_prio(-1)
     d.drs_debug_conv_prio(-1)
-    d.drs_debug_chain_mode(0)
+    d.drs_debug_chain_mode(1)
+    d.drs_debug_wgrad_ablate(0)
 
 
 if __name__ == "__main__":
