@@ -10,8 +10,8 @@ drift apart after a few dozen steps, so one pair of runs says little.  The test 
     sides of a seed share initial weights and patches, so most of the seed-to-seed spread -- +-0.12 of accuracy at this length of
     run, where the moving statistics of decay 0.999 are a tenth of the way in -- is common to both and cancels in the difference):
     the mean per-seed difference of the held-out accuracies (and of the late losses) must lie inside a band set by the measured
-    spread of those differences.  (r05: four seeds, paired; the unpaired band of three seeds was 0.30 of accuracy wide -- a build
-    that labelled at chance would have passed it -- the paired one is ~0.12.)
+    spread of those differences.  (r05: paired; the unpaired band of the same three seeds was 0.30 of accuracy wide -- a build that
+    labelled at chance would have passed it -- the paired one is ~0.13.  A fourth seed costs the suite a minute for 0.01.)
 """
 import numpy as np
 import pytest
@@ -26,7 +26,7 @@ pytestmark = pytest.mark.gpu
 from gpu_util import DEV   # noqa: E402
 
 NET, CH, K, B, S, STEPS, LR, WD = "dilated_grsl_rate8", 5, 6, 6, 20, 120, 0.01, 0.0005
-SEEDS = (0, 1, 2, 3)
+SEEDS = (0, 1, 2)
 
 
 def _run(seed, tile, lab, held, held_lab, mean, std):
@@ -93,7 +93,7 @@ def test_heldout_pixel_accuracy_matches_cpu_oracle_over_seeds():
           % (late_d.mean(), late_d.std(ddof=1), late_t.mean(), late_t.std(ddof=1), np.round(d_loss, 4), d_loss.mean(), se_loss))
     assert acc_t.mean() > 2.0 / K and acc_d.mean() > 2.0 / K
     # the two populations agree: mean paired difference within 3 standard errors of the spread of the differences (+ a floor so
-    # that an accidentally tiny spread cannot fail a correct implementation: four seeds estimate the spread itself only to +-35 %,
+    # that an accidentally tiny spread cannot fail a correct implementation: three seeds estimate the spread itself only to +-40 %,
     # and the CPU side is not run-to-run deterministic -- threaded sums)
     assert abs(d_acc.mean()) <= 3.0 * se_acc + 0.03
     assert abs(d_loss.mean()) <= 3.0 * se_loss + 0.03 * late_t.mean()
