@@ -10,8 +10,9 @@ drift apart after a few dozen steps, so one pair of runs says little.  The test 
     sides of a seed share initial weights and patches, so most of the seed-to-seed spread -- +-0.12 of accuracy at this length of
     run, where the moving statistics of decay 0.999 are a tenth of the way in -- is common to both and cancels in the difference):
     the mean per-seed difference of the held-out accuracies (and of the late losses) must lie inside a band set by the measured
-    spread of those differences.  (r05: paired; the unpaired band of the same three seeds was 0.30 of accuracy wide -- a build that
-    labelled at chance would have passed it -- the paired one is ~0.13.  A fourth seed costs the suite a minute for 0.01.)
+    spread of those differences.  (r05: eight seeds, paired -- the oracle's PyTorch-CPU side now runs with a thread per GRANTED
+    core, tests/conftest.py, 4 s a seed instead of 60; the unpaired band of three seeds was 0.30 of accuracy wide -- a build that
+    labelled at chance would have passed it -- this one is ~0.08.)
 """
 import numpy as np
 import pytest
@@ -26,7 +27,7 @@ pytestmark = pytest.mark.gpu
 from gpu_util import DEV   # noqa: E402
 
 NET, CH, K, B, S, STEPS, LR, WD = "dilated_grsl_rate8", 5, 6, 6, 20, 120, 0.01, 0.0005
-SEEDS = (0, 1, 2)
+SEEDS = tuple(range(8))
 
 
 def _run(seed, tile, lab, held, held_lab, mean, std):
@@ -79,7 +80,7 @@ def test_heldout_pixel_accuracy_matches_cpu_oracle_over_seeds():
         dev = np.abs(ld[:8] / lt[:8] - 1.0)
         print("seed %d  |loss HIP / loss torch - 1| over the first steps: %s" % (seed, np.array2string(dev, precision=5)))
         assert dev[0] < 1e-4 and dev[1:4].max() < 1e-2, dev
-        assert np.mean(ld[-20:]) < 0.6 * ld[0] and np.mean(lt[-20:]) < 0.6 * lt[0]          # both learn
+        assert np.mean(ld[-20:]) < 0.8 * ld[0] and np.mean(lt[-20:]) < 0.8 * lt[0]          # both learn (the last 20 of 120 noisy steps: 0.45-0.65 of the first loss over the seeds)
         acc_d.append(ad); acc_t.append(at)
         late_d.append(np.mean(ld[-20:])); late_t.append(np.mean(lt[-20:]))
     n = len(SEEDS)
@@ -93,9 +94,9 @@ def test_heldout_pixel_accuracy_matches_cpu_oracle_over_seeds():
           % (late_d.mean(), late_d.std(ddof=1), late_t.mean(), late_t.std(ddof=1), np.round(d_loss, 4), d_loss.mean(), se_loss))
     assert acc_t.mean() > 2.0 / K and acc_d.mean() > 2.0 / K
     # the two populations agree: mean paired difference within 3 standard errors of the spread of the differences (+ a floor so
-    # that an accidentally tiny spread cannot fail a correct implementation: three seeds estimate the spread itself only to +-40 %,
+    # that an accidentally tiny spread cannot fail a correct implementation: eight seeds estimate the spread itself only to +-25 %,
     # and the CPU side is not run-to-run deterministic -- threaded sums)
-    assert abs(d_acc.mean()) <= 3.0 * se_acc + 0.03
+    assert abs(d_acc.mean()) <= 3.0 * se_acc + 0.02
     assert abs(d_loss.mean()) <= 3.0 * se_loss + 0.03 * late_t.mean()
 
 
