@@ -10,9 +10,10 @@ drift apart after a few dozen steps, so one pair of runs says little.  The test 
     sides of a seed share initial weights and patches, so most of the seed-to-seed spread -- +-0.12 of accuracy at this length of
     run, where the moving statistics of decay 0.999 are a tenth of the way in -- is common to both and cancels in the difference):
     the mean per-seed difference of the held-out accuracies (and of the late losses) must lie inside a band set by the measured
-    spread of those differences.  (r05: eight seeds, paired -- the oracle's PyTorch-CPU side now runs with a thread per GRANTED
+    spread of those differences.  (r05: twelve seeds, paired -- the oracle's PyTorch-CPU side now runs with a thread per GRANTED
     core, tests/conftest.py, 4 s a seed instead of 60; the unpaired band of three seeds was 0.30 of accuracy wide -- a build that
-    labelled at chance would have passed it -- this one is ~0.08.)
+    labelled at chance would have passed it -- this one is ~0.12.  tools/parity_population.py: the same comparison over 190 seeds,
+    profiles/r05/accuracy_parity_population.txt.)
 """
 import numpy as np
 import pytest
@@ -27,7 +28,7 @@ pytestmark = pytest.mark.gpu
 from gpu_util import DEV   # noqa: E402
 
 NET, CH, K, B, S, STEPS, LR, WD = "dilated_grsl_rate8", 5, 6, 6, 20, 120, 0.01, 0.0005
-SEEDS = tuple(range(8))
+SEEDS = tuple(range(12))
 
 
 def _run(seed, tile, lab, held, held_lab, mean, std):
@@ -94,7 +95,7 @@ def test_heldout_pixel_accuracy_matches_cpu_oracle_over_seeds():
           % (late_d.mean(), late_d.std(ddof=1), late_t.mean(), late_t.std(ddof=1), np.round(d_loss, 4), d_loss.mean(), se_loss))
     assert acc_t.mean() > 2.0 / K and acc_d.mean() > 2.0 / K
     # the two populations agree: mean paired difference within 3 standard errors of the spread of the differences (+ a floor so
-    # that an accidentally tiny spread cannot fail a correct implementation: eight seeds estimate the spread itself only to +-25 %,
+    # that an accidentally tiny spread cannot fail a correct implementation: twelve seeds estimate the spread itself only to +-20 %,
     # and the CPU side is not run-to-run deterministic -- threaded sums)
     assert abs(d_acc.mean()) <= 3.0 * se_acc + 0.02
     assert abs(d_loss.mean()) <= 3.0 * se_loss + 0.03 * late_t.mean()
