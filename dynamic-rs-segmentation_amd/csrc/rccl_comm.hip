@@ -3,7 +3,8 @@
 // torch.distributed ~23 times a step (`drs_allreduce(handle, comm)`; the reference is single-process, isprs:1707).
 //
 // The library does not link librccl: a single-GPU host never needs it.  `librccl.so.1` is looked up among the objects the
-// process has already loaded (a PyTorch host has loaded its own copy) and then on the loader path / under /opt/rocm/lib.
+// process has already loaded (a PyTorch host has loaded its own copy) and then on the loader path / under /opt/rocm/lib;
+// DRS_RCCL_LIB names another NCCL-API library to bind instead.
 // A communicator made here belongs to the library's copy of RCCL; a host that links RCCL itself may hand in its own ncclComm_t
 // (drs_net_set_rccl takes opaque pointers) provided both sides resolve to the same loaded librccl.
 #include "drs_common.hpp"
@@ -11,6 +12,7 @@
 
 #include <dlfcn.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -38,7 +40,16 @@ std::once_flag g_once;
 
 void load_rccl() {
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);          // the copy the host process already runs, if any
+  // DRS_RCCL_LIB: the path of the NCCL-API library to bind instead (another build of RCCL; the shared-memory stand-in the tests
+  // drive the world > 1 code of the step engine with on a one-GPU box, tests/c/nccl_shm_double.cpp).  Named and not loadable: no
+  // fall-back to the copies below -- the caller asked for THAT library.
+  const char* named = std::getenv("DRS_RCCL_LIB");
+  void* h = nullptr;
+  if (named && *named) {
+    h = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { std::fprintf(stderr, "libdrs_hip: DRS_RCCL_LIB=%s could not be loaded: %s\n", named, dlerror()); return; }
+  }
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);          // the copy the host process already runs, if any
   for (int i = 0; !h && i < 3; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
   if (!h) return;
   g_rccl.handle = h;

@@ -136,7 +136,11 @@ class EngineNet(DilatedNet):
         is RCCL ('nccl') -- the host only carries the two 128-byte communicator ids from rank 0 to the other ranks; otherwise (gloo
         rehearsals and CPU tests, DRS_COMM=torch, or RCCL not bindable) through the all-reduce callback into torch.distributed."""
         import os
-        if getattr(self.comm, "backend", None) == "nccl" and os.environ.get("DRS_COMM", "rccl") != "torch":
+        # (DRS_COMM=rccl over a host group that is not RCCL -- gloo -- still takes the library-side path: the host group only carries
+        #  the communicator ids; with DRS_RCCL_LIB naming the NCCL-API library the step engine binds.  The tests run the world > 1
+        #  code of the library-side collectives that way on a one-GPU box, tests/test_gpu_dp.py.)
+        forced = os.environ.get("DRS_COMM") == "rccl" and bool(os.environ.get("DRS_RCCL_LIB"))
+        if (getattr(self.comm, "backend", None) == "nccl" or forced) and os.environ.get("DRS_COMM", "rccl") != "torch":
             err = None
             if self.comm.all_true(bool(_lib.query("drs_rccl_available"))):
                 try:

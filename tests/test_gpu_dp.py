@@ -315,6 +315,103 @@ def test_every_form_of_the_library_side_collectives_gives_the_inline_forms_bits(
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# The library-side collectives at world > 1 on a one-GPU box.  RCCL refuses two ranks on one device, so until r05 the code that an
+# 8-GPU run executes -- engine.hip issuing the step's sums itself (inline / two buckets / asynchronous), beside the two-stream
+# backward pass -- had only ever run at world 1 (identities).  tests/c/nccl_shm_double.cpp is a shared-memory stand-in for the five
+# NCCL entry points the library binds (DRS_RCCL_LIB); the host group (gloo) only carries the communicator ids.  At two ranks a sum
+# of two operands is the same in any order, so every form must give the callback path's bits.
+DBL_B, DBL_S = 8, 33           # per rank: stream-K forward launches, the row-segment filter gradient, the two-stream backward pass
+
+
+def _build_nccl_double(tmp):
+    import subprocess
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c", "nccl_shm_double.cpp")
+    out = os.path.join(str(tmp), "libnccl_shm_double.so")
+    subprocess.run(["g++", "-O1", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src, "-L/opt/rocm/lib", "-lamdhip64", "-lrt",
+                    "-o", out], check=True)
+    return out
+
+
+def _double_inputs(world):
+    rng = np.random.default_rng(5)
+    return rng.normal(size=(world * DBL_B, DBL_S * DBL_S * CH)).astype(np.float32), rng.integers(0, K, size=(world * DBL_B, DBL_S * DBL_S))
+
+
+def _double_worker(rank, world, port, out, lib, cases):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), DRS_RCCL_LIB=lib,
+                      DRS_RCCL_INIT_TIMEOUT_S="150")
+    import torch.distributed as dist
+    from drs_amd.dist import TorchComm, shard_slice
+    from drs_amd.net import DilatedNet
+    torch.cuda.set_device(0)
+    comm = TorchComm("gloo")
+    x, y = _double_inputs(world)
+    sl = shard_slice(world * DBL_B, rank, world)
+    res = {}
+    for name, env in cases:
+        for k in ("DRS_COMM", "DRS_RCCL_ASYNC", "DRS_RCCL_BUCKETS", "DRS_TWO_STREAMS"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        d = DilatedNet(NET, CH, K, 0.005, b_max=DBL_B, s_max=DBL_S, device="cuda:0", seed=3, comm=comm)
+        if env.get("DRS_COMM") == "rccl":
+            assert d.collectives.startswith("rccl") and d.ranks_observed == world, (d.collectives, getattr(d, "ranks_observed", None))
+        else:
+            assert d.collectives == "callback", d.collectives
+        losses = []
+        for _ in range(3):
+            d.feed(x[sl], y[sl], DBL_S)
+            r = d.train_step(DBL_B, DBL_S, 0.01)
+            losses.append(d.loss_value(r["loss_parts"]))
+        torch.cuda.synchronize()
+        res[name + "_params"] = d.params.cpu().numpy()
+        res[name + "_bn"] = d.bn.cpu().numpy()
+        res[name + "_conf"] = r["conf"].cpu().numpy()
+        res[name + "_loss"] = np.asarray(losses)
+        d.close()
+        comm.barrier()
+    if rank == 0:
+        np.savez(out, **res)
+    comm.barrier()
+    dist.destroy_process_group()
+
+
+def test_library_side_collectives_at_two_ranks_give_the_callback_paths_bits(tmp_path):
+    lib = _build_nccl_double(tmp_path)
+    rccl = {"DRS_COMM": "rccl"}
+    cases = [("callback", {"DRS_COMM": "torch"})]
+    for form, env in (("inline", {}), ("buckets", {"DRS_RCCL_BUCKETS": "2"}), ("async", {"DRS_RCCL_ASYNC": "1"})):
+        for two in ("0", "1"):
+            cases.append(("%s_%s" % (form, two), dict(rccl, DRS_TWO_STREAMS=two, **env)))
+    out = str(tmp_path / "double.npz")
+    mp.spawn(_double_worker, args=(2, 29850 + os.getpid() % 1000, out, lib, cases), nprocs=2, join=True)
+    r = np.load(out)
+    assert np.all(np.isfinite(r["callback_loss"])) and r["callback_loss"][2] != r["callback_loss"][0]
+    for name, _ in cases[1:]:
+        for what in ("params", "bn", "conf", "loss"):
+            np.testing.assert_array_equal(r["%s_%s" % (name, what)], r["callback_%s" % what], err_msg="%s %s" % (name, what))
+
+
+def test_library_side_collectives_at_three_ranks_follow_the_callback_path(tmp_path):
+    """three operands: the stand-in adds in rank order, gloo in its own, so the sums differ in the last bit and a few ReLU signs /
+    pool winners flip (the bounds are those of test_two_rank_step_equals_single_rank)"""
+    lib = _build_nccl_double(tmp_path)
+    cases = [("callback", {"DRS_COMM": "torch"}), ("inline", {"DRS_COMM": "rccl"}), ("buckets", {"DRS_COMM": "rccl", "DRS_RCCL_BUCKETS": "2"})]
+    out = str(tmp_path / "double3.npz")
+    mp.spawn(_double_worker, args=(3, 29870 + os.getpid() % 1000, out, lib, cases), nprocs=3, join=True)
+    r = np.load(out)
+
+    def rel(a, b):
+        return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
+    for name in ("inline", "buckets"):
+        np.testing.assert_allclose(r[name + "_loss"], r["callback_loss"], rtol=1e-5)
+        assert rel(r[name + "_params"], r["callback_params"]) < 1e-4
+        assert rel(r[name + "_bn"], r["callback_bn"]) < 1e-5
+        assert np.abs(r[name + "_conf"].astype(np.int64) - r["callback_conf"].astype(np.int64)).sum() <= 8
+    for what in ("params", "bn", "conf", "loss"):      # (the two library-side forms add the same operands in the same order)
+        np.testing.assert_array_equal(r["buckets_" + what], r["inline_" + what])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # data parallelism behind the reference's command line (isprs:1987-2138): two processes through cli.main, placed by the
 # launcher's environment (dist.from_env), against the single-process run.
 ARGV = ["isprs_dilated_random.py", "synthetic:70x80x5/vaihingen/", "OUT", "none", "a,b", "c", "0.01", "0.005", "4", "3", "25", "10",
