@@ -2,7 +2,9 @@
 """Randomised (net type, bands, classes, world size, per-rank batch, side) through the data-parallel training step: W processes
 sharing the one GPU over gloo (the callback collectives), each with its shard, against the single-process step on the whole batch --
 loss, gradients, updated variables, moving statistics, confusion matrix.  (The bounds are those of tests/test_gpu_dp.py: the sums
-associate differently, so a few ReLU signs / pool winners flip.)      python tools/fuzz_dp.py [n=10] [seed=0]"""
+associate differently, so a few ReLU signs / pool winners flip.)      python tools/fuzz_dp.py [n=10] [seed=0]
+With DRS_COMM=rccl DRS_RCCL_LIB=<tests/c/nccl_shm_double.cpp built> in the environment the ranks' sums are issued by the LIBRARY over the
+shared-memory stand-in for RCCL instead (the line says which path ran)."""
 import os, sys, tempfile
 import numpy as np
 import torch
@@ -35,7 +37,7 @@ def worker(rank, cfg, port, out):
     torch.cuda.synchronize()
     if rank == 0:
         np.savez(out, grads=d.grads.cpu().numpy(), params=d.params.cpu().numpy(), bn=d.bn.cpu().numpy(), loss=d.loss_value(res["loss_parts"]),
-                 conf=res["conf"].cpu().numpy())
+                 conf=res["conf"].cpu().numpy(), collectives=str(getattr(d, "collectives", "?")))
     comm.barrier()
     dist.destroy_process_group()
 
@@ -67,7 +69,8 @@ def main(n=10, seed=0):
                      params=rel(r["params"], d.params.cpu().numpy()), bn=rel(r["bn"], d.bn.cpu().numpy()),
                      conf=int(np.abs(r["conf"].astype(np.int64) - res["conf"].cpu().numpy().astype(np.int64)).sum()))
             ok = e["loss"] < 1e-5 and e["grads"] < 1.5e-2 and e["params"] < 2e-4 and e["bn"] < 1e-6 and e["conf"] <= 2
-            print("%s %s  loss %.1e grads %.1e params %.1e bn %.1e conf diff %d" % ("ok  " if ok else "FAIL", cfg, e["loss"], e["grads"], e["params"], e["bn"], e["conf"]), flush=True)
+            print("%s %s  loss %.1e grads %.1e params %.1e bn %.1e conf diff %d   [%s]" % ("ok  " if ok else "FAIL", cfg, e["loss"], e["grads"], e["params"], e["bn"], e["conf"],
+                                                                                      str(r["collectives"])[:24]), flush=True)
             nbad += 0 if ok else 1
     print("%d data-parallel cases, %d failed" % (n, nbad))
     sys.exit(1 if nbad else 0)
