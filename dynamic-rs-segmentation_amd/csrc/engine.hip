@@ -808,12 +808,17 @@ static int set_rccl_impl(drs_net_t* n, int world, int rank, void* comm_small, vo
   // asynchronous sums in flight between two waits: one per block (backward sync-BN) + one per two blocks (gradient buckets) + 4
   n->comm_ring = std::max(64, 2 * (int)n->layers.size() + 8);
   n->comm_in_flight = 0;
+  // the collectives' side streams at the LOWEST stream priority: a pool of hardware queues of their own, never the compute stream's
+  // queue nor the filter-gradient stream's (train_step_impl: wg_stream at the highest; there for why)
+  int comm_prio = 0, greatest_prio = 0;
+  if (hipDeviceGetStreamPriorityRange(&comm_prio, &greatest_prio) != hipSuccess) comm_prio = 0;
+  { const char* pe = std::getenv("DRS_WG_STREAM_PRIO"); if (pe && std::atoi(pe) == 1) comm_prio = greatest_prio; else if (pe && std::atoi(pe) == 0) comm_prio = 0; }
   if (n->rccl_buckets) {      // one side stream for the two gradient buckets, three events
     for (auto& e : n->ev_bucket)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return DRS_ERR_HIP;
     if (comm_stream) { n->comm_stream = (hipStream_t)comm_stream; n->own_comm_stream = false; }
     else {
-      if (hipStreamCreateWithFlags(&n->comm_stream, hipStreamNonBlocking) != hipSuccess) return DRS_ERR_HIP;
+      if (hipStreamCreateWithPriority(&n->comm_stream, hipStreamNonBlocking, comm_prio) != hipSuccess) return DRS_ERR_HIP;
       n->own_comm_stream = true;
     }
   }
@@ -821,10 +826,10 @@ static int set_rccl_impl(drs_net_t* n, int world, int rank, void* comm_small, vo
     n->comm_events.resize(2 * (size_t)n->comm_ring);
     for (auto& e : n->comm_events)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return DRS_ERR_HIP;
-    if (hipStreamCreateWithFlags(&n->small_stream, hipStreamNonBlocking) != hipSuccess) return DRS_ERR_HIP;
+    if (hipStreamCreateWithPriority(&n->small_stream, hipStreamNonBlocking, comm_prio) != hipSuccess) return DRS_ERR_HIP;
     if (comm_stream) { n->comm_stream = (hipStream_t)comm_stream; n->own_comm_stream = false; }
     else {
-      if (hipStreamCreateWithFlags(&n->comm_stream, hipStreamNonBlocking) != hipSuccess) return DRS_ERR_HIP;
+      if (hipStreamCreateWithPriority(&n->comm_stream, hipStreamNonBlocking, comm_prio) != hipSuccess) return DRS_ERR_HIP;
       n->own_comm_stream = true;
     }
   }
@@ -977,7 +982,20 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
   if (n->allreduce || n->timing || (n->rccl_small && !n->rccl_inline && !n->rccl_big)) two = false;
   const bool inline_comm = n->rccl_small && n->rccl_inline;
   if (two && !n->wg_stream) {
-    bool ok = hipStreamCreateWithFlags(&n->wg_stream, hipStreamNonBlocking) == hipSuccess;
+    // The filter gradients' stream at ANOTHER stream priority than the caller's -- not for the priority: the runtime keeps a pool of
+    // hardware queues per priority level and deals the streams of a level out to its pool round robin, so a stream of the caller's
+    // level can land on the very queue the compute stream uses.  The two "streams" are then one queue, nothing overlaps and the
+    // cross-stream waits of this pass only add barriers: one stream more or less made before this one decides it (seen with the
+    // collectives' library exchanged, profiles/r05/collectives_wire_time_model.txt: one rank's step 6.83 instead of 6.67 ms at
+    // 16 x 64 x 64, 3.97 instead of 3.71 at S = 45 -- worse than ONE stream).  A stream of another level is never on the compute
+    // stream's queue.  The highest level, the collectives' side streams (set_rccl_impl) the lowest: in-process A/B, no collectives:
+    // highest = a lucky stream of the caller's level, lowest +1.5 % at S = 64; with every all-reduce a real launch both the same.
+    // DRS_WG_STREAM_PRIO (A/B): 0 = the caller's level (as before round 5), 1 = lowest (and the collectives' streams highest).
+    int least = 0, greatest = 0;
+    const char* pe = std::getenv("DRS_WG_STREAM_PRIO");
+    const int arm = pe ? std::atoi(pe) : 2;
+    bool ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
+              hipStreamCreateWithPriority(&n->wg_stream, hipStreamNonBlocking, arm == 0 ? 0 : (arm == 1 ? least : greatest)) == hipSuccess;
     for (int i = 0; ok && i < 2; ++i)
       ok = hipEventCreateWithFlags(&n->ev_gz[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&n->ev_wg[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) return DRS_ERR_HIP;
