@@ -1486,7 +1486,7 @@ int launch_conv_dma(ConvArgs& a, float* ws, size_t ws_floats, hipStream_t st) {
   a.prio = g_conv_prio >= 0 ? g_conv_prio : (g.G && (long long)mt * nt * nks >= 20LL * g.G ? 1 : 0);
   // a launch of the chain the step waits for, beside a filter gradient on a stream of its own (engine.hip sets drs_tl_chain around its
   // two-stream backward pass): the whole launch at the top priority, no lowering by progress
-  if (g_conv_prio < 0 && drs_tl_chain && drs_g_chain_mode >= 1) a.prio = 3;
+  if (g_conv_prio < 0 && drs_chain_level(drs_tl_chain, drs_g_chain_mode) >= 1) a.prio = 3;
   conv_lpt_setup(a, BM, mt, nt, g.G);
   if (g.G) DRS_LAUNCH((conv_dma_kernel<BM, BN, WM, WN, true>), dim3(g.G), dim3(256), 0, st, a);
   else DRS_LAUNCH((conv_dma_kernel<BM, BN, WM, WN, false>), dim3(mt * nt), dim3(256), 0, st, a);
@@ -1560,7 +1560,7 @@ __attribute__((visibility("hidden"))) int drs_step_prep(const StepPrepArgs& a, h
 
 int drs_g_skip_halo_taps = 1;
 thread_local int drs_tl_chain = 0;
-int drs_g_chain_mode = 1;
+int drs_g_chain_mode = -1;
 
 namespace {
 
@@ -1828,7 +1828,7 @@ int drs_debug_conv_trace(void* dev_buffer) { g_conv_trace = (unsigned long long*
 int drs_debug_conv_splitk(int v) { const int old = g_conv_splitk; if (v >= -1) g_conv_splitk = v; return old; }
 int drs_debug_conv_hybrid(int v) { const int old = g_conv_hybrid; if (v >= 0) g_conv_hybrid = v; return old; }
 int drs_debug_conv_sk_order(int v) { const int old = g_conv_sk_order; if (v >= 0) g_conv_sk_order = v; return old; }
-int drs_debug_chain_mode(int v) { const int old = drs_g_chain_mode; if (v >= 0) drs_g_chain_mode = v; return old; }
+int drs_debug_chain_mode(int v) { const int old = drs_g_chain_mode; if (v >= -1) drs_g_chain_mode = v; return old; }
 int drs_debug_conv_prio(int v) { const int old = g_conv_prio; if (v >= -1) g_conv_prio = v; return old; }
 /* the stream-K geometry drs_conv_forward_ws takes for a launch of `tiles` tiles of nks K-steps, N tile bn, with the full workspace:
    out3 = (workgroups, ranges, tiles that are cut); returns the workgroup count (0 = one workgroup per tile) */

@@ -160,9 +160,13 @@ __device__ __forceinline__ void tile_column_stats(float* red, int t, int wm, boo
 
 // Host-side hint, set by the step engine around its two-stream backward pass (engine.hip): the launches this thread enqueues while it
 // is set belong to the chain the step waits for (batch-norm backward -> input gradient) and share the chip with a filter gradient on a
-// stream of its own; their waves then take the top priority (s_setprio 3).  A hint about scheduling only: never changes a result.
-// drs_g_chain_mode (development switch drs_debug_chain_mode): 0 = hint ignored, 1 = the convolution launches, 2 = + the batch-norm
-// backward launches.
+// stream of its own; their waves then take the top priority (s_setprio 3).  1 = the convolution launches (input gradient, stream-K
+// fix-up); 2 = the batch-norm backward launches as well -- what the engine asks for when the step carries collectives: with an
+// all-reduce launch between the statistics and `bn_bwd_apply` of every block the elementwise launches at the top priority win 0.4-2.5 %
+// at every patch side, without collectives they lose 1-4 % from S = 45 (profiles/r05/chain_priority_ab.txt, last block).  A hint
+// about scheduling only: never changes a result.  drs_g_chain_mode (development switch drs_debug_chain_mode): -1 = as the engine
+// asks (default), 0 / 1 / 2 = that level whatever it asks.
+inline int drs_chain_level(int asked, int mode) { return asked == 0 ? 0 : (mode < 0 ? asked : mode); }
 extern thread_local int drs_tl_chain;
 extern int drs_g_chain_mode;
 

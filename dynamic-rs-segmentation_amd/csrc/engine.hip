@@ -1004,7 +1004,7 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
   // two streams: what this thread enqueues on `st` from here to the end of the backward pass is the chain the step waits for, beside
   // the filter gradients on `ws` (drs_common.hpp: its waves take the top priority; the filter gradient's launches clear the hint)
   struct ChainHint { int old; explicit ChainHint(int v) : old(drs_tl_chain) { drs_tl_chain = v; } ~ChainHint() { drs_tl_chain = old; } };
-  ChainHint chain_hint(two ? 1 : 0);
+  ChainHint chain_hint(two ? (collectives(n) ? 2 : 1) : 0);
   // DRS_RCCL_BUCKETS=2 (opt-in until an 8-GPU A/B exists): the gradient buffer as two all-reduces on a side stream with a communicator
   // of its own; everything else as in the inline form
   const bool buckets = inline_comm && n->rccl_buckets && n->rccl_big;

@@ -1505,7 +1505,7 @@ __global__ void confusion_kernel(const unsigned char* __restrict__ labels, const
   }
 }
 
-inline int chain_hp() { return (drs_tl_chain && drs_g_chain_mode >= 2) ? 1 : 0; }
+inline int chain_hp() { return drs_chain_level(drs_tl_chain, drs_g_chain_mode) >= 2 ? 1 : 0; }
 
 inline ActView mkview(float* base, int S, int P, int ld, int coff) {
   ActView v; v.base = base; v.S = S; v.P = P; v.ld = ld; v.coff = coff; v.terms = nullptr; v.nt = 0; return v;

@@ -3,9 +3,9 @@
 An arm is a string of settings: t<-1|0|1> two-stream backward pass (DRS_TWO_STREAMS: a net per value; 9 = the rule),
 w<0|1|2|9> filter gradient's wave priority by remaining work (drs_debug_wgrad_prio; 9 = the rule), c<0|1|3|9> forward /
 input-gradient kernel (drs_debug_conv_prio; 3 = every launch at the top level; 9 = the rule),
-e<0|1|2> the chain of the two-stream backward pass at the top level (drs_debug_chain_mode: 1 input-gradient launches (default), 2 + batch-norm backward),
+e<0|1|2|9> the chain of the two-stream backward pass at the top level (drs_debug_chain_mode: 1 input-gradient launches, 2 + batch-norm backward; 9 = as the engine asks: 1 without collectives, 2 with),
 a<0|1> TIMING EXPERIMENT with wrong sums: the filter gradient reads the un-shifted pixels for every tap (what perfect re-use of X would buy).
-    python tools/ab_step_prio.py [B=16] [S=64,65] [arms=t9w9c9,t9w2c9,...] [steps=20] [rounds=4]"""
+    python tools/ab_step_prio.py [B=16] [S=64,65] [arms=t9w9c9,t9w2c9,...] [steps=20] [rounds=4] [comm=rccl]"""
 import os, re, sys, time
 import numpy as np
 import torch
@@ -21,11 +21,18 @@ from drs_amd.synthetic import make_tile, grid_instances
 def parse(arm):
     kv = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"([twcea])(-?\d+)", arm))
     f = lambda k: -1 if kv.get(k, 9) == 9 else kv[k]
-    return f("t"), f("w"), f("c"), kv.get("e", 1), kv.get("a", 0)
+    return f("t"), f("w"), f("c"), (-1 if kv.get("e", 9) == 9 else kv["e"]), kv.get("a", 0)
 
 
-def main(B=16, Ss=(64,), arms=("t9w9c9",), steps=20, rounds=4):
+def main(B=16, Ss=(64,), arms=("t9w9c9",), steps=20, rounds=4, comm_kind="none"):
     dev = "cuda:0"
+    comm = None
+    if comm_kind == "rccl":      # every collective of the step issued by the library at world 1 (DRS_RCCL_LIB: through that NCCL-API library,
+        # e.g. tools/ubench/nccl_latency_double.hip, whose all-reduces are real launches with a wire time)
+        os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29536", DRS_FORCE_COLLECTIVES="1", DRS_COMM="rccl")
+        from drs_amd.dist import TorchComm
+        torch.cuda.set_device(0)
+        comm = TorchComm("nccl")
     tile, lab = make_tile(1024, 1024, 5, 6, seed=1234)
     pool = P.TilePool([tile], [lab], dev)
     nets = {}
@@ -37,7 +44,7 @@ def main(B=16, Ss=(64,), arms=("t9w9c9",), steps=20, rounds=4):
                 os.environ["DRS_TWO_STREAMS"] = str(t)
             else:
                 os.environ.pop("DRS_TWO_STREAMS", None)
-            nets[t] = DilatedNet("dilated_grsl_rate8", 5, 6, 0.005, b_max=B, s_max=smax, device=dev)
+            nets[t] = DilatedNet("dilated_grsl_rate8", 5, 6, 0.005, b_max=B, s_max=smax, device=dev, comm=comm)
     for S in Ss:
         inst = grid_instances(1024, 1024, S, 25, 4096, seed=0)
         best = {a: [] for a in arms}
@@ -67,11 +74,13 @@ def main(B=16, Ss=(64,), arms=("t9w9c9",), steps=20, rounds=4):
         print("B=%d S=%d  " % (B, S) + "   ".join("%s %.3f (min %.3f)" % (a, float(np.median(v)), min(v)) for a, v in best.items()), flush=True)
     d.drs_debug_wgrad_prio(-1)
     d.drs_debug_conv_prio(-1)
-    d.drs_debug_chain_mode(1)
+    d.drs_debug_chain_mode(-1)
     d.drs_debug_wgrad_ablate(0)
 
 
 if __name__ == "__main__":
     kw = dict(a.split("=") for a in sys.argv[1:])
     main(int(kw.get("B", 16)), [int(v) for v in kw.get("S", "64").split(",")], kw.get("arms", "t9w9c9,t9w1c9,t9w2c9,t9w2c3,t0w9c9,t0w1c9").split(","),
-         int(kw.get("steps", 20)), int(kw.get("rounds", 4)))
+         int(kw.get("steps", 20)), int(kw.get("rounds", 4)), kw.get("comm", "none"))
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
