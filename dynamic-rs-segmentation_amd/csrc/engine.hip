@@ -404,6 +404,15 @@ struct Timed {
 
 #define DRS_TRY(expr) do { const int rc_ = (expr); if (rc_ != DRS_OK) return rc_; } while (0)
 
+// a non-blocking stream at a stream priority of its own (see train_step_impl: a hardware-queue pool apart from the caller's); a runtime
+// that refuses the priority gets a plain stream -- the placement is an optimisation, never a reason to fail a step
+inline hipError_t stream_at_priority(hipStream_t* s, int prio) {
+  (void)hipGetLastError();
+  if (hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio) == hipSuccess) return hipSuccess;
+  (void)hipGetLastError();
+  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
 // every sum over ranks goes through the host's callback; with a callback installed it does so at world == 1 too (an identity there:
 // lets a one-GPU box drive the whole collective path, RCCL included)
 inline bool collectives(const drs_net* n) { return n->world > 1 || n->allreduce != nullptr || n->rccl_small != nullptr; }
@@ -818,7 +827,7 @@ static int set_rccl_impl(drs_net_t* n, int world, int rank, void* comm_small, vo
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return DRS_ERR_HIP;
     if (comm_stream) { n->comm_stream = (hipStream_t)comm_stream; n->own_comm_stream = false; }
     else {
-      if (hipStreamCreateWithPriority(&n->comm_stream, hipStreamNonBlocking, comm_prio) != hipSuccess) return DRS_ERR_HIP;
+      if (stream_at_priority(&n->comm_stream, comm_prio) != hipSuccess) return DRS_ERR_HIP;
       n->own_comm_stream = true;
     }
   }
@@ -826,10 +835,10 @@ static int set_rccl_impl(drs_net_t* n, int world, int rank, void* comm_small, vo
     n->comm_events.resize(2 * (size_t)n->comm_ring);
     for (auto& e : n->comm_events)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return DRS_ERR_HIP;
-    if (hipStreamCreateWithPriority(&n->small_stream, hipStreamNonBlocking, comm_prio) != hipSuccess) return DRS_ERR_HIP;
+    if (stream_at_priority(&n->small_stream, comm_prio) != hipSuccess) return DRS_ERR_HIP;
     if (comm_stream) { n->comm_stream = (hipStream_t)comm_stream; n->own_comm_stream = false; }
     else {
-      if (hipStreamCreateWithPriority(&n->comm_stream, hipStreamNonBlocking, comm_prio) != hipSuccess) return DRS_ERR_HIP;
+      if (stream_at_priority(&n->comm_stream, comm_prio) != hipSuccess) return DRS_ERR_HIP;
       n->own_comm_stream = true;
     }
   }
@@ -994,8 +1003,8 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     int least = 0, greatest = 0;
     const char* pe = std::getenv("DRS_WG_STREAM_PRIO");
     const int arm = pe ? std::atoi(pe) : 2;
-    bool ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
-              hipStreamCreateWithPriority(&n->wg_stream, hipStreamNonBlocking, arm == 0 ? 0 : (arm == 1 ? least : greatest)) == hipSuccess;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+    bool ok = stream_at_priority(&n->wg_stream, arm == 0 ? 0 : (arm == 1 ? least : greatest)) == hipSuccess;
     for (int i = 0; ok && i < 2; ++i)
       ok = hipEventCreateWithFlags(&n->ev_gz[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&n->ev_wg[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) return DRS_ERR_HIP;
