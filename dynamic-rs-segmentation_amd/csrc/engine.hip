@@ -166,6 +166,8 @@ struct drs_net {
   // chain (two alternating gz slabs); created at first use
   hipStream_t wg_stream;
   hipEvent_t ev_gz[2], ev_wg[2];
+  hipEvent_t ev_cls = nullptr;              // two-stream pass: compute stream -> filter-gradient stream (the step has begun; the classifier launch is done)
+  hipEvent_t ev_prep = nullptr;             // ... and back: the step's preparation launch (filter flips, zero fills) is done
   int two_stream_mode;                      // -1 by the rule in train_step_impl, 0 never, 1 always (DRS_TWO_STREAMS)
   // per-slab (B, S) of the pooling call that last zeroed its halo (the halo of a slab one block owns stays zero)
   std::vector<long long> halo_ok;
@@ -609,6 +611,8 @@ void drs_net_destroy(drs_net_t* n) {
   release_rccl(n);
   if (n->wg_stream) {
     for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(n->ev_gz[i]); (void)hipEventDestroy(n->ev_wg[i]); }
+    if (n->ev_cls) (void)hipEventDestroy(n->ev_cls);
+    if (n->ev_prep) (void)hipEventDestroy(n->ev_prep);
     (void)hipStreamDestroy(n->wg_stream);
   }
   for (auto& r : n->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
@@ -925,60 +929,6 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
   const double n_bn = (double)M * n->world;
   const double n_glob = global_pixels > 0 ? global_pixels : n_bn;
   n->comm_in_flight = 0;      // (a step that failed midway must not leave the next one short of event slots)
-  DRS_TRY(forward_layers(n, B, S, true, n_bn, st));
-  float* params = n->p<float>("params");
-  float* grads = n->p<float>("grads");
-  const int nL = (int)n->layers.size();
-  unsigned int* conf = n->p<unsigned int>("conf");
-  {
-    // one launch: the flipped / transposed filters of the input-gradient passes, the confusion matrix zeroed, and the gradients of
-    // the conv biases zeroed (they sit in front of a mean-subtracting batch norm: their gradient is identically zero)
-    StepPrepArgs pa;
-    pa.n = 0;
-    for (int i = 1; i < nL; ++i) {
-      const Layer& L = n->layers[i];
-      if (pa.n == STEP_PREP_MAX) {                       // (deeper nets than any of the reference's: the rest one by one)
-        DRS_TRY(drs_filter_flip_transpose(params + L.w_off, n->p<float>("wt" + std::to_string(i)), L.k, L.cin, L.cout, st));
-        continue;
-      }
-      pa.w[pa.n] = params + L.w_off; pa.wt[pa.n] = n->p<float>("wt" + std::to_string(i));
-      pa.k[pa.n] = L.k; pa.cin[pa.n] = L.cin; pa.cout[pa.n] = L.cout;
-      ++pa.n;
-    }
-    pa.z0 = conf; pa.nz0 = n->K * n->K;
-    pa.z1 = grads + n->first_bias; pa.nz1 = (int)(n->cls_b - n->first_bias);
-    DRS_TRY(drs_step_prep(pa, st));
-  }
-  // classifier + loss + gradient wrt the features
-  const Slab& f = n->slabs[n->feat];
-  float* gfeat = n->p<float>("gact:" + f.name);
-  double* scalars = n->p<double>("scalars");
-  double* scratch = n->p<double>("colsum_scratch");
-  {
-    Timed t(n, st, K_CLS, M * n->c_last * 8.0);
-    DRS_TRY(drs_classifier_loss(n->p<float>("act:" + f.name), B, S, f.P, f.C, 0, n->c_last, n->K, params + n->cls_w, params + n->cls_b,
-                                n->p<unsigned char>("labels"), (flags & DRS_USE_LOSS_MASK) ? n->p<unsigned char>("loss_mask") : nullptr,
-                                (flags & DRS_USE_ACC_MASK) ? n->p<unsigned char>("acc_mask") : nullptr, (float)(1.0 / n_glob),
-                                (flags & DRS_WANT_LOGITS) ? n->p<float>("logits") : nullptr, n->p<unsigned char>("pred"), gfeat, f.C, 0,
-                                n->p<float>("dw_partial"), n->p<float>("db_partial"), n->p<double>("loss_partial"), conf, st));
-  }
-  const int crow = drs_classifier_rows(B, S);
-  DRS_TRY(drs_rows_reduce_f32(n->p<float>("dw_partial"), crow, n->c_last * n->K, grads + n->cls_w, scratch, st));
-  DRS_TRY(drs_rows_reduce_f32(n->p<float>("db_partial"), crow, n->K, grads + n->cls_b, scratch, st));
-  DRS_TRY(drs_sum_f64(n->p<double>("loss_partial"), crow, scalars, st));
-  DRS_TRY(drs_l2_loss(params, n->n_decay, n->p<double>("l2_scratch"), scalars + 1, st));
-  // gradient all-reduce in buckets that overlap the rest of the backward pass: kernel gradients go as their layers finish, last
-  // layers first; the small classifier / SE / bias tail goes last
-  std::vector<int> pending;
-  size_t bucket_hi = n->cls_w;
-  std::vector<char> written(n->slabs.size(), 0);
-  written[n->feat] = 1;
-  float* gzb[2] = {n->p<float>("gz"), n->p<float>("gz2")};
-  float* gxh = n->p<float>("gxh");
-  float* partial = n->p<float>("partial");
-  double* sums = n->p<double>("sums");
-  float* bwd_means = n->p<float>("bwd_means");
-
   // Small steps (the per-rank batches of data parallelism) run every convolution launch as one round: the chip drains and refills
   // between two dependent kernels.  The filter gradient of block i+1 depends only on that block's gz, so it goes to a stream of its
   // own and runs beside the batch-norm backward / input gradient of block i (two gz slabs in turn): its workgroups fill the CUs the
@@ -1007,9 +957,87 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     bool ok = stream_at_priority(&n->wg_stream, arm == 0 ? 0 : (arm == 1 ? least : greatest)) == hipSuccess;
     for (int i = 0; ok && i < 2; ++i)
       ok = hipEventCreateWithFlags(&n->ev_gz[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&n->ev_wg[i], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&n->ev_cls, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&n->ev_prep, hipEventDisableTiming) == hipSuccess;
     if (!ok) return DRS_ERR_HIP;
   }
   hipStream_t ws = two ? n->wg_stream : st;       // the stream the filter gradients run on
+  float* params = n->p<float>("params");
+  float* grads = n->p<float>("grads");
+  const int nL = (int)n->layers.size();
+  unsigned int* conf = n->p<unsigned int>("conf");
+  // one launch: the flipped / transposed filters of the input-gradient passes, the confusion matrix zeroed, and the gradients of
+  // the conv biases zeroed (they sit in front of a mean-subtracting batch norm: their gradient is identically zero).  Nothing of
+  // the forward pass needs it: with two streams it runs on the filter-gradient stream BESIDE the forward pass (behind everything
+  // the compute stream held when the step began), and the classifier waits for it
+  auto step_prep = [&](hipStream_t sp) -> int {
+    StepPrepArgs pa;
+    pa.n = 0;
+    for (int i = 1; i < nL; ++i) {
+      const Layer& L = n->layers[i];
+      if (pa.n == STEP_PREP_MAX) {                       // (deeper nets than any of the reference's: the rest one by one)
+        DRS_TRY(drs_filter_flip_transpose(params + L.w_off, n->p<float>("wt" + std::to_string(i)), L.k, L.cin, L.cout, sp));
+        continue;
+      }
+      pa.w[pa.n] = params + L.w_off; pa.wt[pa.n] = n->p<float>("wt" + std::to_string(i));
+      pa.k[pa.n] = L.k; pa.cin[pa.n] = L.cin; pa.cout[pa.n] = L.cout;
+      ++pa.n;
+    }
+    pa.z0 = conf; pa.nz0 = n->K * n->K;
+    pa.z1 = grads + n->first_bias; pa.nz1 = (int)(n->cls_b - n->first_bias);
+    DRS_TRY(drs_step_prep(pa, sp));
+    return DRS_OK;
+  };
+  const bool side_jobs = two && std::getenv("DRS_REDUCTIONS_ON_CHAIN") == nullptr;      // (A/B: DRS_REDUCTIONS_ON_CHAIN=1 keeps them on `st`, as before round 5)
+  if (side_jobs) {
+    if (hipEventRecord(n->ev_cls, st) != hipSuccess || hipStreamWaitEvent(ws, n->ev_cls, 0) != hipSuccess) return DRS_ERR_HIP;
+    DRS_TRY(step_prep(ws));
+    if (hipEventRecord(n->ev_prep, ws) != hipSuccess) return DRS_ERR_HIP;
+  }
+  DRS_TRY(forward_layers(n, B, S, true, n_bn, st));
+  if (side_jobs) { if (hipStreamWaitEvent(st, n->ev_prep, 0) != hipSuccess) return DRS_ERR_HIP; }
+  else DRS_TRY(step_prep(st));
+  // classifier + loss + gradient wrt the features
+  const Slab& f = n->slabs[n->feat];
+  float* gfeat = n->p<float>("gact:" + f.name);
+  double* scalars = n->p<double>("scalars");
+  double* scratch = n->p<double>("colsum_scratch");
+  {
+    Timed t(n, st, K_CLS, M * n->c_last * 8.0);
+    DRS_TRY(drs_classifier_loss(n->p<float>("act:" + f.name), B, S, f.P, f.C, 0, n->c_last, n->K, params + n->cls_w, params + n->cls_b,
+                                n->p<unsigned char>("labels"), (flags & DRS_USE_LOSS_MASK) ? n->p<unsigned char>("loss_mask") : nullptr,
+                                (flags & DRS_USE_ACC_MASK) ? n->p<unsigned char>("acc_mask") : nullptr, (float)(1.0 / n_glob),
+                                (flags & DRS_WANT_LOGITS) ? n->p<float>("logits") : nullptr, n->p<unsigned char>("pred"), gfeat, f.C, 0,
+                                n->p<float>("dw_partial"), n->p<float>("db_partial"), n->p<double>("loss_partial"), conf, st));
+  }
+  // the classifier's slab reductions (its kernel / bias gradients, the cross-entropy sum) and the L2 term: seven launches of ~5 us that
+  // nothing needs before the end of the step -- in the two-stream backward pass they go to the filter-gradient stream (below), off
+  // the chain the step waits for
+  const int crow = drs_classifier_rows(B, S);
+  auto slab_reductions = [&](hipStream_t s) -> int {
+    DRS_TRY(drs_rows_reduce_f32(n->p<float>("dw_partial"), crow, n->c_last * n->K, grads + n->cls_w, scratch, s));
+    DRS_TRY(drs_rows_reduce_f32(n->p<float>("db_partial"), crow, n->K, grads + n->cls_b, scratch, s));
+    DRS_TRY(drs_sum_f64(n->p<double>("loss_partial"), crow, scalars, s));
+    DRS_TRY(drs_l2_loss(params, n->n_decay, n->p<double>("l2_scratch"), scalars + 1, s));
+    return DRS_OK;
+  };
+  // gradient all-reduce in buckets that overlap the rest of the backward pass: kernel gradients go as their layers finish, last
+  // layers first; the small classifier / SE / bias tail goes last
+  std::vector<int> pending;
+  size_t bucket_hi = n->cls_w;
+  std::vector<char> written(n->slabs.size(), 0);
+  written[n->feat] = 1;
+  float* gzb[2] = {n->p<float>("gz"), n->p<float>("gz2")};
+  float* gxh = n->p<float>("gxh");
+  float* partial = n->p<float>("partial");
+  double* sums = n->p<double>("sums");
+  float* bwd_means = n->p<float>("bwd_means");
+
+  if (side_jobs) {
+    if (hipEventRecord(n->ev_cls, st) != hipSuccess || hipStreamWaitEvent(ws, n->ev_cls, 0) != hipSuccess) return DRS_ERR_HIP;
+    DRS_TRY(slab_reductions(ws));           // (the step joins `ws` before it reads the gradient buffer or the loss: the filter gradients' events)
+  } else {
+    DRS_TRY(slab_reductions(st));
+  }
   // two streams: what this thread enqueues on `st` from here to the end of the backward pass is the chain the step waits for, beside
   // the filter gradients on `ws` (drs_common.hpp: its waves take the top priority; the filter gradient's launches clear the hint)
   struct ChainHint { int old; explicit ChainHint(int v) : old(drs_tl_chain) { drs_tl_chain = v; } ~ChainHint() { drs_tl_chain = old; } };

@@ -4,6 +4,7 @@ An arm is a string of settings: t<-1|0|1> two-stream backward pass (DRS_TWO_STRE
 w<0|1|2|9> filter gradient's wave priority by remaining work (drs_debug_wgrad_prio; 9 = the rule), c<0|1|3|9> forward /
 input-gradient kernel (drs_debug_conv_prio; 3 = every launch at the top level; 9 = the rule),
 e<0|1|2|9> the chain of the two-stream backward pass at the top level (drs_debug_chain_mode: 1 input-gradient launches, 2 + batch-norm backward; 9 = as the engine asks: 1 without collectives, 2 with),
+r<0|1> the classifier's slab reductions on the filter-gradient stream (0, default) or on the chain as before round 5 (1),
 a<0|1> TIMING EXPERIMENT with wrong sums: the filter gradient reads the un-shifted pixels for every tap (what perfect re-use of X would buy).
     python tools/ab_step_prio.py [B=16] [S=64,65] [arms=t9w9c9,t9w2c9,...] [steps=20] [rounds=4] [comm=rccl]"""
 import os, re, sys, time
@@ -19,9 +20,9 @@ from drs_amd.synthetic import make_tile, grid_instances
 
 
 def parse(arm):
-    kv = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"([twcea])(-?\d+)", arm))
+    kv = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"([twcear])(-?\d+)", arm))
     f = lambda k: -1 if kv.get(k, 9) == 9 else kv[k]
-    return f("t"), f("w"), f("c"), (-1 if kv.get("e", 9) == 9 else kv["e"]), kv.get("a", 0)
+    return f("t"), f("w"), f("c"), (-1 if kv.get("e", 9) == 9 else kv["e"]), kv.get("a", 0), kv.get("r", 0)
 
 
 def main(B=16, Ss=(64,), arms=("t9w9c9",), steps=20, rounds=4, comm_kind="none"):
@@ -50,12 +51,16 @@ def main(B=16, Ss=(64,), arms=("t9w9c9",), steps=20, rounds=4, comm_kind="none")
         best = {a: [] for a in arms}
         for r in range(rounds + 1):
             for a in arms:
-                t, w, c, e, ab = parse(a)
+                t, w, c, e, ab, rc = parse(a)
                 net = nets[t]
                 d.drs_debug_wgrad_prio(w)
                 d.drs_debug_conv_prio(c)
                 d.drs_debug_chain_mode(e)
                 d.drs_debug_wgrad_ablate(ab)
+                if rc:
+                    os.environ["DRS_REDUCTIONS_ON_CHAIN"] = "1"
+                else:
+                    os.environ.pop("DRS_REDUCTIONS_ON_CHAIN", None)
                 np.random.seed(0)
                 def step(i):
                     rows = inst[(i * B) % 4000:(i * B) % 4000 + B]
