@@ -208,11 +208,23 @@ def test_two_ranks_at_a_real_per_rank_shape_follow_the_decision_aligned_oracle(t
             assert rel(fin[n], o.p[n]) < 1e-5, n
 
 
+def _build_latency_double(tmp):
+    """tools/ubench/nccl_latency_double.hip: a world-1 stand-in for RCCL whose all-reduces are REAL launches on the stream they are given
+    (real RCCL launches nothing for a sum over one rank), each holding its stream for a wire time"""
+    import subprocess
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "ubench", "nccl_latency_double.hip")
+    out = os.path.join(str(tmp), "libnccl_latency_double.so")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", src, "-o", out], check=True)
+    return out
+
+
 def _rccl_worker(rank, world, port, out, mode):
     """ONE rank on the real backend ('nccl' = RCCL) with every collective of the step forced on (sums over one rank are identities):
     communicator bound to the device, asynchronous gradient buckets, sync-BN sums, stream waits -- the code an 8-GPU run executes."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", DRS_FORCE_COLLECTIVES="1",
-                      DRS_COMM={"rccl": "rccl", "callback": "torch", "op": "torch"}[mode])
+                      DRS_COMM={"rccl": "rccl", "launches": "rccl", "callback": "torch", "op": "torch"}[mode])
+    if mode == "launches":      # every sum a real launch with 20 us of wire time in the stream it is issued on (the library binds DRS_RCCL_LIB)
+        os.environ.update(DRS_RCCL_LIB=os.path.join(os.path.dirname(out), "libnccl_latency_double.so"), NCCL_DOUBLE_ALPHA_US="20", NCCL_DOUBLE_GBS="100")
     engine = mode != "op"
     import torch.distributed as dist
     from drs_amd.dist import TorchComm
@@ -231,7 +243,7 @@ def _rccl_worker(rank, world, port, out, mode):
         res = d.train_step(B, S, 0.01)
         losses.append(d.loss_value(res["loss_parts"]))
     torch.cuda.synchronize()
-    if mode == "rccl":       # the library issued every sum itself (drs_net_set_rccl): nothing came back into Python
+    if mode in ("rccl", "launches"):       # the library issued every sum itself (drs_net_set_rccl): nothing came back into Python
         assert d.collectives.startswith("rccl") and not calls
     else:
         assert len(calls) >= 3 * 3, calls                   # gradient buckets and backward BN sums went through the communicator
@@ -241,11 +253,14 @@ def _rccl_worker(rank, world, port, out, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["rccl", "callback", "op"], ids=["step-level-library-rccl", "step-level-callback", "op-level"])
+@pytest.mark.parametrize("mode", ["rccl", "launches", "callback", "op"],
+                         ids=["step-level-library-rccl", "step-level-library-sums-as-real-launches", "step-level-callback", "op-level"])
 def test_rccl_collectives_at_world_one_leave_the_step_unchanged(tmp_path, mode):
     from drs_amd.net import DilatedNet
     engine = mode != "op"
     out = str(tmp_path / "rccl.npz")
+    if mode == "launches":
+        _build_latency_double(tmp_path)
     mp.spawn(_rccl_worker, args=(1, 29700 + os.getpid() % 1000, out, mode), nprocs=1, join=True)
     x, y = _inputs()
     d = DilatedNet(NET, CH, K, 0.005, b_max=B, s_max=S, device="cuda:0", seed=3, engine=engine)
