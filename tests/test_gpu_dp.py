@@ -280,10 +280,12 @@ def test_rccl_collectives_at_world_one_leave_the_step_unchanged(tmp_path, mode):
     print("RCCL world-1 run vs no communicator: params bitwise equal = %s" % np.array_equal(r["params"], d.params.cpu().numpy()))
 
 
-def _rccl_forms_worker(rank, world, port, out):
+def _rccl_forms_worker(rank, world, port, out, lib=None):
     """every form of the library-side collectives (drs_rccl_form: inline, asynchronous, inline + two overlapped gradient buckets) x the
     one- and two-stream backward pass, in ONE process on the real backend at world 1 with every collective forced on"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", DRS_FORCE_COLLECTIVES="1", DRS_COMM="rccl")
+    if lib:      # every sum a real launch that holds its stream for 30 us and keeps NaNs in the buffer meanwhile (nccl_latency_double.hip)
+        os.environ.update(DRS_RCCL_LIB=lib, NCCL_DOUBLE_ALPHA_US="30", NCCL_DOUBLE_GBS="50", NCCL_DOUBLE_POISON="1")
     import torch.distributed as dist
     from drs_amd import _lib
     from drs_amd.dist import TorchComm
@@ -316,13 +318,20 @@ def _rccl_forms_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_every_form_of_the_library_side_collectives_gives_the_inline_forms_bits(tmp_path):
+@pytest.mark.parametrize("transport", ["rccl", "poisoned-in-flight"])
+def test_every_form_of_the_library_side_collectives_gives_the_inline_forms_bits(tmp_path, transport):
     """the asynchronous form is reachable only through DRS_RCCL_ASYNC and no test set it; r05 adds DRS_RCCL_BUCKETS.  Sums over
     one rank are identities and every form issues the same kernels on the same operands, so variables, moving statistics, loss and
-    confusion matrix after three steps must be the inline form's bit for bit -- with the one- and the two-stream backward pass."""
+    confusion matrix after three steps must be the inline form's bit for bit -- with the one- and the two-stream backward pass.
+    Real RCCL launches nothing for a sum over one rank, so with it a missing cross-stream hand-over could not show; the second
+    transport (tools/ubench/nccl_latency_double.hip, NCCL_DOUBLE_POISON) makes every sum three launches on the stream it is given --
+    save the buffer and fill it with NaNs, 30 us + of wire time, restore: a consumer not ordered behind the collective reads NaNs, a
+    producer not ordered in front of it is overwritten by the stale copy.  The one-stream inline form has no hand-over to miss."""
     out = str(tmp_path / "forms.npz")
-    mp.spawn(_rccl_forms_worker, args=(1, 29750 + os.getpid() % 1000, out), nprocs=1, join=True)
+    lib = _build_latency_double(tmp_path) if transport != "rccl" else None
+    mp.spawn(_rccl_forms_worker, args=(1, 29750 + os.getpid() % 1000, out, lib), nprocs=1, join=True)
     r = np.load(out)
+    assert np.all(np.isfinite(r["inline_0_params"])) and np.all(np.isfinite(r["inline_0_loss"]))
     for form in ("inline", "async", "buckets", "async_word"):
         for two in ("0", "1"):
             for what in ("params", "bn", "conf", "loss"):
