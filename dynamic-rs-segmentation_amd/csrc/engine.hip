@@ -406,6 +406,30 @@ struct Timed {
 
 #define DRS_TRY(expr) do { const int rc_ = (expr); if (rc_ != DRS_OK) return rc_; } while (0)
 
+#ifdef DRS_DEV
+// Schedule fuzzing (development library, drs_debug_jitter): a launch that sleeps, put on one of the step's streams at the points where
+// they hand work to each other -- up to 150 us, one time in eight up to 4 ms (the slack some hand-overs have: the step's preparation
+// launch is needed a whole forward pass after it was issued).  It moves every cross-stream dependency of the two-stream pass off its
+// usual timing: a missing event wait that the usual timing hides becomes a different result
+// (tests/test_gpu_determinism.py::test_sleeps_on_the_steps_streams_do_not_change_a_bit holds the jittered steps to the unjittered bits).
+__global__ void jitter_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+unsigned long long g_jitter_state = 0;      // 0 = off
+inline void jitter(hipStream_t s) {
+  if (!g_jitter_state) return;
+  g_jitter_state = g_jitter_state * 6364136223846793005ull + 1442695040888963407ull;
+  const unsigned r = (unsigned)(g_jitter_state >> 36);
+  if (!(r & 1)) return;
+  const unsigned span = ((r >> 1) & 7) == 0 ? 400000u : 15000u;      // 100 MHz ticks
+  hipLaunchKernelGGL(jitter_kernel, dim3(1), dim3(64), 0, s, (long long)((r >> 4) % span));
+}
+#define DRS_JITTER(s) jitter(s)
+#else
+#define DRS_JITTER(s) do { } while (0)
+#endif
+
 // a non-blocking stream at a stream priority of its own (see train_step_impl: a hardware-queue pool apart from the caller's); a runtime
 // that refuses the priority gets a plain stream -- the placement is an optimisation, never a reason to fail a step
 inline hipError_t stream_at_priority(hipStream_t* s, int prio) {
@@ -561,6 +585,10 @@ bool all_bound(const drs_net* n) {
 }  // namespace
 
 extern "C" {
+
+#ifdef DRS_DEV
+int drs_debug_jitter(unsigned long long seed) { g_jitter_state = seed; return 0; }
+#endif
 
 int drs_net_create(const char* net_type, int channels, int num_classes, float weight_decay, int b_max, int s_max, int bessel_moving_var,
                    float lr_decay_factor, drs_net_t** out) {
@@ -990,11 +1018,17 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
   const bool side_jobs = two && std::getenv("DRS_REDUCTIONS_ON_CHAIN") == nullptr;      // (A/B: DRS_REDUCTIONS_ON_CHAIN=1 keeps them on `st`, as before round 5)
   if (side_jobs) {
     if (hipEventRecord(n->ev_cls, st) != hipSuccess || hipStreamWaitEvent(ws, n->ev_cls, 0) != hipSuccess) return DRS_ERR_HIP;
+    DRS_JITTER(ws);
     DRS_TRY(step_prep(ws));
     if (hipEventRecord(n->ev_prep, ws) != hipSuccess) return DRS_ERR_HIP;
   }
   DRS_TRY(forward_layers(n, B, S, true, n_bn, st));
-  if (side_jobs) { if (hipStreamWaitEvent(st, n->ev_prep, 0) != hipSuccess) return DRS_ERR_HIP; }
+#ifdef DRS_DEV
+  const bool skip_prep_wait = std::getenv("DRS_MUTATE_SKIP_PREP_WAIT") != nullptr;      // (the check of the check: profiles/r05/NOTES.md)
+#else
+  const bool skip_prep_wait = false;
+#endif
+  if (side_jobs) { if (!skip_prep_wait && hipStreamWaitEvent(st, n->ev_prep, 0) != hipSuccess) return DRS_ERR_HIP; }
   else DRS_TRY(step_prep(st));
   // classifier + loss + gradient wrt the features
   const Slab& f = n->slabs[n->feat];
@@ -1034,6 +1068,7 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
 
   if (side_jobs) {
     if (hipEventRecord(n->ev_cls, st) != hipSuccess || hipStreamWaitEvent(ws, n->ev_cls, 0) != hipSuccess) return DRS_ERR_HIP;
+    DRS_JITTER(ws);
     DRS_TRY(slab_reductions(ws));           // (the step joins `ws` before it reads the gradient buffer or the loss: the filter gradients' events)
   } else {
     DRS_TRY(slab_reductions(st));
@@ -1066,6 +1101,7 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     const Slab& in = n->slabs[L.src];
     ChainHint not_chain(0);
     if (two && hipStreamWaitEvent(ws, n->ev_gz[i & 1], 0) != hipSuccess) return DRS_ERR_HIP;      // block i's gz is written
+    if (two) DRS_JITTER(ws);
     {
       Timed t(n, ws, K_CONV_WGRAD, 2.0 * M * L.k * L.k * L.cin * L.cout);
       DRS_TRY(drs_conv_wgrad(n->p<float>("act:" + in.name), B, S, in.P, in.C, 0, gzb[two ? (i & 1) : 0], L.halo, L.cout, 0, L.k, L.rate, L.pad_b, L.cin_k,
@@ -1133,6 +1169,7 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     DRS_TRY(wait_handles(n, {h_bn}, st));
     float* gz = gzb[two ? (i & 1) : 0];
     if (two && i + 2 < nL && hipStreamWaitEvent(st, n->ev_wg[i & 1], 0) != hipSuccess) return DRS_ERR_HIP;   // block i+2's filter gradient has read this slab
+    if (two) DRS_JITTER(st);
     {
       Timed t(n, st, K_BN_BWD_APPLY, M * L.cout * 12.0);
       if (means_form) DRS_TRY(drs_bn_backward_apply_means(gxh, z, B, S, L.cout, mr, bwd_means, gz, L.halo, L.cout, 0, st));

@@ -49,6 +49,40 @@ def test_two_runs_of_a_mixed_size_training_loop_agree_bit_for_bit(B, sizes, step
     assert np.array_equal(s1, s2)
 
 
+def _jitter_worker(seed, out):
+    """one process on the development library (the same sources + include/drs_dev.h): the mixed-size loop with sleeps of 0 .. 150 us put on
+    the step's streams where they hand work to each other (drs_debug_jitter; 0 = none)"""
+    from drs_amd import _lib
+    from drs_amd import patches as P
+    from drs_amd.synthetic import make_tile
+    d = _lib.dev()
+    _lib._lib = d.lib
+    d.drs_debug_jitter(seed)
+    tile, lab = make_tile(512, 512, 5, 6, seed=1234)
+    pool = P.TilePool([tile], [lab], DEV)
+    losses, state = _run(16, 60, (25, 33, 45, 61, 64), pool)
+    np.savez(out, losses=losses, state=state)
+
+
+def test_sleeps_on_the_steps_streams_do_not_change_a_bit(tmp_path):
+    """Schedule fuzzing of the two-stream training step (r05: its preparation launch beside the forward pass, the classifier's slab
+    reductions, the filter gradients and the chain at wave priorities of their own all hand work across streams): random sleeps at every
+    hand-over move each cross-stream dependency off its usual timing; a missing event wait that the usual timing hides would change the
+    result.  Two seeds of sleeps against none: every loss and every variable bit for bit."""
+    import torch.multiprocessing as mp
+    outs = []
+    for seed in (0, 12345, 987654321):
+        out = str(tmp_path / ("jitter%d.npz" % seed))
+        ctx = mp.get_context("spawn")
+        pr = ctx.Process(target=_jitter_worker, args=(seed, out))
+        pr.start(); pr.join()
+        assert pr.exitcode == 0
+        outs.append(np.load(out))
+    assert np.isfinite(outs[0]["losses"]).all()
+    for o in outs[1:]:
+        assert np.array_equal(o["losses"], outs[0]["losses"]) and np.array_equal(o["state"], outs[0]["state"])
+
+
 KEEP = ("params", "momentum", "bn", "labels", "acc_mask", "loss_mask", "w0pad")
 
 
