@@ -1113,6 +1113,7 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
       pending.push_back(h);
       bucket_hi = L.w_off;
     }
+    if (two) DRS_JITTER(ws);
     if (two && hipEventRecord(n->ev_wg[i & 1], ws) != hipSuccess) return DRS_ERR_HIP;             // this gz slab may be rewritten
     if (buckets && i == bucket_layer && i > 0) {
       // first bucket: the kernels of blocks bucket_layer .. last (Dilated8Pooling: conv5 .. conv8, 76 % of the gradient bytes), summed on the
@@ -1176,6 +1177,7 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
       else DRS_TRY(drs_bn_backward_apply(gxh, z, B, S, L.cout, mr, sums, n_bn, gz, L.halo, L.cout, 0, st));
     }
     if (two && hipEventRecord(n->ev_gz[i & 1], st) != hipSuccess) return DRS_ERR_HIP;
+    if (two) DRS_JITTER(st);
     if (L.src != 0) {
       const Slab& in = n->slabs[L.src];
       const int acc = written[L.src] ? 1 : 0;
