@@ -1023,12 +1023,7 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     if (hipEventRecord(n->ev_prep, ws) != hipSuccess) return DRS_ERR_HIP;
   }
   DRS_TRY(forward_layers(n, B, S, true, n_bn, st));
-#ifdef DRS_DEV
-  const bool skip_prep_wait = std::getenv("DRS_MUTATE_SKIP_PREP_WAIT") != nullptr;      // (the check of the check: profiles/r05/NOTES.md)
-#else
-  const bool skip_prep_wait = false;
-#endif
-  if (side_jobs) { if (!skip_prep_wait && hipStreamWaitEvent(st, n->ev_prep, 0) != hipSuccess) return DRS_ERR_HIP; }
+  if (side_jobs) { if (hipStreamWaitEvent(st, n->ev_prep, 0) != hipSuccess) return DRS_ERR_HIP; }
   else DRS_TRY(step_prep(st));
   // classifier + loss + gradient wrt the features
   const Slab& f = n->slabs[n->feat];
