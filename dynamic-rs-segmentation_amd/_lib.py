@@ -80,6 +80,7 @@ SIGNATURES = {
     "drs_net_global_step": (C.c_longlong, [_p, C.c_longlong]),
     "drs_net_learning_rate": (_f, [_p, _f]),
     "drs_net_set_comm": (_i, [_p, _i, _i, _p, _p, _p]),
+    "drs_rccl_bind_library": (_i, [C.c_char_p]),
     "drs_rccl_available": (_i, []),
     "drs_rccl_form": (_i, []),
     "drs_rccl_unique_id": (_i, [_p]),
@@ -90,6 +91,7 @@ SIGNATURES = {
     "drs_train_step": (_i, [_p, _i, _i, _f, _i, _d, _p]),
     "drs_forward": (_i, [_p, _i, _i, _i, _i, _p]),
     "drs_apply_update": (_i, [_p, _f, _p]),
+    "drs_net_set_two_streams": (_i, [_p, _i]),
     "drs_net_timing": (_i, [_p, _i]),
     "drs_net_num_timing_kinds": (_i, []),
     "drs_net_timing_summary": (_i, [_p, _i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_d), C.POINTER(_d)]),
@@ -106,7 +108,7 @@ DEV_SIGNATURES = {
     "drs_debug_conv_splitk": (_i, [_i]), "drs_debug_conv_hybrid": (_i, [_i]), "drs_debug_conv_sk_order": (_i, [_i]), "drs_debug_conv_prio": (_i, [_i]),
     "drs_debug_conv_sk_geometry": (_i, [_i, _i, _i, _p]), "drs_debug_conv_trace": (_i, [_p]), "drs_debug_conv_lpt": (_i, [_i]), "drs_debug_conv_order": (_i, [_i] * 7 + [_p, _i]),
     "drs_debug_wgrad_variant": (_i, [_i]), "drs_debug_wgrad_seg": (_i, [_i]), "drs_debug_wgrad_balance": (_i, [_i]), "drs_debug_wgrad_target": (_i, [_i]),
-    "drs_debug_wgrad_target_big": (_i, [_i]), "drs_debug_wgrad_len": (_i, [_i]), "drs_debug_wgrad_minchunks": (_i, [_i]), "drs_debug_wgrad_model": (_i, [_i]), "drs_debug_wgrad_ablate": (_i, [_i]), "drs_debug_wgrad_prio": (_i, [_i]), "drs_debug_cls_variant": (_i, [_i]), "drs_debug_slide_blocks": (_i, [_i]), "drs_debug_slide_minrows": (_i, [_i]), "drs_debug_slide_rowpad": (_i, [_i]), "drs_debug_chain_mode": (_i, [_i]), "drs_debug_jitter": (_i, [C.c_ulonglong]), "drs_debug_variant": (_i, [_i]),
+    "drs_debug_wgrad_target_big": (_i, [_i]), "drs_debug_wgrad_len": (_i, [_i]), "drs_debug_wgrad_minchunks": (_i, [_i]), "drs_debug_wgrad_model": (_i, [_i]), "drs_debug_wgrad_ablate": (_i, [_i]), "drs_debug_wgrad_prio": (_i, [_i]), "drs_debug_cls_variant": (_i, [_i]), "drs_debug_slide_blocks": (_i, [_i]), "drs_debug_slide_minrows": (_i, [_i]), "drs_debug_slide_rowpad": (_i, [_i]), "drs_debug_chain_mode": (_i, [_i]), "drs_debug_jitter": (_i, [C.c_ulonglong]), "drs_debug_wg_stream_prio": (_i, [_i]), "drs_debug_reductions_on_chain": (_i, [_i]), "drs_debug_variant": (_i, [_i]),
     "drs_debug_wgrad_cut": (_i, [_i] * 7 + [_p, _i, _p, _p]),
 }
 

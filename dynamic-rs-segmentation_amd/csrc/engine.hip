@@ -129,6 +129,25 @@ const char* const kKindNames[K_NKIND] = {"conv_fwd", "conv_dgrad", "conv_wgrad",
                                          "allreduce_syncbn", "allreduce_grad", "allreduce_scalars"};
 struct TimeRec { int kind; double work; hipEvent_t e0, e1; };
 
+// Device pointers of the bound buffers, looked up by name ONCE (resolve(), after the last drs_net_bind) -- a step is ~130 launches
+// of a few microseconds of host time each at the per-rank sizes, so its enqueue path does no string building and no map lookup.
+struct LayerPtrs {
+  float* z; float* mean_rstd; unsigned char* idx; float* wt;      // raw conv output, (mean, rstd), pool arg-max codes, flipped filter
+  const float* w;                                                 // the filter the forward pass multiplies by (conv1: the padded copy)
+  float* act_in; float* act_out; float* gact_in; float* gact_out; // slabs this block reads / writes and their gradients
+  float *se_act, *se_s, *se_e1, *se_e2;                           // squeeze-and-excitation state of the block (or null)
+};
+struct Ptrs {
+  bool ok = false;
+  float *params, *grads, *momentum, *bn, *partial, *gxh, *gz[2], *slab, *w0pad, *conv_ws, *bwd_means, *act, *gpool, *se_scratch;
+  float *dw_partial, *db_partial, *logits, *feat_act, *feat_gact;
+  size_t conv_ws_floats;
+  double *sums, *scalars, *colsum_scratch, *loss_partial, *l2_scratch;
+  unsigned char *pred, *labels, *acc_mask, *loss_mask;
+  unsigned int* conf;
+  std::vector<LayerPtrs> L;
+};
+
 }  // namespace
 
 struct drs_net {
@@ -168,10 +187,11 @@ struct drs_net {
   hipEvent_t ev_gz[2], ev_wg[2];
   hipEvent_t ev_cls = nullptr;              // two-stream pass: compute stream -> filter-gradient stream (the step has begun; the classifier launch is done)
   hipEvent_t ev_prep = nullptr;             // ... and back: the step's preparation launch (filter flips, zero fills) is done
-  int two_stream_mode;                      // -1 by the rule in train_step_impl, 0 never, 1 always (DRS_TWO_STREAMS)
+  int two_stream_mode;                      // -1 by the rule in train_step_impl, 0 never, 1 always (drs_net_set_two_streams)
   // per-slab (B, S) of the pooling call that last zeroed its halo (the halo of a slab one block owns stays zero)
   std::vector<long long> halo_ok;
   bool timing;
+  Ptrs ptrs;
   std::vector<TimeRec> recs;
   std::vector<hipEvent_t> pool_events;
 
@@ -417,6 +437,8 @@ __global__ void jitter_kernel(long long ticks) {
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 unsigned long long g_jitter_state = 0;      // 0 = off
+int g_wg_stream_prio = 2;                   // drs_debug_wg_stream_prio: the filter-gradient stream's priority arm (2 = the product's: highest)
+int g_reductions_on_chain = 0;              // drs_debug_reductions_on_chain: the classifier's slab reductions stay on the compute stream
 inline void jitter(hipStream_t s) {
   if (!g_jitter_state) return;
   g_jitter_state = g_jitter_state * 6364136223846793005ull + 1442695040888963407ull;
@@ -497,30 +519,65 @@ int wait_handles(drs_net* n, const std::vector<int>& hs, hipStream_t st) {
   return DRS_OK;
 }
 
-const float* weight_ptr(drs_net* n, int i) {
-  return i == 0 ? n->p<float>("w0pad") : n->p<float>("params") + n->layers[i].w_off;
+// every buffer bound -> the pointer table of the step (false: something is still unbound)
+bool resolve(drs_net* n) {
+  Ptrs& P = n->ptrs;
+  if (P.ok) return true;
+  for (auto& b : n->bufs)
+    if (!b.ptr) return false;
+  P.params = n->p<float>("params"); P.grads = n->p<float>("grads"); P.momentum = n->p<float>("momentum"); P.bn = n->p<float>("bn");
+  P.partial = n->p<float>("partial"); P.gxh = n->p<float>("gxh"); P.gz[0] = n->p<float>("gz"); P.gz[1] = n->p<float>("gz2");
+  P.slab = n->p<float>("slab"); P.w0pad = n->p<float>("w0pad"); P.conv_ws = n->p<float>("conv_ws");
+  P.conv_ws_floats = n->buf("conv_ws")->bytes / sizeof(float);
+  P.bwd_means = n->p<float>("bwd_means"); P.act = n->p<float>("act"); P.gpool = n->p<float>("gpool"); P.se_scratch = n->p<float>("se_scratch");
+  P.dw_partial = n->p<float>("dw_partial"); P.db_partial = n->p<float>("db_partial"); P.logits = n->p<float>("logits");
+  P.sums = n->p<double>("sums"); P.scalars = n->p<double>("scalars"); P.colsum_scratch = n->p<double>("colsum_scratch");
+  P.loss_partial = n->p<double>("loss_partial"); P.l2_scratch = n->p<double>("l2_scratch");
+  P.pred = n->p<unsigned char>("pred"); P.labels = n->p<unsigned char>("labels"); P.acc_mask = n->p<unsigned char>("acc_mask");
+  P.loss_mask = n->p<unsigned char>("loss_mask"); P.conf = n->p<unsigned int>("conf");
+  const Slab& f = n->slabs[n->feat];
+  P.feat_act = n->p<float>("act:" + f.name); P.feat_gact = n->p<float>("gact:" + f.name);
+  P.L.assign(n->layers.size(), LayerPtrs());
+  for (size_t i = 0; i < n->layers.size(); ++i) {
+    const Layer& L = n->layers[i];
+    const std::string id = std::to_string(i);
+    LayerPtrs& q = P.L[i];
+    q.z = n->p<float>("z" + id); q.mean_rstd = n->p<float>("mean_rstd" + id); q.idx = n->p<unsigned char>("idx" + id);
+    q.wt = i > 0 ? n->p<float>("wt" + id) : nullptr;
+    q.w = i == 0 ? P.w0pad : P.params + L.w_off;
+    q.act_in = n->p<float>("act:" + n->slabs[L.src].name); q.act_out = n->p<float>("act:" + n->slabs[L.dst].name);
+    q.gact_in = L.src != 0 ? n->p<float>("gact:" + n->slabs[L.src].name) : nullptr;
+    q.gact_out = n->p<float>("gact:" + n->slabs[L.dst].name);
+    q.se_act = q.se_s = q.se_e1 = q.se_e2 = nullptr;
+    if (L.se >= 0) {
+      const std::string sid = std::to_string(L.se);
+      q.se_act = n->p<float>("se_act" + sid); q.se_s = n->p<float>("se_s" + sid); q.se_e1 = n->p<float>("se_e1" + sid); q.se_e2 = n->p<float>("se_e2" + sid);
+    }
+  }
+  P.ok = true;
+  return true;
 }
 
 // conv -> (+bias) -> batch norm -> activation -> pool / SE, for every block (net.py _forward_layers, exact-fp32 arithmetic)
 int forward_layers(drs_net* n, int B, int S, bool training, double count, hipStream_t st) {
   const long long M = (long long)B * S * S;
-  float* params = n->p<float>("params");
-  float* bn = n->p<float>("bn");
+  const Ptrs& P = n->ptrs;
+  float* params = P.params;
+  float* bn = P.bn;
   const Layer& L0 = n->layers[0];
-  DRS_TRY(drs_filter_pad_cin(params + L0.w_off, n->p<float>("w0pad"), L0.k, L0.cin, L0.cin_k, L0.cout, st));
-  float* partial = n->p<float>("partial");
-  double* sums = n->p<double>("sums");
+  DRS_TRY(drs_filter_pad_cin(params + L0.w_off, P.w0pad, L0.k, L0.cin, L0.cin_k, L0.cout, st));
+  float* partial = P.partial;
+  double* sums = P.sums;
   for (size_t i = 0; i < n->layers.size(); ++i) {
     const Layer& L = n->layers[i];
+    const LayerPtrs& q = P.L[i];
     const Slab& in = n->slabs[L.src];
-    const std::string id = std::to_string(i);
-    float* z = n->p<float>("z" + id);
-    float* mr = n->p<float>("mean_rstd" + id);
+    float* z = q.z;
+    float* mr = q.mean_rstd;
     {
       Timed t(n, st, K_CONV_FWD, 2.0 * M * L.k * L.k * L.cin * L.cout);
-      DRS_TRY(drs_conv_forward_ws(n->p<float>("act:" + in.name), B, S, in.P, in.C, 0, weight_ptr(n, (int)i), params + L.b_off, L.k, L.rate, L.pad_b,
-                                  L.cin_k, L.cout, z, L.cout, 0, 0, training ? partial : nullptr, n->p<float>("conv_ws"),
-                                  n->buf("conv_ws")->bytes / sizeof(float), st));
+      DRS_TRY(drs_conv_forward_ws(q.act_in, B, S, in.P, in.C, 0, q.w, params + L.b_off, L.k, L.rate, L.pad_b,
+                                  L.cin_k, L.cout, z, L.cout, 0, 0, training ? partial : nullptr, P.conv_ws, P.conv_ws_floats, st));
     }
     float* mm = bn + L.bn_off;
     float* mv = mm + L.cout;
@@ -537,21 +594,20 @@ int forward_layers(drs_net* n, int B, int S, bool training, double count, hipStr
       DRS_TRY(drs_bn_eval_coeffs(mm, mv, L.cout, mr, st));
     }
     const Slab& out = n->slabs[L.dst];
-    float* outp = n->p<float>("act:" + out.name);
+    float* outp = q.act_out;
     const bool mx = L.pool == 1;
-    unsigned char* idx = (training && mx) ? n->p<unsigned char>("idx" + id) : nullptr;
+    unsigned char* idx = (training && mx) ? q.idx : nullptr;
     if (L.se >= 0) {      // activation into a plain [M][C] buffer, then squeeze-and-excitation scaling into the next slab
       const SeBlock& s = n->se[L.se];
-      const std::string sid = std::to_string(L.se);
-      float* act = n->p<float>("se_act" + sid);
+      float* act = q.se_act;
       { Timed t(n, st, K_BN_FWD, M * L.cout * 8.0);
         DRS_TRY(drs_bn_act_pool_forward(z, B, S, L.cout, mr, n->alpha, 0, act, 0, L.cout, 0, nullptr, st)); }
       Timed t(n, st, K_SE_FWD, M * L.cout * 12.0);
-      DRS_TRY(drs_se_forward(act, B, S, L.cout, s.R, params + s.w1, params + s.b1, params + s.w2, params + s.b2, n->p<float>("se_s" + sid),
-                             n->p<float>("se_e1" + sid), n->p<float>("se_e2" + sid), outp, out.P, out.C, L.dst_coff, st));
+      DRS_TRY(drs_se_forward(act, B, S, L.cout, s.R, params + s.w1, params + s.b1, params + s.w2, params + s.b2, q.se_s, q.se_e1, q.se_e2, outp,
+                             out.P, out.C, L.dst_coff, st));
       n->halo_ok[L.dst] = -1;
     } else if (L.pool == 2) {   // activation into a plain [M][C] buffer, then the k x k average into the next layer's slab
-      float* act = n->p<float>("act");
+      float* act = P.act;
       { Timed t(n, st, K_BN_FWD, M * L.cout * 8.0);
         DRS_TRY(drs_bn_act_pool_forward(z, B, S, L.cout, mr, n->alpha, 0, act, 0, L.cout, 0, nullptr, st)); }
       Timed t(n, st, K_AVG_FWD, M * L.cout * 8.0);
@@ -576,18 +632,14 @@ int forward_layers(drs_net* n, int B, int S, bool training, double count, hipStr
 
 bool check_bs(const drs_net* n, int B, int S) { return B >= 1 && S >= 1 && B <= n->b_max && S <= n->s_max; }
 
-bool all_bound(const drs_net* n) {
-  for (auto& b : n->bufs)
-    if (!b.ptr) return false;
-  return true;
-}
-
 }  // namespace
 
 extern "C" {
 
 #ifdef DRS_DEV
 int drs_debug_jitter(unsigned long long seed) { g_jitter_state = seed; return 0; }
+int drs_debug_wg_stream_prio(int arm) { const int old = g_wg_stream_prio; if (arm >= 0) g_wg_stream_prio = arm; return old; }
+int drs_debug_reductions_on_chain(int on) { const int old = g_reductions_on_chain; if (on >= 0) g_reductions_on_chain = on; return old; }
 #endif
 
 int drs_net_create(const char* net_type, int channels, int num_classes, float weight_decay, int b_max, int s_max, int bessel_moving_var,
@@ -608,7 +660,7 @@ int drs_net_create(const char* net_type, int channels, int num_classes, float we
     n->rccl_inline = false; n->rccl_buckets = false; n->comm_ring = 0; n->comm_in_flight = 0;
     for (auto& e : n->ev_bucket) e = nullptr;
     n->wg_stream = nullptr;
-    { const char* e = std::getenv("DRS_TWO_STREAMS"); n->two_stream_mode = e ? std::atoi(e) : -1; }
+    n->two_stream_mode = -1;
     build_plan(n);
     list_buffers(n);
     n->halo_ok.assign(n->slabs.size(), -1);
@@ -664,6 +716,7 @@ int drs_net_bind(drs_net_t* n, const char* name, void* dev_ptr, size_t bytes) {
   Buf* b = n->buf(name);
   if (!b || bytes < b->bytes) return DRS_ERR_ARG;
   b->ptr = dev_ptr;
+  n->ptrs.ok = false;
   std::fill(n->halo_ok.begin(), n->halo_ok.end(), -1);
   return DRS_OK;
 }
@@ -679,7 +732,7 @@ int drs_net_buffer(drs_net_t* n, const char* name, void** dev_ptr, size_t* bytes
 
 int drs_grad_buffer(drs_net_t* n, float** dev_ptr, size_t* count) {
   if (!n) return DRS_ERR_ARG;
-  if (dev_ptr) *dev_ptr = n->p<float>("grads");
+  if (dev_ptr) *dev_ptr = n->p<float>("grads");      // (not a per-step call)
   if (count) *count = n->n_params;
   return DRS_OK;
 }
@@ -853,7 +906,9 @@ static int set_rccl_impl(drs_net_t* n, int world, int rank, void* comm_small, vo
   // queue nor the filter-gradient stream's (train_step_impl: wg_stream at the highest; there for why)
   int comm_prio = 0, greatest_prio = 0;
   if (hipDeviceGetStreamPriorityRange(&comm_prio, &greatest_prio) != hipSuccess) comm_prio = 0;
-  { const char* pe = std::getenv("DRS_WG_STREAM_PRIO"); if (pe && std::atoi(pe) == 1) comm_prio = greatest_prio; else if (pe && std::atoi(pe) == 0) comm_prio = 0; }
+#ifdef DRS_DEV
+  if (g_wg_stream_prio == 1) comm_prio = greatest_prio; else if (g_wg_stream_prio == 0) comm_prio = 0;
+#endif
   if (n->rccl_buckets) {      // one side stream for the two gradient buckets, three events
     for (auto& e : n->ev_bucket)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return DRS_ERR_HIP;
@@ -876,6 +931,15 @@ static int set_rccl_impl(drs_net_t* n, int world, int rank, void* comm_small, vo
   }
   n->world = world; n->rank = rank; n->rccl_small = comm_small; n->rccl_big = comm_big; n->comm_next = 0;
   n->allreduce = nullptr; n->wait = nullptr; n->comm_user = nullptr;
+  return DRS_OK;
+}
+
+// The backward pass of a training step on two streams (the filter gradients beside the batch-norm-backward / input-gradient chain,
+// train_step_impl): mode -1 = by the library's rule (small steps only; the default), 0 = never (a host that must keep every launch
+// of the step on ITS stream), 1 = always.  Same kernels on the same operands in every mode: bitwise the same step.
+int drs_net_set_two_streams(drs_net_t* n, int mode) {
+  if (!n || mode < -1 || mode > 1) return DRS_ERR_ARG;
+  n->two_stream_mode = mode;
   return DRS_OK;
 }
 
@@ -912,19 +976,18 @@ int drs_net_num_timing_kinds(void) { return K_NKIND; }
 // is_training=False pass over the slab filled by drs_crop_normalize: pred (and logits when DRS_WANT_LOGITS); with DRS_WITH_LABELS
 // the confusion matrix of (labels, pred) is ADDED into conf (validation, isprs:1599), gated by acc_mask under DRS_USE_ACC_MASK
 static int forward_impl(drs_net_t* n, int B, int S, int flags, int ignore_label, void* stream) {
-  if (!n || !check_bs(n, B, S) || !all_bound(n)) return DRS_ERR_ARG;
+  if (!n || !check_bs(n, B, S) || !resolve(n)) return DRS_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const long long M = (long long)B * S * S;
+  const Ptrs& P = n->ptrs;
   DRS_TRY(forward_layers(n, B, S, false, (double)M, st));
   const Slab& f = n->slabs[n->feat];
-  float* params = n->p<float>("params");
-  DRS_TRY(drs_classifier_loss(n->p<float>("act:" + f.name), B, S, f.P, f.C, 0, n->c_last, n->K, params + n->cls_w, params + n->cls_b, nullptr,
-                              nullptr, nullptr, 0.f, (flags & DRS_WANT_LOGITS) ? n->p<float>("logits") : nullptr, n->p<unsigned char>("pred"),
+  float* params = P.params;
+  DRS_TRY(drs_classifier_loss(P.feat_act, B, S, f.P, f.C, 0, n->c_last, n->K, params + n->cls_w, params + n->cls_b, nullptr,
+                              nullptr, nullptr, 0.f, (flags & DRS_WANT_LOGITS) ? P.logits : nullptr, P.pred,
                               nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, st));
   if (flags & DRS_WITH_LABELS)
-    DRS_TRY(drs_confusion(n->p<unsigned char>("labels"), n->p<unsigned char>("pred"),
-                          (flags & DRS_USE_ACC_MASK) ? n->p<unsigned char>("acc_mask") : nullptr, (size_t)M, n->K, ignore_label,
-                          n->p<unsigned int>("conf"), st));
+    DRS_TRY(drs_confusion(P.labels, P.pred, (flags & DRS_USE_ACC_MASK) ? P.acc_mask : nullptr, (size_t)M, n->K, ignore_label, P.conf, st));
   return DRS_OK;
 }
 
@@ -934,11 +997,11 @@ float drs_net_learning_rate(const drs_net_t* n, float lr0) {
 }
 
 int drs_apply_update(drs_net_t* n, float lr0, void* stream) {
-  if (!n || !all_bound(n)) return DRS_ERR_ARG;
+  if (!n || !resolve(n)) return DRS_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   {
     Timed t(n, st, K_MOMENTUM, n->n_params * 20.0);
-    DRS_TRY(drs_momentum_update(n->p<float>("params"), n->p<float>("grads"), n->p<float>("momentum"), n->n_params, n->n_decay,
+    DRS_TRY(drs_momentum_update(n->ptrs.params, n->ptrs.grads, n->ptrs.momentum, n->n_params, n->n_decay,
                                 drs_net_learning_rate(n, lr0), n->wd, MOMENTUM, 1.0f, st));
   }
   n->global_step += 1;
@@ -951,9 +1014,10 @@ int drs_apply_update(drs_net_t* n, float lr0, void* stream) {
 // global_pixels = number of pixels the loss averages over on all ranks (<= 0: B*S*S*world; the contest form passes the number of
 // unmasked pixels).  Every rank must hold the same B (the batch-norm count is B*S*S*world).
 static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, double global_pixels, void* stream) {
-  if (!n || !check_bs(n, B, S) || !all_bound(n)) return DRS_ERR_ARG;
+  if (!n || !check_bs(n, B, S) || !resolve(n)) return DRS_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const long long M = (long long)B * S * S;
+  const Ptrs& P = n->ptrs;
   const double n_bn = (double)M * n->world;
   const double n_glob = global_pixels > 0 ? global_pixels : n_bn;
   n->comm_in_flight = 0;      // (a step that failed midway must not leave the next one short of event slots)
@@ -977,10 +1041,13 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     // 16 x 64 x 64, 3.97 instead of 3.71 at S = 45 -- worse than ONE stream).  A stream of another level is never on the compute
     // stream's queue.  The highest level, the collectives' side streams (set_rccl_impl) the lowest: in-process A/B, no collectives:
     // highest = a lucky stream of the caller's level, lowest +1.5 % at S = 64; with every all-reduce a real launch both the same.
-    // DRS_WG_STREAM_PRIO (A/B): 0 = the caller's level (as before round 5), 1 = lowest (and the collectives' streams highest).
+    // (development library, drs_debug_wg_stream_prio: 0 = the caller's level as before round 5, 1 = lowest and the collectives' streams highest)
     int least = 0, greatest = 0;
-    const char* pe = std::getenv("DRS_WG_STREAM_PRIO");
-    const int arm = pe ? std::atoi(pe) : 2;
+#ifdef DRS_DEV
+    const int arm = g_wg_stream_prio;
+#else
+    const int arm = 2;
+#endif
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
     bool ok = stream_at_priority(&n->wg_stream, arm == 0 ? 0 : (arm == 1 ? least : greatest)) == hipSuccess;
     for (int i = 0; ok && i < 2; ++i)
@@ -989,10 +1056,10 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     if (!ok) return DRS_ERR_HIP;
   }
   hipStream_t ws = two ? n->wg_stream : st;       // the stream the filter gradients run on
-  float* params = n->p<float>("params");
-  float* grads = n->p<float>("grads");
+  float* params = P.params;
+  float* grads = P.grads;
   const int nL = (int)n->layers.size();
-  unsigned int* conf = n->p<unsigned int>("conf");
+  unsigned int* conf = P.conf;
   // one launch: the flipped / transposed filters of the input-gradient passes, the confusion matrix zeroed, and the gradients of
   // the conv biases zeroed (they sit in front of a mean-subtracting batch norm: their gradient is identically zero).  Nothing of
   // the forward pass needs it: with two streams it runs on the filter-gradient stream BESIDE the forward pass (behind everything
@@ -1003,10 +1070,10 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     for (int i = 1; i < nL; ++i) {
       const Layer& L = n->layers[i];
       if (pa.n == STEP_PREP_MAX) {                       // (deeper nets than any of the reference's: the rest one by one)
-        DRS_TRY(drs_filter_flip_transpose(params + L.w_off, n->p<float>("wt" + std::to_string(i)), L.k, L.cin, L.cout, sp));
+        DRS_TRY(drs_filter_flip_transpose(params + L.w_off, P.L[i].wt, L.k, L.cin, L.cout, sp));
         continue;
       }
-      pa.w[pa.n] = params + L.w_off; pa.wt[pa.n] = n->p<float>("wt" + std::to_string(i));
+      pa.w[pa.n] = params + L.w_off; pa.wt[pa.n] = P.L[i].wt;
       pa.k[pa.n] = L.k; pa.cin[pa.n] = L.cin; pa.cout[pa.n] = L.cout;
       ++pa.n;
     }
@@ -1015,7 +1082,11 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     DRS_TRY(drs_step_prep(pa, sp));
     return DRS_OK;
   };
-  const bool side_jobs = two && std::getenv("DRS_REDUCTIONS_ON_CHAIN") == nullptr;      // (A/B: DRS_REDUCTIONS_ON_CHAIN=1 keeps them on `st`, as before round 5)
+#ifdef DRS_DEV
+  const bool side_jobs = two && !g_reductions_on_chain;      // (A/B, drs_debug_reductions_on_chain(1): they stay on `st`, as before round 5)
+#else
+  const bool side_jobs = two;
+#endif
   if (side_jobs) {
     if (hipEventRecord(n->ev_cls, st) != hipSuccess || hipStreamWaitEvent(ws, n->ev_cls, 0) != hipSuccess) return DRS_ERR_HIP;
     DRS_JITTER(ws);
@@ -1027,26 +1098,26 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
   else DRS_TRY(step_prep(st));
   // classifier + loss + gradient wrt the features
   const Slab& f = n->slabs[n->feat];
-  float* gfeat = n->p<float>("gact:" + f.name);
-  double* scalars = n->p<double>("scalars");
-  double* scratch = n->p<double>("colsum_scratch");
+  float* gfeat = P.feat_gact;
+  double* scalars = P.scalars;
+  double* scratch = P.colsum_scratch;
   {
     Timed t(n, st, K_CLS, M * n->c_last * 8.0);
-    DRS_TRY(drs_classifier_loss(n->p<float>("act:" + f.name), B, S, f.P, f.C, 0, n->c_last, n->K, params + n->cls_w, params + n->cls_b,
-                                n->p<unsigned char>("labels"), (flags & DRS_USE_LOSS_MASK) ? n->p<unsigned char>("loss_mask") : nullptr,
-                                (flags & DRS_USE_ACC_MASK) ? n->p<unsigned char>("acc_mask") : nullptr, (float)(1.0 / n_glob),
-                                (flags & DRS_WANT_LOGITS) ? n->p<float>("logits") : nullptr, n->p<unsigned char>("pred"), gfeat, f.C, 0,
-                                n->p<float>("dw_partial"), n->p<float>("db_partial"), n->p<double>("loss_partial"), conf, st));
+    DRS_TRY(drs_classifier_loss(P.feat_act, B, S, f.P, f.C, 0, n->c_last, n->K, params + n->cls_w, params + n->cls_b,
+                                P.labels, (flags & DRS_USE_LOSS_MASK) ? P.loss_mask : nullptr,
+                                (flags & DRS_USE_ACC_MASK) ? P.acc_mask : nullptr, (float)(1.0 / n_glob),
+                                (flags & DRS_WANT_LOGITS) ? P.logits : nullptr, P.pred, gfeat, f.C, 0,
+                                P.dw_partial, P.db_partial, P.loss_partial, conf, st));
   }
   // the classifier's slab reductions (its kernel / bias gradients, the cross-entropy sum) and the L2 term: seven launches of ~5 us that
   // nothing needs before the end of the step -- in the two-stream backward pass they go to the filter-gradient stream (below), off
   // the chain the step waits for
   const int crow = drs_classifier_rows(B, S);
   auto slab_reductions = [&](hipStream_t s) -> int {
-    DRS_TRY(drs_rows_reduce_f32(n->p<float>("dw_partial"), crow, n->c_last * n->K, grads + n->cls_w, scratch, s));
-    DRS_TRY(drs_rows_reduce_f32(n->p<float>("db_partial"), crow, n->K, grads + n->cls_b, scratch, s));
-    DRS_TRY(drs_sum_f64(n->p<double>("loss_partial"), crow, scalars, s));
-    DRS_TRY(drs_l2_loss(params, n->n_decay, n->p<double>("l2_scratch"), scalars + 1, s));
+    DRS_TRY(drs_rows_reduce_f32(P.dw_partial, crow, n->c_last * n->K, grads + n->cls_w, scratch, s));
+    DRS_TRY(drs_rows_reduce_f32(P.db_partial, crow, n->K, grads + n->cls_b, scratch, s));
+    DRS_TRY(drs_sum_f64(P.loss_partial, crow, scalars, s));
+    DRS_TRY(drs_l2_loss(params, n->n_decay, P.l2_scratch, scalars + 1, s));
     return DRS_OK;
   };
   // gradient all-reduce in buckets that overlap the rest of the backward pass: kernel gradients go as their layers finish, last
@@ -1055,11 +1126,11 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
   size_t bucket_hi = n->cls_w;
   std::vector<char> written(n->slabs.size(), 0);
   written[n->feat] = 1;
-  float* gzb[2] = {n->p<float>("gz"), n->p<float>("gz2")};
-  float* gxh = n->p<float>("gxh");
-  float* partial = n->p<float>("partial");
-  double* sums = n->p<double>("sums");
-  float* bwd_means = n->p<float>("bwd_means");
+  float* gzb[2] = {P.gz[0], P.gz[1]};
+  float* gxh = P.gxh;
+  float* partial = P.partial;
+  double* sums = P.sums;
+  float* bwd_means = P.bwd_means;
 
   if (side_jobs) {
     if (hipEventRecord(n->ev_cls, st) != hipSuccess || hipStreamWaitEvent(ws, n->ev_cls, 0) != hipSuccess) return DRS_ERR_HIP;
@@ -1099,8 +1170,8 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     if (two) DRS_JITTER(ws);
     {
       Timed t(n, ws, K_CONV_WGRAD, 2.0 * M * L.k * L.k * L.cin * L.cout);
-      DRS_TRY(drs_conv_wgrad(n->p<float>("act:" + in.name), B, S, in.P, in.C, 0, gzb[two ? (i & 1) : 0], L.halo, L.cout, 0, L.k, L.rate, L.pad_b, L.cin_k,
-                             L.cin, L.cout, n->p<float>("slab"), grads + L.w_off, ws));
+      DRS_TRY(drs_conv_wgrad(P.L[i].act_in, B, S, in.P, in.C, 0, gzb[two ? (i & 1) : 0], L.halo, L.cout, 0, L.k, L.rate, L.pad_b, L.cin_k,
+                             L.cin, L.cout, P.slab, grads + L.w_off, ws));
     }
     if (collectives(n) && !inline_comm && i > 0 && (nL - i) % 2 == 0) {      // every second layer: one bucket
       int h;
@@ -1124,30 +1195,28 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
   int deferred = -1;      // block whose filter gradient is still to be computed (it only needs that block's gz, still in place)
   for (int i = nL - 1; i >= 0; --i) {
     const Layer& L = n->layers[i];
-    const std::string id = std::to_string(i);
+    const LayerPtrs& q = P.L[i];
     const Slab& out = n->slabs[L.dst];
-    const float* gcur = n->p<float>("gact:" + out.name);
+    const float* gcur = q.gact_out;
     const bool mx = L.pool == 1;
     const float* gsrc = gcur;
     int ldg = out.C, cg = L.dst_coff;
     if (L.se >= 0) {
       const SeBlock& s = n->se[L.se];
-      const std::string sid = std::to_string(L.se);
       Timed t(n, st, K_SE_BWD, M * L.cout * 16.0);
-      DRS_TRY(drs_se_backward(gcur, out.C, L.dst_coff, n->p<float>("se_act" + sid), n->p<float>("se_s" + sid), n->p<float>("se_e1" + sid),
-                              n->p<float>("se_e2" + sid), params + s.w1, params + s.w2, B, S, L.cout, s.R, n->p<float>("gpool"), grads + s.w1,
-                              grads + s.b1, grads + s.w2, grads + s.b2, n->p<float>("se_scratch"), st));
-      gsrc = n->p<float>("gpool"); ldg = L.cout; cg = 0;
+      DRS_TRY(drs_se_backward(gcur, out.C, L.dst_coff, q.se_act, q.se_s, q.se_e1, q.se_e2, params + s.w1, params + s.w2, B, S, L.cout, s.R, P.gpool,
+                              grads + s.w1, grads + s.b1, grads + s.w2, grads + s.b2, P.se_scratch, st));
+      gsrc = P.gpool; ldg = L.cout; cg = 0;
     } else if (L.pool == 2) {
       Timed t(n, st, K_AVG_BWD, M * L.cout * 8.0);
-      DRS_TRY(drs_avg_pool_backward(gcur, out.C, L.dst_coff, B, S, L.cout, L.avg_k, n->p<float>("gpool"), st));
-      gsrc = n->p<float>("gpool"); ldg = L.cout; cg = 0;
+      DRS_TRY(drs_avg_pool_backward(gcur, out.C, L.dst_coff, B, S, L.cout, L.avg_k, P.gpool, st));
+      gsrc = P.gpool; ldg = L.cout; cg = 0;
     }
-    float* z = n->p<float>("z" + id);
-    float* mr = n->p<float>("mean_rstd" + id);
+    float* z = q.z;
+    float* mr = q.mean_rstd;
     {
       Timed t(n, st, K_BN_BWD_REDUCE, M * L.cout * (mx ? 13.0 : 12.0));
-      DRS_TRY(drs_bn_backward_reduce(gsrc, ldg, cg, z, mx ? n->p<unsigned char>("idx" + id) : nullptr, B, S, L.cout, mr, n->alpha, mx ? 1 : 0, gxh,
+      DRS_TRY(drs_bn_backward_reduce(gsrc, ldg, cg, z, mx ? q.idx : nullptr, B, S, L.cout, mr, n->alpha, mx ? 1 : 0, gxh,
                                      partial, st));
     }
     // single rank: the sums need no all-reduce, so the reduction also leaves the two means the apply pass subtracts (as fp32, its own
@@ -1178,9 +1247,8 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
       const int acc = written[L.src] ? 1 : 0;
       written[L.src] = 1;
       Timed t(n, st, K_CONV_DGRAD, 2.0 * M * L.k * L.k * L.cin * L.cout);
-      DRS_TRY(drs_conv_forward_ws(gz, B, S, L.halo, L.cout, 0, n->p<float>("wt" + id), nullptr, L.k, L.rate, L.pad_a, L.cout, L.cin,
-                                  n->p<float>("gact:" + in.name), in.C, 0, acc, nullptr, n->p<float>("conv_ws"),
-                                  n->buf("conv_ws")->bytes / sizeof(float), st));
+      DRS_TRY(drs_conv_forward_ws(gz, B, S, L.halo, L.cout, 0, q.wt, nullptr, L.k, L.rate, L.pad_a, L.cout, L.cin,
+                                  q.gact_in, in.C, 0, acc, nullptr, P.conv_ws, P.conv_ws_floats, st));
     }
     deferred = i;
   }

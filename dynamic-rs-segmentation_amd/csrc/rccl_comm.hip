@@ -4,7 +4,8 @@
 //
 // The library does not link librccl: a single-GPU host never needs it.  `librccl.so.1` is looked up among the objects the
 // process has already loaded (a PyTorch host has loaded its own copy) and then on the loader path / under /opt/rocm/lib;
-// DRS_RCCL_LIB names another NCCL-API library to bind instead.
+// drs_rccl_bind_library(path), called by the host before anything else of this file, names another NCCL-API library to bind instead
+// (an explicit call of the host program: no environment variable substitutes the collectives library).
 // A communicator made here belongs to the library's copy of RCCL; a host that links RCCL itself may hand in its own ncclComm_t
 // (drs_net_set_rccl takes opaque pointers) provided both sides resolve to the same loaded librccl.
 #include "drs_common.hpp"
@@ -37,17 +38,18 @@ struct Rccl {
 
 Rccl g_rccl;
 std::once_flag g_once;
+std::mutex g_named_mutex;
+char g_named[1024] = {0};      // drs_rccl_bind_library: the NCCL-API library to bind instead of the process's / the loader's librccl
 
 void load_rccl() {
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  // DRS_RCCL_LIB: the path of the NCCL-API library to bind instead (another build of RCCL; the shared-memory stand-in the tests
-  // drive the world > 1 code of the step engine with on a one-GPU box, tests/c/nccl_shm_double.cpp).  Named and not loadable: no
-  // fall-back to the copies below -- the caller asked for THAT library.
-  const char* named = std::getenv("DRS_RCCL_LIB");
+  // A library named through drs_rccl_bind_library (another build of RCCL; the shared-memory stand-in the tests drive the world > 1
+  // code of the step engine with on a one-GPU box, tests/c/nccl_shm_double.cpp).  Named and not loadable: no fall-back to the
+  // copies below -- the caller asked for THAT library.
   void* h = nullptr;
-  if (named && *named) {
-    h = dlopen(named, RTLD_NOW | RTLD_LOCAL);
-    if (!h) { std::fprintf(stderr, "libdrs_hip: DRS_RCCL_LIB=%s could not be loaded: %s\n", named, dlerror()); return; }
+  if (g_named[0]) {
+    h = dlopen(g_named, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { std::fprintf(stderr, "libdrs_hip: drs_rccl_bind_library(%s): could not be loaded: %s\n", g_named, dlerror()); return; }
   }
   if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);          // the copy the host process already runs, if any
   for (int i = 0; !h && i < 3; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
@@ -85,6 +87,19 @@ __attribute__((visibility("hidden"))) int drs_rccl_all_reduce_sum(void* comm, vo
 }
 
 extern "C" {
+
+// Bind `path` (an NCCL-API shared library: ncclGetUniqueId, ncclCommInitRank, ncclCommDestroy, ncclAllReduce) for the library-side
+// collectives instead of librccl.  Only before the first use of any drs_rccl_* / drs_net_set_rccl entry point: once a library is
+// bound (this one or librccl) the call is rejected (DRS_ERR_ARG), and so is a path that cannot be loaded.
+int drs_rccl_bind_library(const char* path) {
+  if (!path || !*path || std::strlen(path) >= sizeof g_named) return DRS_ERR_ARG;
+  {
+    std::lock_guard<std::mutex> lock(g_named_mutex);
+    if (g_rccl.handle || g_named[0]) return DRS_ERR_ARG;
+    std::strcpy(g_named, path);
+  }
+  return rccl() ? DRS_OK : DRS_ERR_ARG;
+}
 
 int drs_rccl_available(void) { return rccl() ? 1 : 0; }
 

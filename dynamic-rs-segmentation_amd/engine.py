@@ -137,9 +137,9 @@ class EngineNet(DilatedNet):
         rehearsals and CPU tests, DRS_COMM=torch, or RCCL not bindable) through the all-reduce callback into torch.distributed."""
         import os
         # (DRS_COMM=rccl over a host group that is not RCCL -- gloo -- still takes the library-side path: the host group only carries
-        #  the communicator ids; with DRS_RCCL_LIB naming the NCCL-API library the step engine binds.  The tests run the world > 1
-        #  code of the library-side collectives that way on a one-GPU box, tests/test_gpu_dp.py.)
-        forced = os.environ.get("DRS_COMM") == "rccl" and bool(os.environ.get("DRS_RCCL_LIB"))
+        #  the communicator ids.  The tests run the world > 1 code of the library-side collectives that way on a one-GPU box, after
+        #  naming a shared-memory stand-in for RCCL through drs_rccl_bind_library; tests/test_gpu_dp.py.)
+        forced = os.environ.get("DRS_COMM") == "rccl"
         if (getattr(self.comm, "backend", None) == "nccl" or forced) and os.environ.get("DRS_COMM", "rccl") != "torch":
             err = None
             if self.comm.all_true(bool(_lib.query("drs_rccl_available"))):
@@ -253,6 +253,11 @@ class EngineNet(DilatedNet):
                 return -1
         self._cb = (_lib.ALLREDUCE_FN(allreduce), _lib.WAIT_FN(wait))       # kept alive with the net
         _lib.call("drs_net_set_comm", self.h, self.comm.world, self.comm.rank, C.cast(self._cb[0], C.c_void_p), C.cast(self._cb[1], C.c_void_p), None)
+
+    def set_two_streams(self, mode):
+        """the backward pass of a step on two streams: None / -1 = by the library's rule (small steps), 0 never, 1 always
+        (drs_net_set_two_streams; bitwise the same step in every mode)"""
+        _lib.call("drs_net_set_two_streams", self.h, -1 if mode is None else int(mode))
 
     # ------------------------------------------------------------------ state the library owns
     @property

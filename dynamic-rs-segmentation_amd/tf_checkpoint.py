@@ -17,8 +17,10 @@ tensorflow/core/protobuf/tensor_bundle.proto, tensorflow/core/lib/io/table_forma
 The reader accepts Snappy-compressed blocks (TensorFlow's table builder compresses when it helps); the writer emits
 uncompressed blocks, which every TensorFlow reader accepts.
 
-STATUS: there is no TensorFlow in this environment, so this module is verified by round trip, by the format's own
-checksums and against hand-built byte strings only (tests/test_tf_checkpoint.py) -- not against a TensorFlow-written file.
+STATUS: there is no TensorFlow in this environment, so this module is not verified against a TensorFlow-written file.  It is
+verified by round trip, by the formats' own checksums and known answers, and (since round 6) half by half against independent
+implementations present in the build container: Snappy against Arrow's codec (pyarrow), the BundleEntryProto / BundleHeaderProto /
+TensorShapeProto encodings against google.protobuf, the table reader on blocks compressed by Arrow (tests/test_tf_checkpoint.py).
 """
 import struct
 
@@ -169,12 +171,16 @@ def encode_entry(dtype, shape, offset, size, crc):
     msg = _pb_varint_field(1, dtype) + _pb_bytes_field(2, shp)
     if offset:
         msg += _pb_varint_field(4, offset)
-    msg += _pb_varint_field(5, size) + _put_varint((6 << 3) | 5) + struct.pack("<I", crc)
+    msg += _pb_varint_field(5, size)
+    if crc:                                  # (proto3 omits a zero fixed32, as TensorFlow's serialiser does)
+        msg += _put_varint((6 << 3) | 5) + struct.pack("<I", crc)
     return msg
 
 
 def decode_entry(buf):
-    e = dict(dtype=0, shape=[], shard_id=0, offset=0, size=0, crc32c=None)
+    # proto3: a scalar field that holds its default (0) is not on the wire -- a (masked) crc32c of 0 is an ABSENT field, and TensorFlow's
+    # reader checks the tensor against entry.crc32c() == 0 then; so does read_bundle (found against google.protobuf's serialiser, r06)
+    e = dict(dtype=0, shape=[], shard_id=0, offset=0, size=0, crc32c=0)
     for f, wt, v in _pb_fields(buf):
         if f == 1:
             e["dtype"] = v
@@ -378,7 +384,7 @@ def read_bundle(prefix, verify=True):
             with open("%s.data-%05d-of-%05d" % (prefix, sid, nshards), "rb") as f:
                 shards[sid] = f.read()
         raw = shards[sid][e["offset"]:e["offset"] + e["size"]]
-        if verify and e["crc32c"] is not None and unmask_crc(e["crc32c"]) != crc32c_fast(raw):
+        if verify and unmask_crc(e["crc32c"]) != crc32c_fast(raw):
             raise ValueError("tensor checksum mismatch for " + key.decode())
         out[key.decode()] = np.frombuffer(raw, dtype=np.dtype(_NP_OF[e["dtype"]]).newbyteorder("<")).reshape(tuple(e["shape"])).copy()
     return out

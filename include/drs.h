@@ -340,7 +340,10 @@ int drs_net_set_comm(drs_net_t* net, int world, int rank, drs_allreduce_fn allre
  * A host that binds this ABI directly must have HSA_ENABLE_IPC_MODE_LEGACY=0 in its environment BEFORE the HIP runtime starts
  * (the first HIP call of the process): on this driver RCCL's intra-node transport needs dmabuf IPC and ncclCommInitRank otherwise
  * fails with `hipIpcGetMemHandle: invalid argument` (the Python client and bench.py set it at import).
- *   drs_rccl_available : 1 if librccl could be bound.
+ *   drs_rccl_bind_library : name the NCCL-API shared library to bind INSTEAD of librccl (another build of RCCL; a test double).  An
+ *                         explicit call of the host program, accepted only before anything below has bound a library
+ *                         (DRS_ERR_ARG afterwards, or when `path` cannot be loaded): no environment variable substitutes it.
+ *   drs_rccl_available : 1 if librccl (or the named library) could be bound.
  *   drs_rccl_unique_id : ncclGetUniqueId into id128 (128 bytes, host memory); rank 0 calls it, the host hands the bytes to every rank.
  *   drs_rccl_comm_create / _destroy : ncclCommInitRank / ncclCommDestroy (collective over the ranks; the device must be current).
  *   drs_rccl_all_reduce : one in-place sum over the ranks on `stream` (dtype as in drs_net_buffer_info: 0 f32, 1 f64, 3 i32) -- the
@@ -349,6 +352,7 @@ int drs_net_set_comm(drs_net_t* net, int world, int rank, drs_allreduce_fn allre
 #define DRS_RCCL_FORM_ASYNC 2     /* DRS_RCCL_ASYNC != 0: two communicators, side streams, an event hand-over per asynchronous sum (r03) */
 #define DRS_RCCL_FORM_BUCKETS 3   /* DRS_RCCL_BUCKETS >= 2: inline + the gradient buffer as two all-reduces on comm_big's stream, the first under the rest of the backward pass */
 int drs_rccl_form(void);          /* the form drs_net_set_rccl will take, from the environment (the one place that parses it); ASYNC and BUCKETS want comm_big */
+int drs_rccl_bind_library(const char* path);
 int drs_rccl_available(void);
 int drs_rccl_unique_id(unsigned char* id128);
 int drs_rccl_comm_create(int world, int rank, const unsigned char* id128, void** comm);
@@ -358,6 +362,10 @@ int drs_net_set_rccl(drs_net_t* net, int world, int rank, void* comm_small, void
 int drs_train_step(drs_net_t* net, int B, int S, float lr0, int flags, double global_pixels, void* stream);
 int drs_forward(drs_net_t* net, int B, int S, int flags, int ignore_label, void* stream);
 int drs_apply_update(drs_net_t* net, float lr0, void* stream);        /* the update alone (after DRS_NO_UPDATE) */
+/* the backward pass of drs_train_step on two streams (the filter gradients on a stream of the library's beside the batch-norm-backward /
+ * input-gradient chain on `stream`): mode -1 = by the library's rule (steps of fewer than 2^18 pixels; the default), 0 = never (a
+ * host that must see every launch of the step on ITS stream), 1 = always.  Bitwise the same step in every mode. */
+int drs_net_set_two_streams(drs_net_t* net, int mode);
 /* per-kernel-family HIP-event timing of the launches of a step (bench.py's roofline figures); off by default */
 int drs_net_timing(drs_net_t* net, int enable);
 int drs_net_num_timing_kinds(void);

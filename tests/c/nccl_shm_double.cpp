@@ -1,4 +1,4 @@
-// TEST INFRASTRUCTURE -- not part of the product, never loaded unless DRS_RCCL_LIB names it.
+// TEST INFRASTRUCTURE -- not part of the product, never loaded unless a test names it through drs_rccl_bind_library.
 //
 // A stand-in for the five NCCL entry points the step engine binds (dynamic-rs-segmentation_amd/csrc/rccl_comm.hip:
 // ncclGetUniqueId, ncclCommInitRank, ncclCommDestroy, ncclAllReduce, ncclGetErrorString) for a box with ONE GPU, where RCCL

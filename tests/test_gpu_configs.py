@@ -51,19 +51,32 @@ def _conv_case(k, rate, cin, cout, B, S, arith="f32", ld=None):
     """forward, input gradient and filter gradient of one layer shape at (B, S) on the HIP path (either arithmetic), the input a
     channel slice [0, cin) of an `ld`-wide slab whose other channels hold junk, the input gradient ACCUMULATED into an `ld`-wide
     gradient slab when ld != cin: against the fp64 oracle on sampled patches, exactly for the filter gradient of a gradient that is
-    zero outside them, by adjointness on the dense one; skip-on / skip-off bitwise."""
-    from drs_amd import _lib
-    _lib = _lib.dev()         # libdrs_hip_dev.so: the same sources + the switch that forces the halo-tap skip on / off
+    zero outside the sampled patches, by adjointness on the dense one.
+
+    Which binary: everything that is compared with the oracle is computed by the PRODUCT library (libdrs_hip.so, `_lib.load()`: the
+    code object bench.py times) under its own launch rules.  The development library (libdrs_hip_dev.so, the same sources with
+    -DDRS_DEV) is called only for the two forced forms of the halo-tap skip (every tap multiplied / the all-halo ones skipped), which
+    must both give the product's bits.
+
+    cin < 8 is conv1 (isprs:1000: 5x5, `channels` -> 64): the bands zero-padded to 8 as drs_crop_normalize writes them, the filter
+    through drs_filter_pad_cin, the packed-tap kernel; no input gradient (the first layer has none)."""
+    from drs_amd import _lib as prod
+    devl = prod.dev()
+    prod.load()
     ns = {"f32": 0, "bf16x6": 3}[arith]
+    first = cin < 8
+    cin_real, cin = cin, (8 if first else cin)
     ld = ld or cin
     dense = ld != cin
     M = B * S * S
-    g0 = torch.Generator(device=DEV).manual_seed(1000 * k + 10 * rate + S + cin)
+    g0 = torch.Generator(device=DEV).manual_seed(1000 * k + 10 * rate + S + cin_real)
     pb, pa = onets.same_pad(k, rate)
     P = max(pb, pa)
     x = torch.randn(B, S, S, cin, device=DEV, generator=g0)
+    if first:
+        x[..., cin_real:] = 0
     g = torch.randn(B, S, S, cout, device=DEV, generator=g0)
-    w = torch.randn(k, k, cin, cout, device=DEV, generator=g0) / (k * k * cin) ** 0.5
+    w = torch.randn(k, k, cin_real, cout, device=DEV, generator=g0) / (k * k * cin_real) ** 0.5
     bias = torch.randn(cout, device=DEV, generator=g0)
     xw = x
     if dense:
@@ -71,98 +84,126 @@ def _conv_case(k, rate, cin, cout, B, S, arith="f32", ld=None):
         xw[..., :cin] = x
     xp, gp = _padded(xw, P), _padded(g, P)
     st = stream()
-    raw = _lib
     sample = sorted({0, B // 2, B - 1})
     gs = torch.zeros_like(g)
     gs[sample] = g[sample]
     gsp = _padded(gs, P)
     gx0 = torch.randn(M, ld, device=DEV, generator=g0) if dense else None
+    wk = w                                                      # the filter as the kernels take it
+    if first:
+        if ns:
+            pytest.skip("layer stays on the exact-fp32 kernels in every arithmetic")
+        wk = torch.empty(k, k, cin, cout, device=DEV)
+        prod.call("drs_filter_pad_cin", w.data_ptr(), wk.data_ptr(), k, cin_real, cin, cout, st)
     if ns:
         if cout % 64 or cin % 32:
             pytest.skip("layer stays on the exact-fp32 kernels in every arithmetic")
-        xt, gt, gst = _split_planes(_lib, xp, ns), _split_planes(_lib, gp, ns), _split_planes(_lib, gsp, ns)
+        xt, gt, gst = _split_planes(prod, xp, ns), _split_planes(prod, gp, ns), _split_planes(prod, gsp, ns)
         wf = torch.zeros(ns * w.numel(), dtype=torch.int16, device=DEV)
         wd = torch.zeros(ns * w.numel(), dtype=torch.int16, device=DEV)
         split_dgrad = cin % 64 == 0
-        _lib.call("drs_filter_split", w.data_ptr(), k, cin, cin, cout, ns, wf.data_ptr(), wd.data_ptr() if split_dgrad else None, st)
-        nsp = _lib.query("drs_conv_wgrad_split_splits", B, S, k, cin, cout, P, ns)
-        mt = _lib.query("drs_split_conv_mtile", cout)
+        prod.call("drs_filter_split", w.data_ptr(), k, cin, cin, cout, ns, wf.data_ptr(), wd.data_ptr() if split_dgrad else None, st)
+        nsp = prod.query("drs_conv_wgrad_split_splits", B, S, k, cin, cout, P, ns)
+        mt = prod.query("drs_split_conv_mtile", cout)
+        assert nsp == devl.query("drs_conv_wgrad_split_splits", B, S, k, cin, cout, P, ns)
     else:
-        nsp = _lib.query("drs_conv_wgrad_splits", B, S, k, cin, cout)
-        mt = _lib.query("drs_conv_mtile", cout)
+        nsp = prod.query("drs_conv_wgrad_splits", B, S, k, cin, cout)
+        mt = prod.query("drs_conv_mtile", cout)
+        assert nsp == devl.query("drs_conv_wgrad_splits", B, S, k, cin, cout)
     wt = torch.empty(w.numel(), device=DEV)
-    _lib.call("drs_filter_flip_transpose", w.data_ptr(), wt.data_ptr(), k, cin, cout, st)
-    slab = torch.empty(nsp * w.numel(), device=DEV)
+    if not first:
+        prod.call("drs_filter_flip_transpose", w.data_ptr(), wt.data_ptr(), k, cin, cout, st)
+    slab = torch.empty(nsp * wk.numel(), device=DEV)
     rows = (M + mt - 1) // mt
 
-    def run():
+    def run(L):
         y = torch.empty(M, cout, device=DEV)
         stats = torch.zeros(rows * cout * 2, device=DEV)
-        gx = gx0.clone() if dense else torch.empty(M, cin, device=DEV)
+        gx = gx0.clone() if dense else torch.zeros(M, cin, device=DEV)
         gw = torch.empty(w.numel(), device=DEV)
         gws = torch.empty(w.numel(), device=DEV)
         if ns:
-            _lib.call("drs_conv_forward_split", xt.data_ptr(), B, S, P, ld, 0, wf.data_ptr(), bias.data_ptr(), k, rate, pb, cin, cout,
-                      y.data_ptr(), cout, 0, 0, stats.data_ptr(), ns, st)
+            L.call("drs_conv_forward_split", xt.data_ptr(), B, S, P, ld, 0, wf.data_ptr(), bias.data_ptr(), k, rate, pb, cin, cout,
+                   y.data_ptr(), cout, 0, 0, stats.data_ptr(), ns, st)
             if split_dgrad:
-                _lib.call("drs_conv_forward_split", gt.data_ptr(), B, S, P, cout, 0, wd.data_ptr(), None, k, rate, pa, cout, cin, gx.data_ptr(),
-                          ld, 0, 1 if dense else 0, None, ns, st)
+                L.call("drs_conv_forward_split", gt.data_ptr(), B, S, P, cout, 0, wd.data_ptr(), None, k, rate, pa, cout, cin, gx.data_ptr(),
+                       ld, 0, 1 if dense else 0, None, ns, st)
             else:
-                _lib.call("drs_conv_forward", gp.data_ptr(), B, S, P, cout, 0, wt.data_ptr(), None, k, rate, pa, cout, cin, gx.data_ptr(), ld, 0,
-                          1 if dense else 0, None, st)
-            _lib.call("drs_conv_wgrad_split", xt.data_ptr(), B, S, P, ld, 0, gt.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout,
-                      slab.data_ptr(), gw.data_ptr(), ns, st)
-            _lib.call("drs_conv_wgrad_split", xt.data_ptr(), B, S, P, ld, 0, gst.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout,
-                      slab.data_ptr(), gws.data_ptr(), ns, st)
+                L.call("drs_conv_forward", gp.data_ptr(), B, S, P, cout, 0, wt.data_ptr(), None, k, rate, pa, cout, cin, gx.data_ptr(), ld, 0,
+                       1 if dense else 0, None, st)
+            L.call("drs_conv_wgrad_split", xt.data_ptr(), B, S, P, ld, 0, gt.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout,
+                   slab.data_ptr(), gw.data_ptr(), ns, st)
+            L.call("drs_conv_wgrad_split", xt.data_ptr(), B, S, P, ld, 0, gst.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout,
+                   slab.data_ptr(), gws.data_ptr(), ns, st)
         else:
-            _lib.call("drs_conv_forward", xp.data_ptr(), B, S, P, ld, 0, w.data_ptr(), bias.data_ptr(), k, rate, pb, cin, cout, y.data_ptr(),
-                      cout, 0, 0, stats.data_ptr(), st)
-            _lib.call("drs_conv_forward", gp.data_ptr(), B, S, P, cout, 0, wt.data_ptr(), None, k, rate, pa, cout, cin, gx.data_ptr(), ld, 0,
-                      1 if dense else 0, None, st)
-            _lib.call("drs_conv_wgrad", xp.data_ptr(), B, S, P, ld, 0, gp.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout, slab.data_ptr(),
-                      gw.data_ptr(), st)
-            _lib.call("drs_conv_wgrad", xp.data_ptr(), B, S, P, ld, 0, gsp.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout, slab.data_ptr(),
-                      gws.data_ptr(), st)
+            L.call("drs_conv_forward", xp.data_ptr(), B, S, P, ld, 0, wk.data_ptr(), bias.data_ptr(), k, rate, pb, cin, cout, y.data_ptr(),
+                   cout, 0, 0, stats.data_ptr(), st)
+            if not first:
+                L.call("drs_conv_forward", gp.data_ptr(), B, S, P, cout, 0, wt.data_ptr(), None, k, rate, pa, cout, cin, gx.data_ptr(), ld, 0,
+                       1 if dense else 0, None, st)
+            L.call("drs_conv_wgrad", xp.data_ptr(), B, S, P, ld, 0, gp.data_ptr(), P, cout, 0, k, rate, pb, cin, cin_real, cout, slab.data_ptr(),
+                   gw.data_ptr(), st)
+            L.call("drs_conv_wgrad", xp.data_ptr(), B, S, P, ld, 0, gsp.data_ptr(), P, cout, 0, k, rate, pb, cin, cin_real, cout, slab.data_ptr(),
+                   gws.data_ptr(), st)
         torch.cuda.synchronize()
         return y, stats, gx, gw, gws
 
-    res = {}
+    product = run(prod)             # libdrs_hip.so under its own rules: what every oracle comparison below is made on
+    forced = {}
     try:
-        for mode in (0, 2, 1):          # every tap / chunk multiplied; the all-halo ones skipped; the product's own rule (last)
-            raw.drs_debug_skip_taps(mode)
-            res[mode] = run()
+        for mode in (0, 2):         # development library: every tap / chunk multiplied; the all-halo ones skipped
+            devl.drs_debug_skip_taps(mode)
+            forced[mode] = run(devl)
     finally:
-        raw.drs_debug_skip_taps(1)
-    for a, b, c in zip(res[0], res[2], res[1]):
-        assert torch.equal(a, b) and torch.equal(a, c)          # skipped products are exact zeros: bitwise neutral
-    y, stats, gx, gw, gws = res[1]
+        devl.drs_debug_skip_taps(1)
+    for a, b, c in zip(forced[0], forced[2], product):
+        assert torch.equal(a, b) and torch.equal(a, c)          # skipped products are exact zeros: bitwise neutral, in either binary
+    y, stats, gx, gw, gws = product
     if dense:
         assert torch.equal(gx[:, cin:], gx0[:, cin:])           # channels beyond the slice are not touched
         gx = gx[:, :cin] - gx0[:, :cin]                         # what was accumulated (one fp32 rounding of the sum apart)
     tol = 1e-5 if not dense else 2e-5
     # (1) forward and input gradient on the sampled patches against the fp64 oracle
     w64, b64 = w.cpu().numpy().astype(np.float64), bias.cpu().numpy().astype(np.float64)
-    xs, gsn = x[sample].cpu().numpy().astype(np.float64), g[sample].cpu().numpy().astype(np.float64)
+    xs, gsn = x[sample][..., :cin_real].cpu().numpy().astype(np.float64), g[sample].cpu().numpy().astype(np.float64)
     ref = T.conv2d_same(xs, w64, rate) + b64
     gx_ref, gw_ref = T.conv2d_same_bwd(xs, w64, rate, gsn)
     assert rel_err(y.view(B, S, S, cout)[sample].cpu().numpy(), ref) < 1e-5
-    assert rel_err(gx.reshape(B, S, S, cin)[sample].cpu().numpy(), gx_ref) < tol
+    if not first:
+        assert rel_err(gx.reshape(B, S, S, cin)[sample].cpu().numpy(), gx_ref) < tol
     # (2) the filter gradient of the sampled patches (same grid, splits and chunk walk as the dense one), exactly
-    assert rel_err(gws.view(k, k, cin, cout).cpu().numpy(), gw_ref) < 1e-5
+    assert rel_err(gws.view(k, k, cin_real, cout).cpu().numpy(), gw_ref) < 1e-5
     # (3) dense filter gradient and dense input gradient by adjointness with the (checked) forward
     yb = y.double() - bias.double()
     a = (yb * g.reshape(M, cout).double()).sum().item()
-    b = (x.reshape(M, cin).double() * gx.double()).sum().item()
     c = (w.reshape(-1).double() * gw.double()).sum().item()
     scale = (yb.norm() * g.double().norm()).item()
-    assert abs(a - b) < (1e-6 if not dense else 3e-6) * scale and abs(a - c) < 1e-6 * scale, (a, b, c)
+    assert abs(a - c) < 1e-6 * scale, (a, c)
+    if not first:
+        b = (x.reshape(M, cin).double() * gx.double()).sum().item()
+        assert abs(a - b) < (1e-6 if not dense else 3e-6) * scale, (a, b)
     # (4) batch-norm statistics of the epilogue: per-tile sums reduce to the moments of y (ragged last M tile included)
-    sv = conv_stats_moments(_lib, stats, M, mt, cout)
+    sv = conv_stats_moments(prod, stats, M, mt, cout)
     y64 = y.double()
     mean = y64.mean(0).cpu().numpy()
     var = y64.var(0, unbiased=False).cpu().numpy()
     np.testing.assert_allclose(sv[:, 0] / M, mean, rtol=0, atol=1e-6 * np.abs(mean).max() + 1e-7)
     np.testing.assert_allclose(sv[:, 1] / M - (sv[:, 0] / M) ** 2, var, rtol=2e-6)
+
+
+# Dilated8Pooling, every layer (isprs:1000-1021): conv1 is the packed-tap kernel on 5 bands, conv3 the 4x4 / rate 3 asymmetric 4|5 pad
+D8P_SHAPES = [(5, 1, 5, 64), (5, 2, 64, 64), (4, 3, 64, 128), (4, 4, 128, 128), (3, 5, 128, 192), (3, 6, 192, 192), (3, 7, 192, 256),
+              (3, 8, 256, 256)]
+
+
+@pytest.mark.parametrize("B,S", [(128, 64), (16, 64), (16, 25), (16, 50)])
+@pytest.mark.parametrize("k,rate,cin,cout", D8P_SHAPES)
+def test_every_dilated8_layer_at_the_headline_shape_on_the_product_library(k, rate, cin, cout, B, S):
+    """VERDICT r05 item 1.  The shape bench.py's headline times -- 128 x 64 x 64: >= 4096 tiles AND S % 32 == 0, i.e. plain launches,
+    full tiles first, the halo-tap skip, the wave-uniform filter-gradient form -- and one rank's share of it (16 x 64 x 64) and of
+    configs[2] at a small and a middle side (16 x 25: offset tables in the filter gradient, stream-K forward; 16 x 50: row segments),
+    for all eight layers of `dilated_grsl_rate8`, element-wise against oracle/tf_ops.py on sampled patches, on libdrs_hip.so."""
+    _conv_case(k, rate, cin, cout, B, S, "f32")
 
 
 @pytest.mark.parametrize("arith", ["f32", "bf16x6"])

@@ -223,8 +223,10 @@ def _rccl_worker(rank, world, port, out, mode):
     communicator bound to the device, asynchronous gradient buckets, sync-BN sums, stream waits -- the code an 8-GPU run executes."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", DRS_FORCE_COLLECTIVES="1",
                       DRS_COMM={"rccl": "rccl", "launches": "rccl", "callback": "torch", "op": "torch"}[mode])
-    if mode == "launches":      # every sum a real launch with 20 us of wire time in the stream it is issued on (the library binds DRS_RCCL_LIB)
-        os.environ.update(DRS_RCCL_LIB=os.path.join(os.path.dirname(out), "libnccl_latency_double.so"), NCCL_DOUBLE_ALPHA_US="20", NCCL_DOUBLE_GBS="100")
+    if mode == "launches":      # every sum a real launch with 20 us of wire time in the stream it is issued on (the library binds the named stand-in)
+        os.environ.update(NCCL_DOUBLE_ALPHA_US="20", NCCL_DOUBLE_GBS="100")
+        from drs_amd import _lib
+        _lib.call("drs_rccl_bind_library", os.path.join(os.path.dirname(out), "libnccl_latency_double.so").encode())
     engine = mode != "op"
     import torch.distributed as dist
     from drs_amd.dist import TorchComm
@@ -284,10 +286,12 @@ def _rccl_forms_worker(rank, world, port, out, lib=None):
     """every form of the library-side collectives (drs_rccl_form: inline, asynchronous, inline + two overlapped gradient buckets) x the
     one- and two-stream backward pass, in ONE process on the real backend at world 1 with every collective forced on"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", DRS_FORCE_COLLECTIVES="1", DRS_COMM="rccl")
-    if lib:      # every sum a real launch that holds its stream for 30 us and keeps NaNs in the buffer meanwhile (nccl_latency_double.hip)
-        os.environ.update(DRS_RCCL_LIB=lib, NCCL_DOUBLE_ALPHA_US="30", NCCL_DOUBLE_GBS="50", NCCL_DOUBLE_POISON="1")
-    import torch.distributed as dist
     from drs_amd import _lib
+    if lib:      # every sum a real launch that holds its stream for 30 us and keeps NaNs in the buffer meanwhile (nccl_latency_double.hip)
+        os.environ.update(NCCL_DOUBLE_ALPHA_US="30", NCCL_DOUBLE_GBS="50", NCCL_DOUBLE_POISON="1")
+        _lib.call("drs_rccl_bind_library", lib.encode())
+        assert _lib.load().drs_rccl_bind_library(lib.encode()) == 1       # once bound, a second naming is rejected
+    import torch.distributed as dist
     from drs_amd.dist import TorchComm
     from drs_amd.net import DilatedNet
     torch.cuda.set_device(0)
@@ -299,10 +303,10 @@ def _rccl_forms_worker(rank, world, port, out, lib=None):
             for k in ("DRS_RCCL_ASYNC", "DRS_RCCL_BUCKETS"):
                 os.environ.pop(k, None)
             os.environ.update(env)
-            os.environ["DRS_TWO_STREAMS"] = two
             want = {"inline": 1, "async": 2, "buckets": 3, "async_word": 1}[form]        # atoi("yes") == 0: the LIBRARY's reading, and the label follows it
             assert _lib.query("drs_rccl_form") == want
             d = DilatedNet(NET, CH, K, 0.005, b_max=B, s_max=S, device="cuda:0", seed=3, comm=comm)
+            d.set_two_streams(int(two))
             assert d.collectives.startswith({1: "rccl (inline:", 2: "rccl (asynchronous", 3: "rccl (inline + two overlapped"}[want]), d.collectives
             for _ in range(3):
                 d.feed(x, y, S)
@@ -342,7 +346,7 @@ def test_every_form_of_the_library_side_collectives_gives_the_inline_forms_bits(
 # The library-side collectives at world > 1 on a one-GPU box.  RCCL refuses two ranks on one device, so until r05 the code that an
 # 8-GPU run executes -- engine.hip issuing the step's sums itself (inline / two buckets / asynchronous), beside the two-stream
 # backward pass -- had only ever run at world 1 (identities).  tests/c/nccl_shm_double.cpp is a shared-memory stand-in for the five
-# NCCL entry points the library binds (DRS_RCCL_LIB); the host group (gloo) only carries the communicator ids.  At two ranks a sum
+# NCCL entry points the library binds (named through drs_rccl_bind_library); the host group (gloo) only carries the communicator ids.  At two ranks a sum
 # of two operands is the same in any order, so every form must give the callback path's bits.
 DBL_B, DBL_S = 8, 33           # per rank: stream-K forward launches, the row-segment filter gradient, the two-stream backward pass
 
@@ -362,10 +366,11 @@ def _double_inputs(world):
 
 
 def _double_worker(rank, world, port, out, lib, cases):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), DRS_RCCL_LIB=lib,
-                      DRS_RCCL_INIT_TIMEOUT_S="150")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), DRS_RCCL_INIT_TIMEOUT_S="150")
     import torch.distributed as dist
+    from drs_amd import _lib
     from drs_amd.dist import TorchComm, shard_slice
+    _lib.call("drs_rccl_bind_library", lib.encode())       # the shared-memory stand-in for the five NCCL entry points the library binds
     from drs_amd.net import DilatedNet
     torch.cuda.set_device(0)
     comm = TorchComm("gloo")
@@ -373,10 +378,13 @@ def _double_worker(rank, world, port, out, lib, cases):
     sl = shard_slice(world * DBL_B, rank, world)
     res = {}
     for name, env in cases:
-        for k in ("DRS_COMM", "DRS_RCCL_ASYNC", "DRS_RCCL_BUCKETS", "DRS_TWO_STREAMS"):
+        for k in ("DRS_COMM", "DRS_RCCL_ASYNC", "DRS_RCCL_BUCKETS"):
             os.environ.pop(k, None)
+        env = dict(env)
+        two = env.pop("two_streams", None)
         os.environ.update(env)
         d = DilatedNet(NET, CH, K, 0.005, b_max=DBL_B, s_max=DBL_S, device="cuda:0", seed=3, comm=comm)
+        d.set_two_streams(two)
         if env.get("DRS_COMM") == "rccl":
             assert d.collectives.startswith("rccl") and d.ranks_observed == world, (d.collectives, getattr(d, "ranks_observed", None))
         else:
@@ -405,7 +413,7 @@ def test_library_side_collectives_at_two_ranks_give_the_callback_paths_bits(tmp_
     cases = [("callback", {"DRS_COMM": "torch"})]
     for form, env in (("inline", {}), ("buckets", {"DRS_RCCL_BUCKETS": "2"}), ("async", {"DRS_RCCL_ASYNC": "1"})):
         for two in ("0", "1"):
-            cases.append(("%s_%s" % (form, two), dict(rccl, DRS_TWO_STREAMS=two, **env)))
+            cases.append(("%s_%s" % (form, two), dict(rccl, two_streams=int(two), **env)))
     out = str(tmp_path / "double.npz")
     mp.spawn(_double_worker, args=(2, 29850 + os.getpid() % 1000, out, lib, cases), nprocs=2, join=True)
     r = np.load(out)

@@ -144,6 +144,20 @@ def test_halo_tap_skipping_is_bitwise_neutral(lib, k, rate, cin, cout, B, S):
         np.testing.assert_array_equal(a, b, err_msg=name)
     ref = T.conv2d_same(x.astype(np.float64), w.astype(np.float64), rate)
     assert rel_err(res[2][0].reshape(B, S, S, cout), ref) < 1e-5
+    # the product library (libdrs_hip.so, its own rule: no skip at these sizes) gives the same bits as both forced forms
+    from drs_amd import _lib as prod
+    out = torch.zeros(M * cout, dtype=torch.float32, device=DEV)
+    gx = torch.zeros(M * cin, dtype=torch.float32, device=DEV)
+    gw = torch.zeros(w.size, dtype=torch.float32, device=DEV)
+    prod.call("drs_conv_forward", xd.data_ptr(), B, S, P, cin, 0, wd.data_ptr(), None, k, rate, pb, cin, cout, out.data_ptr(), cout, 0, 0, None, stream())
+    prod.call("drs_conv_forward", gd.data_ptr(), B, S, P, cout, 0, wt.data_ptr(), None, k, rate, pa, cout, cin, gx.data_ptr(), cin, 0, 0, None, stream())
+    nsp = prod.query("drs_conv_wgrad_splits", B, S, k, cin, cout)
+    slab = torch.zeros(nsp * w.size, dtype=torch.float32, device=DEV)
+    prod.call("drs_conv_wgrad", xd.data_ptr(), B, S, P, cin, 0, gd.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout, slab.data_ptr(), gw.data_ptr(),
+              stream())
+    torch.cuda.synchronize()
+    for a, b, name in zip((out, gx, gw), res[0][:3], ("fwd", "dgrad", "wgrad")):
+        np.testing.assert_array_equal(a.cpu().numpy(), b, err_msg="product library, " + name)
 
 
 def test_conv1_band_padding(lib):
@@ -538,6 +552,19 @@ def test_register_staged_and_lds_dma_kernel_forms_are_bitwise_equal(lib, k, rate
         assert torch.equal(a, b)
     ref = T.conv2d_same(x.astype(np.float64), w.astype(np.float64), rate) + bias.astype(np.float64)
     assert rel_err(res[1][0].cpu().numpy().reshape(ref.shape), ref) < 1e-5
+    # the product library (libdrs_hip.so) picks one of the two forms per tile: the same bits, whichever it picked
+    from drs_amd import _lib as prod
+    out = torch.zeros(M * cout, dtype=torch.float32, device=DEV)
+    stats = torch.zeros(((M + mt - 1) // mt) * cout * 2, dtype=torch.float32, device=DEV)
+    prod.call("drs_conv_forward", xd.data_ptr(), B, S, P, cin, 0, wd.data_ptr(), bd.data_ptr(), k, rate, pb, cin, cout, out.data_ptr(), cout, 0, 0,
+              stats.data_ptr(), stream())
+    assert prod.query("drs_conv_wgrad_splits", B, S, k, cin, cout) == res[0][3]
+    slab = torch.zeros(res[0][3] * w.size, dtype=torch.float32, device=DEV)
+    gw = torch.zeros(w.size, dtype=torch.float32, device=DEV)
+    prod.call("drs_conv_wgrad", xd.data_ptr(), B, S, P, cin, 0, gd.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout, slab.data_ptr(), gw.data_ptr(),
+              stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out, res[1][0]) and torch.equal(stats, res[1][1]) and torch.equal(gw, res[1][2])
 
 
 @pytest.mark.parametrize("S,B", [(5, 3), (8, 5), (10, 2), (11, 3), (12, 2), (16, 3), (31, 1), (32, 2), (33, 1), (48, 1), (63, 1), (96, 1),
@@ -593,6 +620,14 @@ def test_filter_gradient_chunk_walk_over_patch_sides(lib, S, B):
     assert rel_err(outs[0].cpu().numpy().reshape(gw_ref.shape), gw_ref) < 1e-5
     for o in outs[1:]:
         assert torch.equal(outs[0], o)
+    from drs_amd import _lib as prod                  # libdrs_hip.so: its own pick of form, skip and addressing -- the same bits
+    nsp = prod.query("drs_conv_wgrad_splits", B, S, k, cin, cout)
+    slab = torch.zeros(nsp * w.size, dtype=torch.float32, device=DEV)
+    gw = torch.full((w.size,), 7.0, dtype=torch.float32, device=DEV)
+    prod.call("drs_conv_wgrad", xd.data_ptr(), B, S, P, cin, 0, gd.data_ptr(), P, cout, 0, k, rate, pb, cin, cin, cout, slab.data_ptr(), gw.data_ptr(),
+              stream())
+    torch.cuda.synchronize()
+    assert torch.equal(gw, outs[0])
     assert rel_err(gw_eq.cpu().numpy().reshape(gw_ref.shape), gw_ref) < 1e-5
     assert float((gw_eq - outs[0]).abs().max() / outs[0].abs().max()) < 2e-6
 
@@ -636,6 +671,21 @@ def test_classifier_forms_agree(lib, C, K, B, S, P):
     finally:
         lib.drs_debug_cls_variant(1)
     for a, b in zip(res[2], res[3]):
+        assert torch.equal(a, b)
+    from drs_amd import _lib as prod                  # libdrs_hip.so picks the form by class count and pixel count
+    logits = torch.zeros(M * K, dtype=torch.float32, device=DEV)
+    pred = torch.zeros(M, dtype=torch.uint8, device=DEV)
+    gfeat = torch.zeros(M * C, dtype=torch.float32, device=DEV)
+    dwp = torch.zeros(rows * C * K, dtype=torch.float32, device=DEV)
+    dbp = torch.zeros(rows * K, dtype=torch.float32, device=DEV)
+    lp = torch.zeros(rows, dtype=torch.float64, device=DEV)
+    conf = torch.zeros(K * K, dtype=torch.int32, device=DEV)
+    assert prod.query("drs_classifier_rows", B, S) == rows
+    prod.call("drs_classifier_loss", fd.data_ptr(), B, S, P, C, 0, C, K, wdev.data_ptr(), bdev.data_ptr(), yd.data_ptr(), lmd.data_ptr(),
+              amd.data_ptr(), 1.0 / max(1, int(lm.sum())), logits.data_ptr(), pred.data_ptr(), gfeat.data_ptr(), C, 0, dwp.data_ptr(), dbp.data_ptr(),
+              lp.data_ptr(), conf.data_ptr(), stream())
+    torch.cuda.synchronize()
+    for a, b in zip((logits, pred, gfeat, dwp, dbp, lp, conf), res[2] if K >= 4 else res[0]):
         assert torch.equal(a, b)
     assert torch.equal(res[0][1], res[2][1]) or float((res[0][1] != res[2][1]).float().mean()) < 1e-3
     assert torch.equal(res[0][6], res[2][6]) or float((res[0][6] - res[2][6]).abs().sum()) <= 2e-3 * M

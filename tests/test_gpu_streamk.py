@@ -50,6 +50,27 @@ def test_streamk_every_cut_matches_oracle(k, rate, cin, cout, B, S):
     pstats = torch.zeros(-(-M // mt) * cout * 2, device=DEV)
     lib.call("drs_conv_forward", xd.data_ptr(), B, S, P, cin, 0, wd.data_ptr(), bd.data_ptr(), k, rate, pb, cin, cout, plain.data_ptr(), cout, 0, 0,
              pstats.data_ptr(), st)
+    # the PRODUCT library (libdrs_hip.so) under its own rule for the cut: held to the oracle itself, and the development library at
+    # its default (-1 = the same rule) must give the same bits -- the forced cuts below then only vary the development binary
+    pws, pnws = _ws(_lib, cout)
+    pout = torch.full((M, cout + 32), -3.0, device=DEV)
+    pst = torch.zeros(-(-M // mt) * cout * 2, device=DEV)
+    _lib.call("drs_conv_forward_ws", xd.data_ptr(), B, S, P, cin, 0, wd.data_ptr(), bd.data_ptr(), k, rate, pb, cin, cout, pout.data_ptr(), cout + 32, 32,
+              0, pst.data_ptr(), pws.data_ptr(), pnws, st)
+    dout = torch.full((M, cout + 32), -3.0, device=DEV)
+    dst = torch.zeros(-(-M // mt) * cout * 2, device=DEV)
+    lib.drs_debug_conv_splitk(-1)
+    lib.call("drs_conv_forward_ws", xd.data_ptr(), B, S, P, cin, 0, wd.data_ptr(), bd.data_ptr(), k, rate, pb, cin, cout, dout.data_ptr(), cout + 32, 32,
+             0, dst.data_ptr(), ws.data_ptr(), nws, st)
+    torch.cuda.synchronize()
+    assert pnws == nws and mt == _lib.query("drs_conv_mtile", cout)
+    got = pout.cpu().numpy()
+    assert np.all(got[:, :32] == -3.0)
+    assert rel_err(got[:, 32:].reshape(B, S, S, cout), ref) < 1e-5
+    sv = conv_stats_moments(_lib, pst, M, mt, cout)
+    assert np.abs(sv[:, 0] - ref.reshape(-1, cout).sum(0)).max() < 1e-5 * np.abs(ref.reshape(-1, cout)).sum(0).max()
+    assert rel_err(sv[:, 1], (ref.reshape(-1, cout) ** 2).sum(0)) < 1e-5
+    assert torch.equal(pout, dout) and torch.equal(pst, dst)
     whole = [W for W in range(1, tiles + 1) if U % W == 0 and (U // W) % nks == 0]
     cuts = sorted({1, 2, 3, 7, tiles - 1, tiles, tiles + 1, 2 * tiles, 3 * tiles + 1, U // 2, U - 1, U, U + 5, 768} | set(whole[:3]))
     try:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """In-process A/B of one rank's training step (development library) over wave-priority / stream arms, interleaved on one device.
-An arm is a string of settings: t<-1|0|1> two-stream backward pass (DRS_TWO_STREAMS: a net per value; 9 = the rule),
+An arm is a string of settings: t<-1|0|1> two-stream backward pass (drs_net_set_two_streams: a net per value; 9 = the rule),
 w<0|1|2|9> filter gradient's wave priority by remaining work (drs_debug_wgrad_prio; 9 = the rule), c<0|1|3|9> forward /
 input-gradient kernel (drs_debug_conv_prio; 3 = every launch at the top level; 9 = the rule),
 e<0|1|2|9> the chain of the two-stream backward pass at the top level (drs_debug_chain_mode: 1 input-gradient launches, 2 + batch-norm backward; 9 = as the engine asks: 1 without collectives, 2 with),
@@ -28,8 +28,10 @@ def parse(arm):
 def main(B=16, Ss=(64,), arms=("t9w9c9",), steps=20, rounds=4, comm_kind="none"):
     dev = "cuda:0"
     comm = None
-    if comm_kind == "rccl":      # every collective of the step issued by the library at world 1 (DRS_RCCL_LIB: through that NCCL-API library,
-        # e.g. tools/ubench/nccl_latency_double.hip, whose all-reduces are real launches with a wire time)
+    if comm_kind == "rccl":      # every collective of the step issued by the library at world 1 (AB_RCCL_LIB, this tool's variable: through that
+        # NCCL-API library, e.g. tools/ubench/nccl_latency_double.hip, whose all-reduces are real launches with a wire time)
+        if os.environ.get("AB_RCCL_LIB"):
+            _lib.call("drs_rccl_bind_library", os.environ["AB_RCCL_LIB"].encode())
         os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29536", DRS_FORCE_COLLECTIVES="1", DRS_COMM="rccl")
         from drs_amd.dist import TorchComm
         torch.cuda.set_device(0)
@@ -41,11 +43,8 @@ def main(B=16, Ss=(64,), arms=("t9w9c9",), steps=20, rounds=4, comm_kind="none")
     for a in arms:
         t = parse(a)[0]
         if t not in nets:
-            if t >= 0:
-                os.environ["DRS_TWO_STREAMS"] = str(t)
-            else:
-                os.environ.pop("DRS_TWO_STREAMS", None)
             nets[t] = DilatedNet("dilated_grsl_rate8", 5, 6, 0.005, b_max=B, s_max=smax, device=dev, comm=comm)
+            nets[t].set_two_streams(t)
     for S in Ss:
         inst = grid_instances(1024, 1024, S, 25, 4096, seed=0)
         best = {a: [] for a in arms}
@@ -57,10 +56,7 @@ def main(B=16, Ss=(64,), arms=("t9w9c9",), steps=20, rounds=4, comm_kind="none")
                 d.drs_debug_conv_prio(c)
                 d.drs_debug_chain_mode(e)
                 d.drs_debug_wgrad_ablate(ab)
-                if rc:
-                    os.environ["DRS_REDUCTIONS_ON_CHAIN"] = "1"
-                else:
-                    os.environ.pop("DRS_REDUCTIONS_ON_CHAIN", None)
+                d.drs_debug_reductions_on_chain(1 if rc else 0)
                 np.random.seed(0)
                 def step(i):
                     rows = inst[(i * B) % 4000:(i * B) % 4000 + B]

@@ -17,6 +17,9 @@ def main(B=16, S=64, steps=20, arith="f32", comm_kind="none"):
     if comm_kind != "none":
         os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", DRS_FORCE_COLLECTIVES="1")
         os.environ["DRS_COMM"] = "rccl" if comm_kind == "rccl" else "torch"
+        if os.environ.get("BENCH_RCCL_LIB"):      # this tool's own variable (a stand-in whose sums are real launches, tools/ubench/nccl_latency_double.hip)
+            from drs_amd import _lib
+            _lib.call("drs_rccl_bind_library", os.environ["BENCH_RCCL_LIB"].encode())
         if comm_kind == "callback2":
             os.environ["DRS_BN_COMM"] = "1"
         from drs_amd.dist import TorchComm

@@ -3,7 +3,7 @@
 sharing the one GPU over gloo (the callback collectives), each with its shard, against the single-process step on the whole batch --
 loss, gradients, updated variables, moving statistics, confusion matrix.  (The bounds are those of tests/test_gpu_dp.py: the sums
 associate differently, so a few ReLU signs / pool winners flip.)      python tools/fuzz_dp.py [n=10] [seed=0]
-With DRS_COMM=rccl DRS_RCCL_LIB=<tests/c/nccl_shm_double.cpp built> in the environment the ranks' sums are issued by the LIBRARY over the
+With DRS_COMM=rccl FUZZ_DP_RCCL_LIB=<tests/c/nccl_shm_double.cpp built> in the environment the ranks' sums are issued by the LIBRARY over the
 shared-memory stand-in for RCCL instead (the line says which path ran)."""
 import os, sys, tempfile
 import numpy as np
@@ -23,6 +23,9 @@ def inputs(cfg):
 def worker(rank, cfg, port, out):
     net, ch, K, W, b, S = cfg
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(W))
+    if os.environ.get("FUZZ_DP_RCCL_LIB"):      # this tool's own variable: the library itself reads none (drs_rccl_bind_library is a call)
+        from drs_amd import _lib
+        _lib.call("drs_rccl_bind_library", os.environ["FUZZ_DP_RCCL_LIB"].encode())
     import torch.distributed as dist
     from drs_amd.dist import TorchComm, shard_slice
     from drs_amd.net import DilatedNet

@@ -1,4 +1,4 @@
-// DEVELOPMENT AID (tools/collectives_model.sh) -- not part of the product, never loaded unless DRS_RCCL_LIB names it.
+// DEVELOPMENT AID (tests/test_gpu_dp.py, tools/bench_step.py BENCH_RCCL_LIB=) -- not part of the product, never loaded unless a caller names it through drs_rccl_bind_library.
 //
 // A WORLD-1 stand-in for the five NCCL entry points the step engine binds that gives every all-reduce a WIRE TIME: the call enqueues,
 // on the stream it is given, a one-wave kernel that sleeps for  alpha + bytes / beta  (NCCL_DOUBLE_ALPHA_US, NCCL_DOUBLE_GBS) and
