@@ -57,6 +57,20 @@ def mark(stage, rank=None):
 
 
 _CHILDREN = []           # process groups this (GPU-free) parent started and has not reaped yet
+_PENDING = {"lines": None}      # the finished default run's output while the optional second pass is still running (supervise)
+
+
+def _flush_pending():
+    """write the finished first run's line(s) exactly once, from wherever the supervisor leaves (normal return, signal handler)"""
+    lines, _PENDING["lines"] = _PENDING["lines"], None
+    if not lines:
+        return
+    for ln in lines:
+        (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln + "\n")
+    try:
+        sys.stdout.flush()
+    except Exception:
+        pass
 
 
 def _kill_group(proc):
@@ -92,8 +106,18 @@ def _install_cleanup_handlers():
     import signal
 
     def handler(signum, frame):
+        _flush_pending()          # a completed measurement is never lost to a teardown during the optional second pass
         for proc in list(_CHILDREN):
             _kill_group(proc)
+        # the plain parent relays its launcher's stdout at the end: a line a rank's supervisor got out while it was being torn down
+        # (its own _flush_pending) is passed on here
+        st = _PENDING.get("relay")
+        if st is not None:
+            time.sleep(0.3)       # (the pump thread reads what the dying children wrote)
+            js = [ln for ln in "".join(st["out"]).splitlines() if ln.strip().startswith("{")]
+            if js:
+                sys.stdout.write(js[-1] + "\n")
+                sys.stdout.flush()
         os._exit(128 + signum)
     for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
         try:
@@ -102,17 +126,20 @@ def _install_cleanup_handlers():
             pass
 
 
-def _run_watched(cmd, env, limit_s, need_marks=True, rendezvous_slack=1.0):
+def _run_watched(cmd, env, limit_s, need_marks=True, rendezvous_slack=1.0, wall_limit_s=None):
     """start `cmd` as a fresh process group, relay its stderr (watching the markers) and collect its stdout.
     Returns (rc or None if killed by the watchdog, stdout text, last marker stage, the silence limit that applied last).
     `rendezvous_slack` multiplies the limit until the process group is up: the ranks of a fall-back attempt arrive up to one watchdog
-    period apart (each supervisor times out alone).  However this function is left (return, exception, signal handler), the child's
-    process group does not outlive it."""
+    period apart (each supervisor times out alone).  `wall_limit_s`: a cap on the child's TOTAL run time, markers or not.  However
+    this function is left (return, exception, signal handler), the child's process group does not outlive it."""
     import subprocess
     import threading
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True, preexec_fn=_die_with_parent)
     _CHILDREN.append(proc)
     state = dict(last=time.time(), stage="started", out=[])
+    t_start = time.time()
+    if not need_marks:
+        _PENDING["relay"] = state      # (plain_parent's one child: see the signal handler)
 
     def pump_err():
         for raw in iter(proc.stderr.readline, b""):
@@ -150,6 +177,11 @@ def _run_watched(cmd, env, limit_s, need_marks=True, rendezvous_slack=1.0):
                     sys.stderr.write("bench.py watchdog: no progress marker for %.0f s after stage '%s': killing the process group\n" % (lim, state["stage"]))
                     killed = True
                     break
+                if wall_limit_s is not None and time.time() - t_start > wall_limit_s:
+                    sys.stderr.write("bench.py watchdog: %.0f s of wall time used up at stage '%s': killing the process group\n" % (wall_limit_s, state["stage"]))
+                    lim = wall_limit_s
+                    killed = True
+                    break
     finally:
         # the leader may be gone while members of its group live on (a launcher's ranks): signal the GROUP whatever the leader's state
         if killed or proc.poll() is None:
@@ -175,8 +207,13 @@ def _fallback_port(port0, i):
     import socket
     import tempfile
     derived = port0 + 101 * i
-    path = os.path.join(tempfile.gettempdir(), "drs_bench_%d_%d_%d.port" % (os.getppid(), port0, i))
+    # keyed by the launcher's pid AND a per-launch token (a reused pid with the same port must not find an earlier launch's file)
+    path = os.path.join(tempfile.gettempdir(), "drs_bench_%d_%s_%d_%d.port" % (os.getppid(), _launch_token(), port0, i))
     if os.environ.get("RANK", "0") == "0":
+        try:
+            os.unlink(path)          # whatever is there is not this attempt's
+        except OSError:
+            pass
         port = derived
         try:
             with socket.socket() as so:
@@ -193,7 +230,9 @@ def _fallback_port(port0, i):
         except OSError:
             return derived
         return port
-    t_end = time.time() + float(os.environ.get("DRS_BENCH_PORT_WAIT_S", "30"))
+    # rank 0's supervisor may arrive a whole watchdog period (x its rendezvous slack) after this one: wait that long before giving up
+    stage_s = float(os.environ.get("DRS_BENCH_WATCHDOG_STAGE_S", "120"))
+    t_end = time.time() + float(os.environ.get("DRS_BENCH_PORT_WAIT_S", str(2.5 * stage_s)))
     while time.time() < t_end:
         try:
             return int(open(path).read().strip())
@@ -213,6 +252,11 @@ def supervise(argv):
         env = dict(os.environ)
         env.update(extra)
         env.update(DRS_BENCH_CHILD="1", DRS_BENCH_ATTEMPT=label, DRS_BENCH_FALLBACK_REASON=reason)
+        # first contact with RCCL at N > 1 must be cheap to diagnose: warnings of every attempt go to a file per attempt and rank
+        # (RCCL itself expands %h / %p); after a failed attempt its tail travels in the next attempt's line and in the failure line
+        env.setdefault("NCCL_DEBUG", "WARN")
+        if "NCCL_DEBUG_FILE" not in os.environ:
+            env["NCCL_DEBUG_FILE"] = os.path.join(_tmpdir(), "drs_bench_nccl_%d_%s_rank%s.%%h.%%p.log" % (os.getppid(), label, os.environ.get("RANK", "0")))
         if i > 0:
             # a rendezvous of its own: the launcher's store still holds the keys of the attempt that was killed.  Rank 0's child hosts it.
             env.update(MASTER_PORT=str(_fallback_port(port0, i)), TORCHELASTIC_USE_AGENT_STORE="False")
@@ -220,17 +264,24 @@ def supervise(argv):
         if rc == 0:
             # stdout carries the ONE JSON line (rank 0's) and nothing else: whatever a library printed to the child's descriptor 1 goes to stderr
             lines = out.splitlines()
+            _PENDING["lines"] = lines       # from here on the line gets out whatever happens (signal handler, exception below)
             if label == "default" and os.environ.get("DRS_BENCH_SECOND_PASS", "1") != "0":
-                lines = _second_pass(argv, port0, lines)
-            for ln in lines:
-                (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln + "\n")
-            sys.stdout.flush()
+                try:
+                    _PENDING["lines"] = _second_pass(argv, port0, lines)
+                except Exception as e:      # the optional pass must never cost the first one
+                    sys.stderr.write("bench.py supervisor: second pass failed in the supervisor: %r\n" % (e,))
+            _flush_pending()
+            _cleanup_port_files(port0)
             return 0
         reason = ("timeout: silent for %.0f s after stage '%s'" % (lim, stage)) if rc is None else ("exit code %s after stage '%s'" % (rc, stage))
         reason = "%s attempt: %s" % (label, reason)
+        tail = _nccl_debug_tail(env.get("NCCL_DEBUG_FILE"))
+        if tail:
+            os.environ["DRS_BENCH_NCCL_TAIL"] = tail      # the next attempt's line carries it (extra.first_contact.failed_attempt_nccl_tail)
         sys.stderr.write("bench.py supervisor (rank %s): %s%s\n" % (os.environ.get("RANK", "?"), reason, "; falling back" if i + 1 < len(chain) else "; giving up"))
+    _cleanup_port_files(port0)
     if os.environ.get("RANK", "0") == "0":
-        sys.stdout.write(failure_line("every attempt failed; last: " + reason))
+        sys.stdout.write(failure_line("every attempt failed; last: " + reason, nccl_tail=os.environ.get("DRS_BENCH_NCCL_TAIL")))
         sys.stdout.flush()
     else:
         # the launcher tears every rank down as soon as ONE exits non-zero: let rank 0's line get out first
@@ -249,8 +300,9 @@ def _second_pass(argv, port0, first_lines):
     env.update(DRS_BENCH_CHILD="1", DRS_BENCH_ATTEMPT="buckets", DRS_BENCH_FALLBACK_REASON="", DRS_BENCH_IS_SECOND_PASS="1",
                MASTER_PORT=str(_fallback_port(port0, 7)), TORCHELASTIC_USE_AGENT_STORE="False")
     limit = float(os.environ.get("DRS_BENCH_SECOND_PASS_LIMIT_S", "120"))
-    rc, out, stage, lim = _run_watched([sys.executable, os.path.abspath(__file__)] + argv + ["--no-cpu-baseline", "--no-opt-in", "--no-size-table"],
-                                       env, limit, rendezvous_slack=1.5)
+    wall = float(os.environ.get("DRS_BENCH_SECOND_PASS_WALL_S", "240"))       # silence AND total time are bounded: the driver's own limit is not ours to spend
+    rc, out, stage, lim = _run_watched([sys.executable, os.path.abspath(__file__)] + argv + ["--no-cpu-baseline", "--no-opt-in", "--no-size-table", "--no-configs"],
+                                       env, limit, rendezvous_slack=1.5, wall_limit_s=wall)
     if os.environ.get("RANK", "0") != "0":
         return first_lines
     res = None
@@ -282,9 +334,50 @@ def _second_pass(argv, port0, first_lines):
     return merged
 
 
-def failure_line(error):
+def failure_line(error, nccl_tail=None):
     return json.dumps({"metric": "training patches/sec dilated_grsl_rate8 64x64x5", "value": None, "unit": "patches/s",
-                       "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "error": error}) + "\n"
+                       "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "error": error,
+                       "extra": {"first_contact": {"failed_attempt_nccl_tail": nccl_tail}}}) + "\n"
+
+
+def _tmpdir():
+    import tempfile
+    return tempfile.gettempdir()
+
+
+def _launch_token():
+    """what tells one launch's files from another's with a reused pid: the launcher's run id where there is one"""
+    import hashlib
+    start = ""
+    try:       # the launcher (the supervisors' common parent): its start time in clock ticks since boot -- the same for every rank, new per launch
+        start = open("/proc/%d/stat" % os.getppid()).read().rsplit(")", 1)[1].split()[19]
+    except (OSError, IndexError):
+        pass
+    return hashlib.sha1((os.environ.get("TORCHELASTIC_RUN_ID", "") + "|" + os.environ.get("MASTER_PORT", "") + "|" + start).encode()).hexdigest()[:10]
+
+
+def _nccl_debug_tail(pattern, nlines=12):
+    """the last lines RCCL wrote (NCCL_DEBUG=WARN) into this rank's debug file(s) of a failed attempt, as one short string"""
+    import glob
+    if not pattern:
+        return None
+    out = []
+    for f in sorted(glob.glob(pattern.replace("%h", "*").replace("%p", "*"))):
+        try:
+            out.extend(ln.rstrip() for ln in open(f, errors="replace").read().splitlines()[-nlines:])
+        except OSError:
+            continue
+    text = " | ".join(ln for ln in out[-nlines:] if ln)
+    return text[-1500:] if text else None
+
+
+def _cleanup_port_files(port0):
+    import glob
+    for f in glob.glob(os.path.join(_tmpdir(), "drs_bench_%d_%s_%d_*.port*" % (os.getppid(), _launch_token(), port0))):
+        try:
+            os.unlink(f)
+        except OSError:
+            pass
 
 
 def plain_parent(args, argv):
@@ -567,6 +660,108 @@ def per_rank_size_table(dev, pool, mean, std, sizes=(25, 35, 45, 55, 64, 65, 75,
                 note="one rank's step at the per-rank batch of an 8-GPU run, no collectives; stream-K convolutions below 4096 tiles")
 
 
+def baseline_configs(dev, steps=20):
+    """BASELINE.json configs[1..4] on this one GPU, outside the timed region (the same loops and draws as
+    tools/bench_configs.py, so the driver's line and the builder's logs can be held against each other):
+      config 2  dilated_grsl (Dilated6Pooling), single_fixed 64 x 64, 5 bands, batch 64, 2048^2 tile       isprs:962-993
+      config 3  dilated_grsl_rate8, `uniform` over [25, 85] (any integer side per step, isprs:1727-1737), batch 128
+      config 4  dilated_icpr_rate6_densely (DenseDilated6), `multinomial` over {25, 50, 75, 100}, 4 bands, 2 classes, batch 128
+      config 5  dilated_grsl_rate8 sliding-window inference of a 6000 x 6000 x 5 mosaic, 64 x 64 windows at stride 32, overlap-add of
+                the logits, arg-max map (isprs:1241-1284) + a checksum of that map
+    Each: the rate, and its share of the fp32 MFMA ceiling (algorithmic flops of the steps really run / time / 157.3 TFLOP/s)."""
+    from drs_amd.net import DilatedNet
+    from drs_amd import loops, patches as P
+    from drs_amd.synthetic import make_tile, grid_instances
+    out = {}
+
+    def train_rate(key, net_type, ch, K, B, tile_side, draw, label):
+        tile, lab = make_tile(tile_side, tile_side, ch, K, seed=1234)
+        pool = P.TilePool([tile], [lab], dev, dtype=np.float64)
+        mean, std = tile[:, :, :3].mean(axis=(0, 1)).tolist(), tile[:, :, :3].std(axis=(0, 1)).tolist()
+        np.random.seed(11)
+        sizes = [draw() for _ in range(steps + 5)]
+        s_max = max(sizes)
+        net = DilatedNet(net_type, ch, K, WD, b_max=B, s_max=s_max, device=dev, seed=42)
+        inst = grid_instances(tile_side, tile_side, s_max, 25, max(B * 64, 2 * B), seed=0)
+
+        def step(i):
+            sd = sizes[i]
+            o = (i * B) % max(1, len(inst) - B)
+            rows = inst[o:o + B]
+            aug = P.draw_augmentation(rows, sd, ch, noise="device")
+            P.crop_to_net(net, pool, rows, sd, mean, std, aug)
+            return net.train_step(B, sd, LR)
+        for i in range(5):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(5, steps + 5):
+            res = step(i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        px = sum(B * sd * sd for sd in sizes[5:])
+        flops = 3 * 2 * net.plan.mac_per_pixel() * px
+        out[key] = dict(workload=label, value=round(B * steps / dt, 1), unit="patches/s", ms_per_step=round(1e3 * dt / steps, 3), steps=steps, warmup=5,
+                        batch=B, mean_side=round(float(np.mean(sizes[5:])), 1), trained_mpx_per_s=round(px / dt / 1e6, 1),
+                        tflops=round(flops / dt / 1e12, 1), fp32_ceiling_frac=round(flops / dt / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+                        final_loss=round(net.loss_value(res["loss_parts"]), 5))
+        del net, pool
+        torch.cuda.empty_cache()
+        mark("%s done" % key)
+    train_rate("config2", "dilated_grsl", 5, 6, 64, 2048, lambda: 64,
+               "dilated_grsl (Dilated6Pooling) training, single_fixed 64x64, 5 bands, batch 64, 2048x2048 tile")
+    v3 = [25, 45, 65, 85]
+    train_rate("config3", NET, CHANNELS, CLASSES, 128, 2048, lambda: P.draw_patch_size("uniform", v3)[0],
+               "dilated_grsl_rate8 training, `uniform` over [25, 85] (any integer side per step), 5 bands, batch 128 on ONE GPU")
+    v4 = [25, 50, 75, 100]
+    probs = P.define_multinomial_probs(v4)
+    train_rate("config4", "dilated_icpr_rate6_densely", 4, 2, 128, 500, lambda: P.draw_patch_size("multinomial", v4, probs)[0],
+               "dilated_icpr_rate6_densely (DenseDilated6) training, `multinomial` over {25,50,75,100}, update_type=loss sizes, 4 bands, 2 classes, batch 128 on ONE GPU")
+    # ---- config 5: the mosaic is made ON the device (SURVEY 8d's recipe: bands 0-2 U[0,1) under a 9 x 9 box filter, band 3 U[0,1), band 4
+    # 0.2 U[0,1); a host-side make_tile of 36 M pixels takes ~40 s and adds nothing to a forward-only timing)
+    n, S, Bw = 6000, 64, 256
+    g0 = torch.Generator(device=dev).manual_seed(5)
+    m = torch.rand(5, n, n, device=dev, generator=g0)
+    m[:3] = torch.nn.functional.avg_pool2d(m[:3].unsqueeze(0), 9, stride=1, padding=4, count_include_pad=False)[0]
+    m[4] *= 0.2
+    mosaic = m.permute(1, 2, 0).contiguous().reshape(-1)
+    mean = m[:3].mean(dim=(1, 2)).tolist()
+    std = m[:3].std(dim=(1, 2)).tolist()
+    del m
+    pool = P.TilePool([np.zeros((S, S, CHANNELS), dtype=np.float32)], None, dev, dtype=np.float32)      # shell; the mosaic is on the device already
+    pool.tiles, pool.labels = mosaic, torch.zeros(n * n, dtype=torch.uint8, device=dev)
+    pool.h, pool.w = [n], [n]
+    pool.tile_h = torch.tensor([n], dtype=torch.int32, device=dev)
+    pool.tile_w = torch.tensor([n], dtype=torch.int32, device=dev)
+    net = DilatedNet(NET, CHANNELS, CLASSES, WD, b_max=Bw, s_max=S, device=dev, seed=42)
+    P.crop_to_net(net, pool, np.concatenate([np.zeros((Bw, 1), dtype=np.int64), P.window_positions(n, n, S, S // 2, 0, Bw)], axis=1), S, mean, std)
+    net.forward(Bw, S)                       # code objects loaded outside the timing
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pred, _ = loops.predict_tile(net, pool, 0, S, Bw, mean, std)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nh, nw = P.window_counts(n, n, S, S // 2)
+    nwin = nh * nw
+    flops = 2.0 * net.plan.mac_per_pixel() * nwin * S * S
+    hist = torch.bincount(pred.reshape(-1).long(), minlength=CLASSES)
+    idx = torch.arange(n * n, device=dev, dtype=torch.int64)
+    checksum = int(((pred.reshape(-1).long() + 1) * (idx % 65521 + 1)).sum().item() % (1 << 61))
+    out["config5"] = dict(workload="dilated_grsl_rate8 sliding-window inference, 6000x6000x5 synthetic mosaic, 64x64 windows at stride 32, "
+                                   "overlap-add of logits + arg-max map, ONE GPU (window batches of 256)",
+                          value=round(dt, 3), unit="s", windows=nwin, window_mpx_per_s=round(nwin * S * S / dt / 1e6, 1),
+                          map_mpx_per_s=round(n * n / dt / 1e6, 2), fp32_floor_s=round(flops / (PEAK_FP32_MFMA_TFLOPS * 1e12), 3),
+                          fp32_ceiling_frac=round(flops / dt / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+                          map_class_histogram=[int(v) for v in hist.tolist()],
+                          map_checksum="sum((label+1) * (flat_index %% 65521 + 1)) mod 2^61 = %d" % checksum)
+    del net, pool, pred, mosaic
+    torch.cuda.empty_cache()
+    mark("config5 done")
+    out["note"] = ("BASELINE.json configs[1..4] on one GPU, each outside the headline's timed region; same loops, seeds and draws as "
+                   "tools/bench_configs.py (config 5's mosaic is synthesised on the device here)")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -576,6 +771,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-opt-in", action="store_true", help="skip the short bf16x3 measurement reported beside the fp32 headline")
     ap.add_argument("--no-size-table", action="store_true", help="skip the per-rank patch-size table (N = 1 only)")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 2-5 beside the headline (N = 1 only, ~15 s)")
     ap.add_argument("--arith", choices=sorted(ARITH), default="f32",
                     help="arithmetic of the convolution kernels: exact fp32 MFMA (default) or split-bf16 (conv_split.hip)")
     args = ap.parse_args()
@@ -619,8 +815,10 @@ def main():
     if forced:
         for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
             os.environ.setdefault(k, v)
+    t_pg = time.perf_counter()
     if world > 1 or forced:
         comm = TorchComm("gloo" if rehearsal else "nccl")
+    t_pg = time.perf_counter() - t_pg
     rank = comm.rank if comm else 0
     mark("process group up")
     B_local = GLOBAL_BATCH // world
@@ -654,14 +852,26 @@ def main():
         P.crop_to_net(net, pool, rows[sl], PATCH, mean, std, mine)
         return net.train_step(B_local, PATCH, LR)      # loss parts, predictions and the confusion matrix stay on the device
 
-    if args.warmup == 0:
-        one_step()          # with W = 0 still load the code objects / create the communicators outside the timed region
-    for _ in range(args.warmup):
+    t_first = time.perf_counter()
+    one_step()              # with W = 0 still load the code objects / create the communicators outside the timed region
+    torch.cuda.synchronize()
+    t_first = time.perf_counter() - t_first
+    mark("first step done")
+    for _ in range(max(0, args.warmup - 1)):
         one_step()
     if comm:
         comm.barrier()
     torch.cuda.synchronize()
     mark("warm-up done")
+    # the first contact of this world size with the collectives, per rank: host process-group set-up, seconds inside
+    # ncclCommInitRank per library-side communicator, the first all-reduce, the first whole step (RCCL's kernels and connections load there)
+    first_contact = None
+    if comm:
+        mine = dict(rank=rank, process_group_init_s=round(t_pg, 3), first_step_s=round(t_first, 3), **(getattr(net, "first_contact", None) or {}))
+        first_contact = dict(per_rank=comm.gather_objects(mine), nccl_debug=os.environ.get("NCCL_DEBUG"),
+                             failed_attempt_nccl_tail=os.environ.get("DRS_BENCH_NCCL_TAIL") or None,
+                             note="seconds, per rank: torch.distributed process group; ncclCommInitRank per library-side communicator "
+                                  "(engine.py _install_rccl); its first all-reduce; the first training step with its collectives")
     # one HIP event per step on the launch stream (an asynchronous record: not on the host's critical path): the MEDIAN step, SURVEY 8(d)
     step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
@@ -788,6 +998,10 @@ def main():
     if world == 1 and args.arith == "f32" and not args.no_size_table and not forced:
         size_table = per_rank_size_table(dev, pool, mean, std)
     mark("size table done")
+    configs = None
+    if world == 1 and args.arith == "f32" and not args.no_configs and not forced:
+        configs = baseline_configs(dev)
+    mark("configs done")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -819,7 +1033,7 @@ def main():
             "workspace_gb_per_gpu": round(net.workspace_bytes() / 1e9, 2),
             "train_tflops": round(value * 3 * 2 * net.plan.mac_per_pixel() * PATCH * PATCH / 1e12, 2),
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "opt_in_arithmetic": opt_in,
-            "extra": {"per_rank_size_table": size_table, "per_rank_ms": per_rank_ms,
+            "extra": {"configs": configs, "first_contact": first_contact, "per_rank_size_table": size_table, "per_rank_ms": per_rank_ms,
                       "step_ms_events": dict(median=round(step_ms[len(step_ms) // 2], 3), min=round(step_ms[0], 3), max=round(step_ms[-1], 3),
                                              note="HIP events between consecutive steps on rank 0's launch stream; `value` stays steps / wall time")},
         }

@@ -470,21 +470,19 @@ constexpr size_t SMALL_BYTES = 16384;     // sums up to here go to the small com
 // `big_only`: an asynchronous sum that must not touch the small communicator whatever its size (two-stream backward pass: the
 // small communicator is then driven from the compute stream alone, so every asynchronous sum goes to the big one's stream --
 // one communicator is never driven from two streams that no event orders)
-int all_reduce_impl(drs_net* n, void* ptr, size_t count, int dtype, int async, hipStream_t st, int* handle, bool big_only);
+// Timed on the stream the sum RUNS on, around the collective call itself: `st` for the inline and the synchronous forms, the side
+// stream behind its wait for the data for an asynchronous library-side sum.  A sum that goes through the host's callback runs on a
+// stream of the host's that this side cannot bracket: no record then (bench.py reports no allreduce_* row rather than the time of
+// an event hand-over).
 int all_reduce(drs_net* n, int kind, void* ptr, size_t count, int dtype, int async, hipStream_t st, int* handle, bool big_only = false) {
   static const size_t esz[4] = {4, 8, 1, 4};
   if (handle) *handle = -1;
   if (!collectives(n)) return DRS_OK;
-  Timed t(n, st, kind, (double)(count * esz[dtype]));
-  return all_reduce_impl(n, ptr, count, dtype, async, st, handle, big_only);
-}
-
-int all_reduce_impl(drs_net* n, void* ptr, size_t count, int dtype, int async, hipStream_t st, int* handle, bool big_only) {
+  const double bytes = (double)(count * esz[dtype]);
   if (n->rccl_small) {
-    static const size_t esz[4] = {4, 8, 1, 4};
-    if (n->rccl_inline) return drs_rccl_all_reduce_sum(n->rccl_small, ptr, count, dtype, st);
+    if (n->rccl_inline) { Timed t(n, st, kind, bytes); return drs_rccl_all_reduce_sum(n->rccl_small, ptr, count, dtype, st); }
     const bool small = !n->rccl_big || (!(big_only && async) && count * esz[dtype] <= SMALL_BYTES);
-    if (!async) return drs_rccl_all_reduce_sum(small ? n->rccl_small : n->rccl_big, ptr, count, dtype, st);
+    if (!async) { Timed t(n, st, kind, bytes); return drs_rccl_all_reduce_sum(small ? n->rccl_small : n->rccl_big, ptr, count, dtype, st); }
     if (n->comm_in_flight >= n->comm_ring) return DRS_ERR_ARG;      // an event slot still waited for would be recorded again
     ++n->comm_in_flight;
     const int h = n->comm_next;
@@ -492,7 +490,10 @@ int all_reduce_impl(drs_net* n, void* ptr, size_t count, int dtype, int async, h
     hipStream_t side = small ? n->small_stream : n->comm_stream;
     if (hipEventRecord(n->comm_events[2 * h], st) != hipSuccess) return DRS_ERR_HIP;
     if (hipStreamWaitEvent(side, n->comm_events[2 * h], 0) != hipSuccess) return DRS_ERR_HIP;
-    DRS_TRY(drs_rccl_all_reduce_sum(small ? n->rccl_small : n->rccl_big, ptr, count, dtype, side));
+    {
+      Timed t(n, side, kind, bytes);
+      DRS_TRY(drs_rccl_all_reduce_sum(small ? n->rccl_small : n->rccl_big, ptr, count, dtype, side));
+    }
     if (hipEventRecord(n->comm_events[2 * h + 1], side) != hipSuccess) return DRS_ERR_HIP;
     if (handle) *handle = h;
     return DRS_OK;

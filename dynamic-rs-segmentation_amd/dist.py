@@ -82,6 +82,14 @@ class TorchComm(object):
         dist.broadcast_object_list(box, src=src)
         return box[0]
 
+    def gather_objects(self, obj):
+        """every rank's picklable object, in rank order, on every rank (diagnostics: each rank's first-contact timings)"""
+        if self.world == 1:
+            return [obj]
+        box = [None] * self.world
+        dist.all_gather_object(box, obj)
+        return box
+
     def agree(self, values, what="value"):
         """raise on every rank unless all ranks hold the same integers (a cheap guard of the lock-step host logic)"""
         if self.world == 1:

@@ -192,13 +192,38 @@ class EngineNet(DilatedNet):
         # everywhere?" question of _install_comm with a no, and every rank takes the callback path together.  (The thread that is
         # still inside RCCL is a daemon: it goes with the process.)
         limit = float(os.environ.get("DRS_RCCL_INIT_TIMEOUT_S", "90"))
-        for raw in ids:
-            h = C.c_void_p()
-            def create(raw=raw, h=h):
-                torch.cuda.set_device(self.dev)      # (the current device is per thread)
-                _lib.call("drs_rccl_comm_create", self.comm.world, self.comm.rank, (C.c_ubyte * 128).from_buffer_copy(raw), C.byref(h))
-            call_with_timeout(create, limit, "drs_rccl_comm_create (ncclCommInitRank, world %d, rank %d)" % (self.comm.world, self.comm.rank))
-            self._rccl.append(h)
+        import time
+        # first contact with RCCL at this world size, for the record (bench.py: extra.first_contact): seconds inside ncclCommInitRank per
+        # communicator, seconds of the first all-reduce (connection set-up + kernel load happen there)
+        self.first_contact = dict(comm_init_s=[], first_allreduce_s=None)
+        create_err = None
+        abandoned = [False]       # set when this rank gives up: a create() still inside RCCL destroys what it gets, late, instead of leaking it
+        try:
+            for raw in ids:
+                h = C.c_void_p()
+                def create(raw=raw, h=h):
+                    torch.cuda.set_device(self.dev)      # (the current device is per thread)
+                    _lib.call("drs_rccl_comm_create", self.comm.world, self.comm.rank, (C.c_ubyte * 128).from_buffer_copy(raw), C.byref(h))
+                    if abandoned[0] and h.value:
+                        _lib.load().drs_rccl_comm_destroy(h)
+                        h.value = None
+                t0 = time.perf_counter()
+                call_with_timeout(create, limit, "drs_rccl_comm_create (ncclCommInitRank, world %d, rank %d)" % (self.comm.world, self.comm.rank))
+                self.first_contact["comm_init_s"].append(round(time.perf_counter() - t0, 3))
+                self._rccl.append(h)
+        except Exception as e:
+            create_err = e
+            abandoned[0] = True
+        # "did every rank get its communicators?" over the HOST group, before anything is issued on the new ones: a rank whose create
+        # timed out or raised never enters the known-answer sums below, and the others would wait in them without a limit
+        if not self.comm.all_true(create_err is None):
+            for h in self._rccl:
+                try:
+                    _lib.load().drs_rccl_comm_destroy(h)
+                except Exception:
+                    pass
+            self._rccl = []
+            raise create_err or _lib.DrsError("another rank could not create its RCCL communicators")
         # known-answer check of both communicators through the call the step engine issues, in each of its three types
         W, r = self.comm.world, self.comm.rank
         st = torch.cuda.current_stream(self.dev).cuda_stream
@@ -206,8 +231,11 @@ class EngineNet(DilatedNet):
         for h in self._rccl:                   # (every rank issues all six, whatever it finds: the calls are collective)
             for dt, code in ((torch.float32, 0), (torch.float64, 1), (torch.int32, 3)):
                 t = torch.tensor([r + 1, 1, -(r + 1) * 3], dtype=dt, device=self.dev)
+                t0 = time.perf_counter()
                 _lib.call("drs_rccl_all_reduce", h, t.data_ptr(), 3, code, st)
                 got = t.cpu().tolist()
+                if self.first_contact["first_allreduce_s"] is None:
+                    self.first_contact["first_allreduce_s"] = round(time.perf_counter() - t0, 3)
                 if got != [W * (W + 1) // 2, W, -3 * (W * (W + 1) // 2)]:
                     bad.append((str(dt), got))
                 self.ranks_observed = int(got[1])        # the sum of one `1` per rank, as RCCL delivered it

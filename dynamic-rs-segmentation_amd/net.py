@@ -121,11 +121,8 @@ class DilatedNet(object):
         # (the few-band first block stays on the exact-fp32 kernels in every arithmetic: its packed K-steps multiply 8 padded bands where the
         # split kernels would multiply 32 -- 0.13 against 0.34 ms forward, 0.19 against 0.50 ms filter gradient at B = 128)
         self.dev = torch.device(device)
-        if self.dev.type == "cuda" and torch.cuda.is_available():
-            # the library sizes its stream-K workspace and cuts its launches by the CURRENT device's CU count (conv_mfma.hip cu_count):
-            # make this net's device current before the first library call that asks
-            torch.cuda.set_device(self.dev)
-        self.plan = Plan(net_type, channels, num_classes, first_cin_pad=8)
+        if self.dev.type == "cuda" and self.dev.index is None and torch.cuda.is_available():
+            self.dev = torch.device("cuda", torch.cuda.current_device())       # 'cuda' = the process's current device
         self.wd = float(weight_decay)
         self.b_max, self.s_max = int(b_max), int(s_max)
         self.comm = comm if comm is not None else NoComm()
@@ -136,6 +133,12 @@ class DilatedNet(object):
         self.timer = None
         if self.b_max * self.s_max * self.s_max >= (1 << 24):
             raise ValueError("B*S*S must stay below 2^24")
+        # One process drives ONE GPU: the library sizes its stream-K workspace and cuts its launches by the CURRENT device's CU
+        # count (conv_mfma.hip cu_count) and every launch of a step goes to a stream of this net's device, so that device is made -- and
+        # stays -- the process's current one.  (An index-less 'cuda' was resolved above: set_device refuses it)
+        if self.dev.type == "cuda" and torch.cuda.is_available():
+            torch.cuda.set_device(self.dev.index)
+        self.plan = Plan(net_type, channels, num_classes, first_cin_pad=8)
         self._alloc_params()
         self._init_params(seed)
         self._alloc()

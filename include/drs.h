@@ -36,8 +36,9 @@ extern "C" {
 
 /* ---- tf.nn.atrous_conv2d / tf.nn.conv2d (SAME, stride 1) + tf.nn.bias_add  (isprs:710-713) -------------
  * out[p, coff_out + o] (=|+=) sum_{u,v,c} in[p + (u,v)*rate - pad_before, c] * w[u][v][c][o] + bias[o]
- * `in` is a haloed view with P >= max(pad_before, pad_after); cin, cout multiples of 32 (conv1's 3..5 bands
- * are zero-padded to 32 by drs_crop_normalize / drs_filter_pad_cin).  `out` is [B*S*S][ld_out].
+ * `in` is a haloed view with P >= max(pad_before, pad_after); cout a multiple of 32; cin a multiple of 32, or 8 / 16 for
+ * conv1 (its 3..5 bands zero-padded by drs_crop_normalize, the filter by drs_filter_pad_cin -- see there for its size).
+ * `out` is [B*S*S][ld_out].
  * stats_partial (or NULL; not together with accumulate): [ceil(B*S*S / drs_conv_mtile(cout))][cout][2], per M tile and
  * output channel (s, M2) = (sum of the tile's outputs, sum of their squared deviations from the TILE's mean): the first half
  * of train-mode batch norm (isprs:658-660), two-pass inside the tile as TensorFlow is two-pass over the batch;
@@ -74,7 +75,9 @@ int drs_conv_wgrad(const float* x, int B, int S, int Px, int ld_x, int coff_x, c
 
 /* wt[k-1-u][k-1-v][o][c] = w[u][v][c][o]: the filter of the input-gradient pass */
 int drs_filter_flip_transpose(const float* w, float* wt, int k, int cin, int cout, void* stream);
-/* wp[u][v][c < cin_pad][o] = c < cin ? w[u][v][c][o] : 0 */
+/* wp[u][v][c < cin_pad][o] = c < cin ? w[u][v][c][o] : 0.  For cin_pad = 8 / 16 (conv1's 3..5 bands in an 8-channel slab: the
+ * packed-tap form of drs_conv_forward, 32 / cin_pad taps to a K-step of 32 rows) the caller's `wp` holds
+ * round_up(k*k*cin_pad, 32) * cout floats and the rows past the last tap must be ZERO (this call writes the first k*k*cin_pad rows). */
 int drs_filter_pad_cin(const float* w, float* wp, int k, int cin, int cin_pad, int cout, void* stream);
 
 /* ---- the same convolution in split-bf16 arithmetic (csrc/conv_split.hip) ---------------------------------------

@@ -143,3 +143,52 @@ def test_no_child_outlives_a_parent_that_is_killed_during_a_hang(tmp_path, sig):
                 pass
         if p.poll() is None:
             p.kill()
+
+
+@pytest.mark.parametrize("shape", ["launcher", "plain"])
+def test_a_teardown_during_the_second_pass_still_delivers_the_first_line(tmp_path, shape):
+    """the finished default measurement used to be written only after the optional second pass returned; a driver
+    time-out or the launcher's teardown during that pass lost it.  Now the supervisor holds the line and its signal handler writes it."""
+    import signal
+    import time
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "DRS_BENCH_CHILD", "DRS_COMM", "DRS_RCCL_ASYNC"):
+        e.pop(k, None)
+    e.update(DRS_BENCH_SELFTEST="1", DRS_BENCH_FAKE_HANG="buckets", DRS_BENCH_SECOND_PASS_LIMIT_S="600", DRS_BENCH_SECOND_PASS_WALL_S="600")
+    port = 24000 + os.getpid() % 5000
+    cmd = [sys.executable, BENCH, "--gpus", "2"]
+    if shape == "launcher":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+               str(port)] + cmd[1:]
+    outf, errf = open(str(tmp_path / "out.txt"), "wb"), open(str(tmp_path / "err.txt"), "wb")
+    p = subprocess.Popen(cmd, cwd=str(tmp_path), env=e, stdout=outf, stderr=errf)
+    try:
+        t_end = time.time() + 240
+        while time.time() < t_end:                         # first pass done (2 x warm-up done), second pass up and hanging (4 x process group up)
+            err = open(str(tmp_path / "err.txt"), "rb").read()
+            if err.count(b"stage=process group up") >= 4:
+                break
+            assert p.poll() is None, err.decode()
+            time.sleep(0.5)
+        else:
+            raise AssertionError("the second pass never reached its hang: " + open(str(tmp_path / "err.txt")).read())
+        assert not open(str(tmp_path / "out.txt"), "rb").read().strip()      # nothing is out yet: the line is waiting for the second pass
+        p.send_signal(signal.SIGTERM)
+        p.wait(timeout=90)
+    finally:
+        if p.poll() is None:
+            p.kill()
+    lines = [ln for ln in open(str(tmp_path / "out.txt")).read().splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, (lines, open(str(tmp_path / "err.txt")).read()[-2000:])
+    d = json.loads(lines[0])
+    assert d["value"] == 1.0 and d["n_gpus"] == 2 and "second_pass" not in (d.get("extra") or {})
+
+
+def test_the_second_pass_has_an_overall_wall_clock_cap(tmp_path):
+    """markers keep coming but the pass never ends (here: the cap is shorter than the pass): cut by wall time, first line intact"""
+    rc, lines, err = _run([sys.executable, BENCH, "--gpus", "2"], tmp_path, DRS_BENCH_SECOND_PASS_WALL_S="0.5")
+    assert rc == 0, err
+    d = json.loads(lines[-1])
+    assert len(lines) == 1 and d["value"] == 1.0
+    sp = d["extra"]["second_pass"]
+    assert "timeout" in sp.get("error", "") or sp.get("value") == 1.0       # (a pass quicker than the cap's one-second poll is allowed to finish)

@@ -93,7 +93,8 @@ def _conv_case(k, rate, cin, cout, B, S, arith="f32", ld=None):
     if first:
         if ns:
             pytest.skip("layer stays on the exact-fp32 kernels in every arithmetic")
-        wk = torch.empty(k, k, cin, cout, device=DEV)
+        # (the packed-tap kernel walks K-steps of 32 rows: the padded filter is [round_up(k*k*8, 32)][cout], the rows past the last tap zero)
+        wk = torch.zeros(-(-k * k * cin // 32) * 32 * cout, device=DEV)
         prod.call("drs_filter_pad_cin", w.data_ptr(), wk.data_ptr(), k, cin_real, cin, cout, st)
     if ns:
         if cout % 64 or cin % 32:
