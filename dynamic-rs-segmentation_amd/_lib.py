@@ -108,7 +108,7 @@ DEV_SIGNATURES = {
     "drs_debug_conv_splitk": (_i, [_i]), "drs_debug_conv_hybrid": (_i, [_i]), "drs_debug_conv_sk_order": (_i, [_i]), "drs_debug_conv_prio": (_i, [_i]),
     "drs_debug_conv_sk_geometry": (_i, [_i, _i, _i, _p]), "drs_debug_conv_trace": (_i, [_p]), "drs_debug_conv_lpt": (_i, [_i]), "drs_debug_conv_order": (_i, [_i] * 7 + [_p, _i]),
     "drs_debug_wgrad_variant": (_i, [_i]), "drs_debug_wgrad_seg": (_i, [_i]), "drs_debug_wgrad_balance": (_i, [_i]), "drs_debug_wgrad_target": (_i, [_i]),
-    "drs_debug_wgrad_target_big": (_i, [_i]), "drs_debug_wgrad_len": (_i, [_i]), "drs_debug_wgrad_minchunks": (_i, [_i]), "drs_debug_wgrad_model": (_i, [_i]), "drs_debug_wgrad_ablate": (_i, [_i]), "drs_debug_wgrad_prio": (_i, [_i]), "drs_debug_cls_variant": (_i, [_i]), "drs_debug_slide_blocks": (_i, [_i]), "drs_debug_slide_minrows": (_i, [_i]), "drs_debug_slide_rowpad": (_i, [_i]), "drs_debug_chain_mode": (_i, [_i]), "drs_debug_jitter": (_i, [C.c_ulonglong]), "drs_debug_wg_stream_prio": (_i, [_i]), "drs_debug_reductions_on_chain": (_i, [_i]), "drs_debug_variant": (_i, [_i]),
+    "drs_debug_wgrad_target_big": (_i, [_i]), "drs_debug_wgrad_len": (_i, [_i]), "drs_debug_wgrad_minchunks": (_i, [_i]), "drs_debug_wgrad_model": (_i, [_i]), "drs_debug_wgrad_ablate": (_i, [_i]), "drs_debug_wgrad_prio": (_i, [_i]), "drs_debug_cls_variant": (_i, [_i]), "drs_debug_slide_blocks": (_i, [_i]), "drs_debug_slide_minrows": (_i, [_i]), "drs_debug_slide_rowpad": (_i, [_i]), "drs_debug_chain_mode": (_i, [_i]), "drs_debug_jitter": (_i, [C.c_ulonglong]), "drs_debug_wg_stream_prio": (_i, [_i]), "drs_debug_reductions_on_chain": (_i, [_i]), "drs_debug_wgrad_schedule": (_i, [_i, _i, _i]), "drs_debug_variant": (_i, [_i]),
     "drs_debug_wgrad_cut": (_i, [_i] * 7 + [_p, _i, _p, _p]),
 }
 

@@ -132,6 +132,7 @@ struct TimeRec { int kind; double work; hipEvent_t e0, e1; };
 // Device pointers of the bound buffers, looked up by name ONCE (resolve(), after the last drs_net_bind) -- a step is ~130 launches
 // of a few microseconds of host time each at the per-rank sizes, so its enqueue path does no string building and no map lookup.
 struct LayerPtrs {
+  float* gzL = nullptr; float* slabL = nullptr;                   // (development library, drs_debug_wgrad_schedule: this layer's own gz / split slab)
   float* z; float* mean_rstd; unsigned char* idx; float* wt;      // raw conv output, (mean, rstd), pool arg-max codes, flipped filter
   const float* w;                                                 // the filter the forward pass multiplies by (conv1: the padded copy)
   float* act_in; float* act_out; float* gact_in; float* gact_out; // slabs this block reads / writes and their gradients
@@ -192,6 +193,11 @@ struct drs_net {
   std::vector<long long> halo_ok;
   bool timing;
   Ptrs ptrs;
+#ifdef DRS_DEV
+  bool layer_slabs = false;                 // the net lists a gz slab and a split slab per layer (drs_debug_wgrad_schedule before drs_net_create)
+  hipStream_t wg_streams[4] = {nullptr, nullptr, nullptr, nullptr};      // [0] = wg_stream
+  hipEvent_t ev_gzL[16] = {}, ev_wgS[4] = {}, ev_chain_end = nullptr;
+#endif
   std::vector<TimeRec> recs;
   std::vector<hipEvent_t> pool_events;
 
@@ -329,6 +335,10 @@ void build_plan(drs_net* n) {
   n->n_bn = off;
 }
 
+#ifdef DRS_DEV
+int g_wg_layer_slabs = 0;      // drs_debug_wgrad_schedule (see train_step_impl)
+#endif
+
 // every device buffer a step touches, sized once for (b_max, s_max); the caller allocates and binds them
 void list_buffers(drs_net* n) {
   const size_t B = n->b_max, S = n->s_max, M = B * S * S;
@@ -370,6 +380,15 @@ void list_buffers(drs_net* n) {
   n->add_buf("gz", B * (S + 2 * hmax) * (S + 2 * hmax) * cmax, F32);
   n->add_buf("gz2", B * (S + 2 * hmax) * (S + 2 * hmax) * cmax, F32);       // the second haloed output-gradient slab of the two-stream backward pass
   n->add_buf("slab", slab, F32);
+#ifdef DRS_DEV
+  n->layer_slabs = g_wg_layer_slabs != 0 && n->layers.size() <= 16;
+  if (n->layer_slabs)
+    for (size_t i = 0; i < n->layers.size(); ++i) {
+      const Layer& L = n->layers[i];
+      n->add_buf("gzL" + std::to_string(i), B * (S + 2 * L.halo) * (S + 2 * L.halo) * L.cout, F32);
+      n->add_buf("slabL" + std::to_string(i), (size_t)drs_conv_wgrad_splits(n->b_max, n->s_max, L.k, L.cin_k, L.cout) * L.k * L.k * L.cin_k * L.cout, F32);
+    }
+#endif
   const Layer& L0 = n->layers[0];
   n->add_buf("w0pad", (size_t)round_up(L0.k * L0.k * L0.cin_k, 32) * L0.cout, F32);
   bool any_avg = false;
@@ -438,6 +457,12 @@ __global__ void jitter_kernel(long long ticks) {
 }
 unsigned long long g_jitter_state = 0;      // 0 = off
 int g_wg_stream_prio = 2;                   // drs_debug_wg_stream_prio: the filter-gradient stream's priority arm (2 = the product's: highest)
+// r06 experiment (drs_debug_wgrad_schedule): the filter gradients of a two-stream step with a gz slab and a split
+// slab PER LAYER (set before drs_net_create: the net then lists "gzL<i>" / "slabL<i>"), so that the chain never waits for a filter
+// gradient to release a slab, on `streams` filter-gradient streams (layer i on stream i % streams: their launches overlap each other's
+// fill and drain -- what ONE grouped launch over the layers would do), issued as the chain goes (defer 0), or all after the chain's
+// last launch, each waiting only for its own gz (defer 2) or for the END of the chain (defer 1: the chain runs uncontended).
+int g_wg_streams = 1, g_wg_defer = 0;       // (g_wg_layer_slabs is declared above list_buffers, which reads it)
 int g_reductions_on_chain = 0;              // drs_debug_reductions_on_chain: the classifier's slab reductions stay on the compute stream
 inline void jitter(hipStream_t s) {
   if (!g_jitter_state) return;
@@ -550,6 +575,9 @@ bool resolve(drs_net* n) {
     q.gact_in = L.src != 0 ? n->p<float>("gact:" + n->slabs[L.src].name) : nullptr;
     q.gact_out = n->p<float>("gact:" + n->slabs[L.dst].name);
     q.se_act = q.se_s = q.se_e1 = q.se_e2 = nullptr;
+#ifdef DRS_DEV
+    if (n->layer_slabs) { q.gzL = n->p<float>("gzL" + id); q.slabL = n->p<float>("slabL" + id); }
+#endif
     if (L.se >= 0) {
       const std::string sid = std::to_string(L.se);
       q.se_act = n->p<float>("se_act" + sid); q.se_s = n->p<float>("se_s" + sid); q.se_e1 = n->p<float>("se_e1" + sid); q.se_e2 = n->p<float>("se_e2" + sid);
@@ -641,6 +669,12 @@ extern "C" {
 int drs_debug_jitter(unsigned long long seed) { g_jitter_state = seed; return 0; }
 int drs_debug_wg_stream_prio(int arm) { const int old = g_wg_stream_prio; if (arm >= 0) g_wg_stream_prio = arm; return old; }
 int drs_debug_reductions_on_chain(int on) { const int old = g_reductions_on_chain; if (on >= 0) g_reductions_on_chain = on; return old; }
+int drs_debug_wgrad_schedule(int layer_slabs, int streams, int defer) {
+  if (layer_slabs >= 0) g_wg_layer_slabs = layer_slabs;      // read by drs_net_create: nets made afterwards list the per-layer slabs
+  if (streams >= 1) g_wg_streams = streams;                  // read per step
+  if (defer >= 0) g_wg_defer = defer;                        // read per step
+  return 0;
+}
 #endif
 
 int drs_net_create(const char* net_type, int channels, int num_classes, float weight_decay, int b_max, int s_max, int bessel_moving_var,
@@ -696,6 +730,12 @@ void drs_net_destroy(drs_net_t* n) {
     if (n->ev_prep) (void)hipEventDestroy(n->ev_prep);
     (void)hipStreamDestroy(n->wg_stream);
   }
+#ifdef DRS_DEV
+  for (int j = 1; j < 4; ++j) if (n->wg_streams[j]) (void)hipStreamDestroy(n->wg_streams[j]);
+  for (auto e : n->ev_wgS) if (e) (void)hipEventDestroy(e);
+  for (auto e : n->ev_gzL) if (e) (void)hipEventDestroy(e);
+  if (n->ev_chain_end) (void)hipEventDestroy(n->ev_chain_end);
+#endif
   for (auto& r : n->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (auto e : n->pool_events) (void)hipEventDestroy(e);
   delete n;
@@ -1057,6 +1097,27 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     if (!ok) return DRS_ERR_HIP;
   }
   hipStream_t ws = two ? n->wg_stream : st;       // the stream the filter gradients run on
+#ifdef DRS_DEV
+  // r06 experiment (see g_wg_streams): per-layer gz / split slabs, 1..4 filter-gradient streams, eager or deferred issue
+  const bool xs = two && n->layer_slabs && !collectives(n);
+  const int NS = xs ? std::min(4, std::max(1, g_wg_streams)) : 1;
+  const int defer = xs ? g_wg_defer : 0;
+  if (xs) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+    n->wg_streams[0] = n->wg_stream;
+    for (int j = 1; j < NS; ++j)
+      if (!n->wg_streams[j] && stream_at_priority(&n->wg_streams[j], greatest) != hipSuccess) return DRS_ERR_HIP;
+    for (int j = 0; j < 4; ++j)
+      if (!n->ev_wgS[j] && hipEventCreateWithFlags(&n->ev_wgS[j], hipEventDisableTiming) != hipSuccess) return DRS_ERR_HIP;
+    for (int j = 0; j < 16; ++j)
+      if (!n->ev_gzL[j] && hipEventCreateWithFlags(&n->ev_gzL[j], hipEventDisableTiming) != hipSuccess) return DRS_ERR_HIP;
+    if (!n->ev_chain_end && hipEventCreateWithFlags(&n->ev_chain_end, hipEventDisableTiming) != hipSuccess) return DRS_ERR_HIP;
+  }
+#else
+  constexpr bool xs = false;
+  constexpr int defer = 0;
+#endif
   float* params = P.params;
   float* grads = P.grads;
   const int nL = (int)n->layers.size();
@@ -1167,6 +1228,16 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     const Layer& L = n->layers[i];
     const Slab& in = n->slabs[L.src];
     ChainHint not_chain(0);
+#ifdef DRS_DEV
+    if (xs) {      // this layer's own slabs, stream i % NS, behind this layer's gz (or the chain's end)
+      hipStream_t wsi = n->wg_streams[i % NS];
+      if (hipStreamWaitEvent(wsi, defer == 1 ? n->ev_chain_end : n->ev_gzL[i], 0) != hipSuccess) return DRS_ERR_HIP;
+      DRS_TRY(drs_conv_wgrad(P.L[i].act_in, B, S, in.P, in.C, 0, P.L[i].gzL, L.halo, L.cout, 0, L.k, L.rate, L.pad_b, L.cin_k, L.cin, L.cout,
+                             P.L[i].slabL, grads + L.w_off, wsi));
+      if (hipEventRecord(n->ev_wgS[i % NS], wsi) != hipSuccess) return DRS_ERR_HIP;
+      return DRS_OK;
+    }
+#endif
     if (two && hipStreamWaitEvent(ws, n->ev_gz[i & 1], 0) != hipSuccess) return DRS_ERR_HIP;      // block i's gz is written
     if (two) DRS_JITTER(ws);
     {
@@ -1231,17 +1302,23 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     // on the critical path, and the small communicator is then driven from this stream only, forward and backward)
     int h_bn;
     DRS_TRY(all_reduce(n, K_AR_SYNCBN, sums, 2 * (size_t)L.cout, F64, two ? 0 : 1, st, &h_bn));
-    if (deferred >= 0) DRS_TRY(filter_gradient(deferred));
+    if (deferred >= 0 && !defer) DRS_TRY(filter_gradient(deferred));
     DRS_TRY(wait_handles(n, {h_bn}, st));
     float* gz = gzb[two ? (i & 1) : 0];
-    if (two && i + 2 < nL && hipStreamWaitEvent(st, n->ev_wg[i & 1], 0) != hipSuccess) return DRS_ERR_HIP;   // block i+2's filter gradient has read this slab
+#ifdef DRS_DEV
+    if (xs) gz = q.gzL;
+#endif
+    if (two && !xs && i + 2 < nL && hipStreamWaitEvent(st, n->ev_wg[i & 1], 0) != hipSuccess) return DRS_ERR_HIP;   // block i+2's filter gradient has read this slab
     if (two) DRS_JITTER(st);
     {
       Timed t(n, st, K_BN_BWD_APPLY, M * L.cout * 12.0);
       if (means_form) DRS_TRY(drs_bn_backward_apply_means(gxh, z, B, S, L.cout, mr, bwd_means, gz, L.halo, L.cout, 0, st));
       else DRS_TRY(drs_bn_backward_apply(gxh, z, B, S, L.cout, mr, sums, n_bn, gz, L.halo, L.cout, 0, st));
     }
-    if (two && hipEventRecord(n->ev_gz[i & 1], st) != hipSuccess) return DRS_ERR_HIP;
+#ifdef DRS_DEV
+    if (xs && hipEventRecord(n->ev_gzL[i], st) != hipSuccess) return DRS_ERR_HIP;
+#endif
+    if (two && !xs && hipEventRecord(n->ev_gz[i & 1], st) != hipSuccess) return DRS_ERR_HIP;
     if (two) DRS_JITTER(st);
     if (L.src != 0) {
       const Slab& in = n->slabs[L.src];
@@ -1253,10 +1330,25 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     }
     deferred = i;
   }
+#ifdef DRS_DEV
+  if (xs) {
+    if (defer) {
+      if (hipEventRecord(n->ev_chain_end, st) != hipSuccess) return DRS_ERR_HIP;
+      for (int i = nL - 1; i >= 0; --i) DRS_TRY(filter_gradient(i));
+    } else {
+      DRS_TRY(filter_gradient(deferred));
+    }
+    // the side jobs went to wg_stream = wg_streams[0]: its last event covers them when a filter gradient followed; join every stream used
+    for (int j = 0; j < std::min(NS, nL); ++j)
+      if (hipStreamWaitEvent(st, n->ev_wgS[j], 0) != hipSuccess) return DRS_ERR_HIP;
+  } else
+#endif
+  {
   DRS_TRY(filter_gradient(deferred));
   if (two) {      // every filter gradient is in place before the rest of the step reads the gradient buffer
     if (hipStreamWaitEvent(st, n->ev_wg[0], 0) != hipSuccess) return DRS_ERR_HIP;
     if (nL > 1 && hipStreamWaitEvent(st, n->ev_wg[1], 0) != hipSuccess) return DRS_ERR_HIP;
+  }
   }
   if (inline_comm) {      // one all-reduce of the whole flat gradient buffer, then the loss and the confusion matrix, in program order
     if (buckets) {

@@ -95,6 +95,28 @@ class NoComm(object):
         pass
 
 
+def initial_params(plan, seed):
+    """the flat fp32 parameter buffer at step 0 (host code): Xavier-uniform kernels (isprs:702), _fc_layer kernels truncated normal
+    stddev 0.005 (isprs:669), biases 0.1 (isprs:707), classifier bias 0 (isprs:1028)"""
+    rng = np.random.default_rng(seed)
+    host = np.zeros(plan.n_params, dtype=np.float32)
+    for name, (off, shape) in plan.offsets.items():
+        n = int(np.prod(shape))
+        if name.endswith("/weights") and len(shape) == 2:
+            v = rng.normal(0.0, 0.005, size=n)
+            while np.any(np.abs(v) > 0.01):
+                bad = np.abs(v) > 0.01
+                v[bad] = rng.normal(0.0, 0.005, size=int(bad.sum()))
+            host[off:off + n] = v.astype(np.float32)
+        elif name.endswith("/weights"):
+            k1, k2, ci, co = shape
+            lim = math.sqrt(6.0 / (k1 * k2 * ci + k1 * k2 * co))
+            host[off:off + n] = rng.uniform(-lim, lim, size=n).astype(np.float32)
+        elif name != "conv_classifier/biases":
+            host[off:off + n] = 0.1
+    return host
+
+
 class DilatedNet(object):
     def __new__(cls, *args, **kw):
         """`DilatedNet(...)` is the step-level net (engine.EngineNet: one library call per sess.run, csrc/engine.hip) for the
@@ -147,23 +169,7 @@ class DilatedNet(object):
     def _init_params(self, seed):
         """Xavier-uniform kernels (isprs:702), biases 0.1 (isprs:707), classifier bias 0 (isprs:1028),
         moving mean 0 / variance 1 (contrib batch_norm initialisers)."""
-        rng = np.random.default_rng(seed)
-        host = np.zeros(self.plan.n_params, dtype=np.float32)
-        for name, (off, shape) in self.plan.offsets.items():
-            n = int(np.prod(shape))
-            if name.endswith("/weights") and len(shape) == 2:         # _fc_layer: truncated normal, stddev 0.005 (isprs:669)
-                v = rng.normal(0.0, 0.005, size=n)
-                while np.any(np.abs(v) > 0.01):
-                    bad = np.abs(v) > 0.01
-                    v[bad] = rng.normal(0.0, 0.005, size=int(bad.sum()))
-                host[off:off + n] = v.astype(np.float32)
-            elif name.endswith("/weights"):
-                k1, k2, ci, co = shape
-                lim = math.sqrt(6.0 / (k1 * k2 * ci + k1 * k2 * co))
-                host[off:off + n] = rng.uniform(-lim, lim, size=n).astype(np.float32)
-            elif name != "conv_classifier/biases":
-                host[off:off + n] = 0.1
-        self.params.copy_(torch.from_numpy(host))
+        self.params.copy_(torch.from_numpy(initial_params(self.plan, seed)))
         bn = np.zeros(self.plan.n_bn, dtype=np.float32)
         for L in self.plan.layers:
             o = self.plan.bn_offsets[L.name]

@@ -53,6 +53,14 @@ def main(B=16, S=64, steps=20, arith="f32", comm_kind="none"):
 
 if __name__ == "__main__":
     kw = dict(a.split("=") for a in sys.argv[1:])
+    if "sched" in kw:          # r06 experiment: the filter gradients' schedule (tools/ab_wgrad_schedule.py: p | L<streams><e|d|o>), the whole net on the dev library
+        import re
+        from drs_amd import _lib
+        d = _lib.dev()
+        _lib._lib = d.lib
+        m = re.fullmatch(r"L(\d)([edo])", kw["sched"])
+        if m:
+            d.drs_debug_wgrad_schedule(1, int(m.group(1)), {"e": 0, "d": 1, "o": 2}[m.group(2)])
     if "slide" in kw or "minrows" in kw:        # A/B of the sliding elementwise kernels' launch geometry inside the step: the whole net on the dev library
         from drs_amd import _lib
         d = _lib.dev()

@@ -4,7 +4,7 @@
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-opt-in --no-size-table"
+BENCH="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-opt-in --no-size-table --no-configs"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $BENCH > $O/stats.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $BENCH > $O/pmc_fetch.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $BENCH > $O/pmc_write.log 2>&1 || exit 1
