@@ -9,11 +9,6 @@ python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?"
 DRS_FORCE_COLLECTIVES=1 python bench.py --steps 40 --no-cpu-baseline --no-opt-in --no-size-table > $O/bench_forced_rccl_world1.json 2> $O/bench_forced.err; echo "forced rc=$?"
 bash tools/profile_round.sh $1 > $O/profile_round.log 2>&1; echo "profile rc=$?"
 cd $R
-python tools/bench_configs.py > $O/configs_3_5.log 2>&1; echo "configs rc=$?"
-{ for B in 128 64 32 16 8; do echo "== tools/ab_lpt.py B=$B (old: natural order, skipping from 4096 workgroups; new: full tiles first, skipping wherever the order applies; all: every tap multiplied)"; python tools/ab_lpt.py B=$B rounds=4 2>&1 | grep -v amdgpu; done; } > $O/launch_order_ab.txt 2>&1
-{ echo "== tools/conv_tail.py lpt=0 (natural order)"; python tools/conv_tail.py layers=2,3,4,5,6,7,8 lpt=0 2>&1 | grep -v amdgpu; echo "== tools/conv_tail.py lpt=1 (full tiles first)"; python tools/conv_tail.py layers=2,3,4,5,6,7,8 lpt=1 2>&1 | grep -v amdgpu;
-  echo "== tools/conv_tail.py which=wgrad"; python tools/conv_tail.py which=wgrad layers=2,3,4,5,6,7,8 2>&1 | grep -v amdgpu; } > $O/conv_tail.txt 2>&1
-{ echo "== tools/ab_wgrad.py arms=a3,a0 (a3 = no wave priority by remaining work, a0 = default)"; python tools/ab_wgrad.py arms=a3,a0 rounds=5 2>&1 | grep -v amdgpu;
-  echo "== tools/wgrad_spread.py layers=3,8 (default: priorities on)"; python tools/wgrad_spread.py layers=3,8 2>&1 | grep -v amdgpu;
-  echo "== tools/ab_wgrad.py arms=l96,l128,l160,l192"; python tools/ab_wgrad.py arms=l96,l128,l160,l192 rounds=4 layers=2,3,4,5,6,7,8 2>&1 | grep -v amdgpu; } > $O/wgrad_priority_ab.txt 2>&1
+# (round 6: BASELINE configs 2-5 are in the bench line itself -- extra.configs; the launch-order / tail / priority A/Bs of rounds 4-5 live in
+#  profiles/r04, profiles/r05 and are not repeated)
 echo final pass done
