@@ -1302,7 +1302,7 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     // on the critical path, and the small communicator is then driven from this stream only, forward and backward)
     int h_bn;
     DRS_TRY(all_reduce(n, K_AR_SYNCBN, sums, 2 * (size_t)L.cout, F64, two ? 0 : 1, st, &h_bn));
-    if (deferred >= 0 && !defer) DRS_TRY(filter_gradient(deferred));
+    if (deferred >= 0 && (defer == 0 || defer == 3)) DRS_TRY(filter_gradient(deferred));
     DRS_TRY(wait_handles(n, {h_bn}, st));
     float* gz = gzb[two ? (i & 1) : 0];
 #ifdef DRS_DEV
@@ -1316,7 +1316,7 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
       else DRS_TRY(drs_bn_backward_apply(gxh, z, B, S, L.cout, mr, sums, n_bn, gz, L.halo, L.cout, 0, st));
     }
 #ifdef DRS_DEV
-    if (xs && hipEventRecord(n->ev_gzL[i], st) != hipSuccess) return DRS_ERR_HIP;
+    if (xs && defer != 3 && hipEventRecord(n->ev_gzL[i], st) != hipSuccess) return DRS_ERR_HIP;
 #endif
     if (two && !xs && hipEventRecord(n->ev_gz[i & 1], st) != hipSuccess) return DRS_ERR_HIP;
     if (two) DRS_JITTER(st);
@@ -1328,11 +1328,16 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
       DRS_TRY(drs_conv_forward_ws(gz, B, S, L.halo, L.cout, 0, q.wt, nullptr, L.k, L.rate, L.pad_a, L.cout, L.cin,
                                   q.gact_in, in.C, 0, acc, nullptr, P.conv_ws, P.conv_ws_floats, st));
     }
+#ifdef DRS_DEV
+    // defer 3: block i's filter gradient is released by the END of block i's input gradient (not by its gz): it then runs beside block
+    // i-1's elementwise passes and input gradient instead of beside its own block's input gradient
+    if (xs && defer == 3 && hipEventRecord(n->ev_gzL[i], st) != hipSuccess) return DRS_ERR_HIP;
+#endif
     deferred = i;
   }
 #ifdef DRS_DEV
   if (xs) {
-    if (defer) {
+    if (defer == 1 || defer == 2) {
       if (hipEventRecord(n->ev_chain_end, st) != hipSuccess) return DRS_ERR_HIP;
       for (int i = nL - 1; i >= 0; --i) DRS_TRY(filter_gradient(i));
     } else {

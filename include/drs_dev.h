@@ -39,7 +39,7 @@ int drs_debug_slide_minrows(int v);      /* ... and the fewest rows of a strip i
 int drs_debug_jitter(unsigned long long seed);   /* schedule fuzzing of the two-stream training step: != 0 = sleeps of 0 .. 150 us (a generator seeded with it) on the step's streams where they hand work to each other; 0 = off */
 int drs_debug_wg_stream_prio(int arm);   /* stream priority of the filter-gradient stream a net makes at its first two-stream step: 2 highest (default = the product), 0 the caller's level (as before round 5), 1 lowest and the collectives' side streams highest; < 0 reads */
 int drs_debug_reductions_on_chain(int on);   /* 1: the classifier's slab reductions, the L2 term and the step's preparation launch stay on the compute stream (as before round 5); 0 (default = the product): on the filter-gradient stream */
-int drs_debug_wgrad_schedule(int layer_slabs, int streams, int defer);   /* r06 experiment on the two-stream training step (no collectives): layer_slabs 1 (BEFORE drs_net_create: the net lists "gzL<i>" / "slabL<i>") = a gz slab and a split slab per layer, so the chain never waits for a filter gradient; streams 1..4 = layer i's filter gradient on stream i % streams; defer 0 = issued as the chain goes, 1 = all after the chain's last launch and behind it, 2 = issued after the chain's last launch, each behind its own gz only; a negative argument leaves that setting */
+int drs_debug_wgrad_schedule(int layer_slabs, int streams, int defer);   /* r06 experiment on the two-stream training step (no collectives): layer_slabs 1 (BEFORE drs_net_create: the net lists "gzL<i>" / "slabL<i>") = a gz slab and a split slab per layer, so the chain never waits for a filter gradient; streams 1..4 = layer i's filter gradient on stream i % streams; defer 0 = issued as the chain goes, 1 = all after the chain's last launch and behind it, 2 = issued after the chain's last launch, each behind its own gz only, 3 = issued as the chain goes but released by the end of its own block's input gradient (it then runs beside the NEXT block's elementwise passes); a negative argument leaves that setting */
 int drs_debug_chain_mode(int v);         /* two-stream backward pass, the launches of the chain the step waits for at the top wave priority: -1 as the engine asks (default: 1 without collectives, 2 with), 0 none, 1 the input-gradient launches (+ stream-K fix-up), 2 + the batch-norm backward launches */
 int drs_debug_slide_rowpad(int v);       /* TIMING EXPERIMENT (the callers must size z / idx / ga / gxh for it): phantom pixels after every stored image row in the two sliding elementwise kernels */
 int drs_debug_cls_variant(int v);        /* classifier block: 1 MFMA from 4 classes up, LDS-DMA form up to C = 256 (default), 2 register MFMA form always, 3 LDS-DMA form where it fits, 0 vector-ALU always */

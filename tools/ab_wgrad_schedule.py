@@ -9,6 +9,9 @@ In-process A/B of one rank's training step (development library, no collectives)
              the chain goes
     L<n>d    the same, but every filter gradient waits for the END of the chain (the chain runs uncontended, then the "group")
     L<n>o    issued after the chain's last launch, each behind its own gz only (host order of the deferred form, dependencies of the eager one)
+    L<n>a    issued as the chain goes, but block i's filter gradient is released by the END of block i's input gradient: it runs beside block
+             i-1's elementwise passes (which leave the matrix pipe idle) and input gradient.  With two=1 the L-arms force the two-stream pass
+             at any batch (at B = 128 the product runs ONE stream: `p` is then that)
 Every arm runs the same kernels on the same operands: the gradients after a step are compared bit for bit with the product's.
 
     python tools/ab_wgrad_schedule.py [B=16] [S=25,35,45,55,64,65,75,85] [arms=p,L1e,L2e,L4e,L1d,L2d,L4d,L4o] [steps=20] [rounds=4]
@@ -33,19 +36,21 @@ from drs_amd.synthetic import make_tile, grid_instances  # noqa: E402
 def parse(arm):
     if arm == "p":
         return 0, 1, 0
-    m = re.fullmatch(r"L(\d)([edo])", arm)
-    return 1, int(m.group(1)), {"e": 0, "d": 1, "o": 2}[m.group(2)]
+    m = re.fullmatch(r"L(\d)([edoa])", arm)
+    return 1, int(m.group(1)), {"e": 0, "d": 1, "o": 2, "a": 3}[m.group(2)]
 
 
-def main(B=16, Ss=(64,), arms=("p", "L1e"), steps=20, rounds=4):
+def main(B=16, Ss=(64,), arms=("p", "L1e"), steps=20, rounds=4, two=None):
     dev = "cuda:0"
-    tile, lab = make_tile(1024, 1024, 5, 6, seed=1234)
+    tile, lab = make_tile(1024, 1024, 5, 6, seed=1234)      # (instances wrap around: 4096 of them serve any batch)
     pool = P.TilePool([tile], [lab], dev)
     smax = max(Ss)
     nets = {}
     for slabs in sorted({parse(a)[0] for a in arms}):
         d.drs_debug_wgrad_schedule(slabs, -1, -1)
         nets[slabs] = DilatedNet("dilated_grsl_rate8", 5, 6, 0.005, b_max=B, s_max=smax, device=dev, seed=42)
+        if slabs and two is not None:
+            nets[slabs].set_two_streams(two)
     d.drs_debug_wgrad_schedule(0, -1, -1)
     weighted = {a: 0.0 for a in arms}
     for S in Ss:
@@ -99,4 +104,4 @@ def main(B=16, Ss=(64,), arms=("p", "L1e"), steps=20, rounds=4):
 if __name__ == "__main__":
     kw = dict(a.split("=") for a in sys.argv[1:])
     main(int(kw.get("B", 16)), tuple(int(v) for v in kw.get("S", "64").split(",")), tuple(kw.get("arms", "p,L1e,L2e,L4e,L1d,L2d,L4d,L4o").split(",")),
-         int(kw.get("steps", 20)), int(kw.get("rounds", 4)))
+         int(kw.get("steps", 20)), int(kw.get("rounds", 4)), int(kw["two"]) if "two" in kw else None)

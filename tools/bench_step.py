@@ -11,7 +11,7 @@ from drs_amd.net import DilatedNet, KernelTimer
 from drs_amd import patches as P
 from drs_amd.synthetic import make_tile, grid_instances
 
-def main(B=16, S=64, steps=20, arith="f32", comm_kind="none"):
+def main(B=16, S=64, steps=20, arith="f32", comm_kind="none", two=None):
     dev = "cuda:0"
     comm = None
     if comm_kind != "none":
@@ -29,6 +29,8 @@ def main(B=16, S=64, steps=20, arith="f32", comm_kind="none"):
     pool = P.TilePool([tile], [lab], dev)
     inst = grid_instances(1024, 1024, S, 25, 4096, seed=0)
     net = DilatedNet("dilated_grsl_rate8", 5, 6, 0.005, b_max=B, s_max=S, device=dev, arith=arith, comm=comm)
+    if two is not None:          # two=0|1: the backward pass on one / two streams whatever the library's rule says (drs_net_set_two_streams)
+        net.set_two_streams(two)
     np.random.seed(0)
     def step(i):
         rows = inst[(i * B) % 4000:(i * B) % 4000 + B]
@@ -58,15 +60,16 @@ if __name__ == "__main__":
         from drs_amd import _lib
         d = _lib.dev()
         _lib._lib = d.lib
-        m = re.fullmatch(r"L(\d)([edo])", kw["sched"])
+        m = re.fullmatch(r"L(\d)([edoa])", kw["sched"])
         if m:
-            d.drs_debug_wgrad_schedule(1, int(m.group(1)), {"e": 0, "d": 1, "o": 2}[m.group(2)])
+            d.drs_debug_wgrad_schedule(1, int(m.group(1)), {"e": 0, "d": 1, "o": 2, "a": 3}[m.group(2)])
     if "slide" in kw or "minrows" in kw:        # A/B of the sliding elementwise kernels' launch geometry inside the step: the whole net on the dev library
         from drs_amd import _lib
         d = _lib.dev()
         _lib._lib = d.lib
         if "slide" in kw: d.drs_debug_slide_blocks(int(kw["slide"]))
         if "minrows" in kw: d.drs_debug_slide_minrows(int(kw["minrows"]))
-    main(int(kw.get("B", 16)), int(kw.get("S", 64)), int(kw.get("steps", 20)), kw.get("arith", "f32"), kw.get("comm", "none"))
+    main(int(kw.get("B", 16)), int(kw.get("S", 64)), int(kw.get("steps", 20)), kw.get("arith", "f32"), kw.get("comm", "none"),
+         int(kw["two"]) if "two" in kw else None)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
