@@ -814,6 +814,12 @@ def main():
     rehearsal = os.environ.get("DRS_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+        # a rehearsal of the LIBRARY-side collectives on one GPU needs a stand-in for RCCL (which refuses two ranks on one device):
+        # DRS_BENCH_RCCL_LIB names it (tests/c/nccl_shm_double.cpp built); this script's own variable -- the library reads none, it is
+        # told by a call -- and honoured in a rehearsal only
+        if os.environ.get("DRS_BENCH_RCCL_LIB"):
+            from drs_amd import _lib as _drs_lib
+            _drs_lib.call("drs_rccl_bind_library", os.environ["DRS_BENCH_RCCL_LIB"].encode())
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
 
