@@ -254,7 +254,8 @@ def supervise(argv):
         env.update(DRS_BENCH_CHILD="1", DRS_BENCH_ATTEMPT=label, DRS_BENCH_FALLBACK_REASON=reason)
         # first contact with RCCL at N > 1 must be cheap to diagnose: warnings of every attempt go to a file per attempt and rank
         # (RCCL itself expands %h / %p); after a failed attempt its tail travels in the next attempt's line and in the failure line
-        env.setdefault("NCCL_DEBUG", "WARN")
+        if env.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":      # (this image exports VERSION: the banner only)
+            env["NCCL_DEBUG"] = "WARN"
         if "NCCL_DEBUG_FILE" not in os.environ:
             env["NCCL_DEBUG_FILE"] = os.path.join(_tmpdir(), "drs_bench_nccl_%d_%s_rank%s.%%h.%%p.log" % (os.getppid(), label, os.environ.get("RANK", "0")))
         if i > 0:
