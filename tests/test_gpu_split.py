@@ -14,7 +14,11 @@ pytestmark = pytest.mark.gpu
 
 from gpu_util import DEV, conv_stats_moments, dev, padded, rel_err, stream   # noqa: E402
 
-TOL = {2: 1e-5, 3: 1e-5}
+# two terms (bf16x3) drop the t1*u1 partial product: 2^-16 = 1.5e-5 of a product.  Over sums of hundreds of products the errors average
+# well below 1e-5 of the tensor's maximum; a sum of a FEW products (a 5 x 5 patch under a rate-6 filter: most taps meet the halo) keeps
+# nearly the per-product bound -- tests/fuzz/fuzz_split.py seed 617, case (2, 6, 128, 256, 2, 5, 2): 1.10e-5 (profiles/r06/fuzz.txt).
+# Three terms (bf16x6) stay under the exact-fp32 kernels' 1e-5.
+TOL = {2: 1.6e-5, 3: 1e-5}
 
 
 @pytest.fixture(scope="module")
