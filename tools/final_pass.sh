@@ -11,4 +11,10 @@ bash tools/profile_round.sh $1 > $O/profile_round.log 2>&1; echo "profile rc=$?"
 cd $R
 # (round 6: BASELINE configs 2-5 are in the bench line itself -- extra.configs; the launch-order / tail / priority A/Bs of rounds 4-5 live in
 #  profiles/r04, profiles/r05 and are not repeated)
+{ echo "# tools/soak.py at the round's final revision: two identical runs compared bit for bit";
+  python tools/soak.py B=16 steps=3000 2>&1 | grep -v amdgpu;
+  python tools/soak.py B=32 steps=800 lo=33 hi=100 net=dilated_icpr_rate6_densely channels=4 classes=2 2>&1 | grep -v amdgpu;
+  python tools/soak.py B=16 steps=600 comm=rccl 2>&1 | grep -v amdgpu;
+  echo "# tools/poison_check.py: the same step with every scratch buffer NaN / 0xFF-filled first";
+  python tools/poison_check.py 2>&1 | grep -v amdgpu; python tools/poison_check.py B=16 S=64 2>&1 | grep -v amdgpu; } > $O/soak_determinism.txt 2>&1; tail -2 $O/soak_determinism.txt
 echo final pass done
