@@ -491,6 +491,7 @@ inline hipError_t stream_at_priority(hipStream_t* s, int prio) {
 inline bool collectives(const drs_net* n) { return n->world > 1 || n->allreduce != nullptr || n->rccl_small != nullptr; }
 
 constexpr size_t SMALL_BYTES = 16384;     // sums up to here go to the small communicator
+constexpr size_t MAX_SLABS = 32;          // activation slabs of a net (the deepest table has 13); checked in drs_net_create
 
 // `big_only`: an asynchronous sum that must not touch the small communicator whatever its size (two-stream backward pass: the
 // small communicator is then driven from the compute stream alone, so every asynchronous sum goes to the big one's stream --
@@ -530,9 +531,10 @@ int all_reduce(drs_net* n, int kind, void* ptr, size_t count, int dtype, int asy
   return DRS_OK;
 }
 
-int wait_handles(drs_net* n, const std::vector<int>& hs, hipStream_t st) {
+int wait_handles(drs_net* n, const int* hs, size_t count, hipStream_t st) {
   if (n->rccl_small) {
-    for (int h : hs) {
+    for (size_t i = 0; i < count; ++i) {
+      const int h = hs[i];
       if (h < 0) continue;
       if (hipStreamWaitEvent(st, n->comm_events[2 * h + 1], 0) != hipSuccess) return DRS_ERR_HIP;
       --n->comm_in_flight;
@@ -540,8 +542,8 @@ int wait_handles(drs_net* n, const std::vector<int>& hs, hipStream_t st) {
     return DRS_OK;
   }
   if (!collectives(n) || !n->wait) return DRS_OK;
-  for (int h : hs)
-    if (h >= 0 && n->wait(n->comm_user, h, st) != 0) return DRS_ERR_HIP;
+  for (size_t i = 0; i < count; ++i)
+    if (hs[i] >= 0 && n->wait(n->comm_user, hs[i], st) != 0) return DRS_ERR_HIP;
   return DRS_OK;
 }
 
@@ -697,6 +699,7 @@ int drs_net_create(const char* net_type, int channels, int num_classes, float we
     n->wg_stream = nullptr;
     n->two_stream_mode = -1;
     build_plan(n);
+    if (n->slabs.size() > MAX_SLABS) { delete n; return DRS_ERR_ARG; }
     list_buffers(n);
     n->halo_ok.assign(n->slabs.size(), -1);
   } catch (...) {
@@ -1184,9 +1187,9 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
   };
   // gradient all-reduce in buckets that overlap the rest of the backward pass: kernel gradients go as their layers finish, last
   // layers first; the small classifier / SE / bias tail goes last
-  std::vector<int> pending;
+  std::vector<int> pending;      // (handles of asynchronous sums: filled only by the callback / asynchronous forms; empty, no allocation, otherwise)
   size_t bucket_hi = n->cls_w;
-  std::vector<char> written(n->slabs.size(), 0);
+  char written[MAX_SLABS] = {0};
   written[n->feat] = 1;
   float* gzb[2] = {P.gz[0], P.gz[1]};
   float* gxh = P.gxh;
@@ -1303,7 +1306,7 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     int h_bn;
     DRS_TRY(all_reduce(n, K_AR_SYNCBN, sums, 2 * (size_t)L.cout, F64, two ? 0 : 1, st, &h_bn));
     if (deferred >= 0 && (defer == 0 || defer == 3)) DRS_TRY(filter_gradient(deferred));
-    DRS_TRY(wait_handles(n, {h_bn}, st));
+    DRS_TRY(wait_handles(n, &h_bn, 1, st));
     float* gz = gzb[two ? (i & 1) : 0];
 #ifdef DRS_DEV
     if (xs) gz = q.gzL;
@@ -1384,7 +1387,7 @@ static int train_step_impl(drs_net_t* n, int B, int S, float lr0, int flags, dou
     pending.push_back(h);
     DRS_TRY(all_reduce(n, K_AR_SCALARS, conf, (size_t)n->K * n->K, I32, side, st, &h));
     pending.push_back(h);
-    DRS_TRY(wait_handles(n, pending, st));
+    DRS_TRY(wait_handles(n, pending.data(), pending.size(), st));
   }
   DRS_TRY(drs_scale_f64(scalars, 1, 1.0 / n_glob, st));
   if (!(flags & DRS_NO_UPDATE)) DRS_TRY(drs_apply_update(n, lr0, st));
