@@ -135,6 +135,11 @@ def main():
         rows = {}
         for f in argv[1:]:
             z = np.load(f)
+            if "seeds" in z.files:           # the compact form committed under profiles/: seeds[n], <side>[n, 11]
+                for side in ("hip", "torch", "fp64"):
+                    for sd, row in zip(z["seeds"], z[side]):
+                        rows.setdefault(int(sd), {})[side] = row
+                continue
             for key in z.files:
                 side, seed = key.rsplit("_", 1)
                 rows.setdefault(int(seed), {})[side] = z[key]
