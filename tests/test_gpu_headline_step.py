@@ -1,5 +1,6 @@
 """-m gpu: the step bench.py's headline times -- dilated_grsl_rate8 (Dilated8Pooling, isprs:996-1033), 128 patches of 64 x 64 x 5 of
-a 2048 x 2048 tile, through the product library's step engine (drs_train_step, libdrs_hip.so) -- held to the oracle launch by launch.
+a 2048 x 2048 tile, through the product library's step engine (drs_train_step, libdrs_hip.so) -- held to the oracle launch by launch;
+and the same for BASELINE configs[1] (Dilated6Pooling, batch 64 of 64 x 64) and configs[3]'s net (DenseDilated6, batch 128 of 75 x 75 x 4).
 
 The fp64 oracle of a whole step at this size does not fit a test (2.2 TFLOP forward, ~30 GB of fp64 activations), and train-mode
 batch norm couples all 128 patches, so the comparison is TEACHER-FORCED: every launch of the step is checked on ITS OWN operands as
@@ -19,22 +20,28 @@ pytestmark = pytest.mark.gpu
 
 from gpu_util import DEV, rel_err   # noqa: E402
 
-NET, CH, K, B, S, WD, LR = "dilated_grsl_rate8", 5, 6, 128, 64, 0.005, 0.01
-SAMPLE = (0, 61, 127)
+WD, LR = 0.005, 0.01
+D8P_LAYERS = [(5, 1, 5, 64), (5, 2, 64, 64), (4, 3, 64, 128), (4, 4, 128, 128), (3, 5, 128, 192), (3, 6, 192, 192), (3, 7, 192, 256), (3, 8, 256, 256)]      # isprs:1000-1021
+
+# the headline (BASELINE.json metric / configs[2]'s net at the metric's shape), configs[1] at its own shape (Dilated6Pooling, isprs:962-993),
+# configs[3]'s net at one of the sides `multinomial` lists (DenseDilated6: ReLU, no pool, every block a slice of the 448-wide concat slab,
+# conv1 / conv2 on the 256 x 32 register tile, input gradients ACCUMULATED into the concat gradient; isprs:914-959)
+CASES = [("dilated_grsl_rate8", 5, 6, 128, 64, 2048), ("dilated_grsl", 5, 6, 64, 64, 2048), ("dilated_icpr_rate6_densely", 4, 2, 128, 75, 500)]
 
 
-def _interior(slab, C, P):
-    return slab[:B * (S + 2 * P) ** 2 * C].view(B, S + 2 * P, S + 2 * P, C)[:, P:P + S, P:P + S, :]
-
-
-def test_every_launch_of_the_headline_step_on_its_own_operands():
+@pytest.mark.parametrize("NET,CH,K,B,S,TILE", CASES, ids=["headline-dilated8-128x64", "config2-dilated6pooling-64x64", "config4-dense-128x75"])
+def test_every_launch_of_the_step_on_its_own_operands(NET, CH, K, B, S, TILE):
     from drs_amd import _lib, patches as P
     from drs_amd.net import DilatedNet
     from drs_amd.synthetic import grid_instances, make_tile
     _lib.load()
-    tile, lab = make_tile(2048, 2048, CH, K, seed=1234)
+    SAMPLE = (0, B // 2 - 3, B - 1)
+
+    def _interior(slab, C, P):
+        return slab[:B * (S + 2 * P) ** 2 * C].view(B, S + 2 * P, S + 2 * P, C)[:, P:P + S, P:P + S, :]
+    tile, lab = make_tile(TILE, TILE, CH, K, seed=1234)
     pool = P.TilePool([tile], [lab], DEV, dtype=np.float64)
-    inst = grid_instances(2048, 2048, S, 25, B * 4, seed=0)
+    inst = grid_instances(TILE, TILE, S, 25, B * 4, seed=0)
     mean, std = tile[:, :, :3].mean(axis=(0, 1)).tolist(), tile[:, :, :3].std(axis=(0, 1)).tolist()
     net = DilatedNet(NET, CH, K, WD, b_max=B, s_max=S, device=DEV, seed=42)
     assert type(net).__name__ == "EngineNet" and net.plan.net_type == NET
@@ -46,8 +53,11 @@ def test_every_launch_of_the_headline_step_on_its_own_operands():
     torch.cuda.synchronize()
     M = B * S * S
     layers = net.plan.layers
-    assert [(L.k, L.rate, L.cin, L.cout) for L in layers] == [(5, 1, 5, 64), (5, 2, 64, 64), (4, 3, 64, 128), (4, 4, 128, 128), (3, 5, 128, 192),
-                                                              (3, 6, 192, 192), (3, 7, 192, 256), (3, 8, 256, 256)]      # isprs:1000-1021
+    if NET == "dilated_grsl_rate8":
+        assert [(L.k, L.rate, L.cin, L.cout) for L in layers] == D8P_LAYERS
+    dense = net.plan.dense
+    kind = "lrelu" if net.plan.alpha > 0 else "relu"
+    assert (kind, dense) == {"dilated_grsl_rate8": ("lrelu", False), "dilated_grsl": ("lrelu", False), "dilated_icpr_rate6_densely": ("relu", True)}[NET]
     sample = list(SAMPLE)
     for i, L in enumerate(layers):
         Cin_slab, Pin = net.plan.buffers[L.src]
@@ -73,12 +83,15 @@ def test_every_launch_of_the_headline_step_on_its_own_operands():
         mu, var = z64.mean(0), z64.var(0, unbiased=False)
         assert float((mr[:, 0] - mu).abs().max()) <= 1e-6 * float(mu.abs().max()) + 1e-7, L.name
         assert float((mr[:, 1] / (var + 1e-3).rsqrt() - 1).abs().max()) < 2e-6, L.name                 # eps 0.001: contrib batch_norm (isprs:658)
-        # (3) normalise + leaky ReLU 0.1 + 3 x 3 / stride-1 max-pool (isprs:715-721, 745-746) on the sampled patches, given the engine's moments
+        # (3) normalise + (leaky) ReLU [+ 3 x 3 / stride-1 max-pool] (isprs:715-721, 745-746) on the sampled patches, given the engine's moments
         zs = z[sample].cpu().numpy().astype(np.float64)
         xhat = (zs - mr[:, 0].cpu().numpy()) * mr[:, 1].cpu().numpy()
-        act = T.act_fwd(xhat, "lrelu")
-        pooled, idx = T.max_pool_3x3(act)
+        act = T.act_fwd(xhat, kind)
         got = _interior(net.abuf[L.dst], Cout_slab, Pout)[sample][..., L.dst_coff:L.dst_coff + L.cout].cpu().numpy()
+        if net.plan.pools[i] is None:
+            assert rel_err(got, act) < 1e-5, L.name
+            continue
+        pooled, idx = T.max_pool_3x3(act)
         assert rel_err(got, pooled) < 1e-5, L.name
         # arg-max codes: equal wherever the winner is clear in fp64 (first maximum in scan order on ties, as TF's MaxPoolGrad)
         didx = net.idx[i][:M * L.cout].view(B, S, S, L.cout)[sample].cpu().numpy()
@@ -112,9 +125,10 @@ def test_every_launch_of_the_headline_step_on_its_own_operands():
     assert torch.equal(out["conf"].long(), want)                                            # integer atomics: exact
     # ---- backward, what the buffers still hold after the step
     dl = (torch.softmax(lg, 1) - torch.nn.functional.one_hot(labels, K)) / M                # d(mean CE) / d(logits)
-    gfeat = net.gbuf[net.plan.feat][:M * Cf].view(M, Cf)
-    ref_g = dl @ wc.t()
-    assert float((gfeat.double() - ref_g).abs().max()) <= 1e-5 * float(ref_g.abs().max())
+    if not dense:           # (the dense net's concat gradient has by now ACCUMULATED every later block's input gradient on top of the classifier's)
+        gfeat = net.gbuf[net.plan.feat][:M * Cf].view(M, Cf)
+        ref_g = dl @ wc.t()
+        assert float((gfeat.double() - ref_g).abs().max()) <= 1e-5 * float(ref_g.abs().max())
     gw = torch.from_numpy(net.get_gradient("conv_classifier/weights").reshape(Cf, K)).to(DEV).double()
     ref_w = feat.t() @ dl
     assert float((gw - ref_w).abs().max()) <= 1e-5 * float(ref_w.abs().max())
@@ -137,3 +151,4 @@ def test_every_launch_of_the_headline_step_on_its_own_operands():
     assert float((g0 - ref0).abs().max()) <= 1e-5 * float(ref0.abs().max())
     # the input gradient of conv2 (the last input-gradient launch: gact of conv1's output slab) on the sampled patches needs conv2's gz,
     # which `gz` no longer holds: covered on random operands at this shape by tests/test_gpu_configs.py
+    assert M >= (1 << 18)         # (one-stream backward pass: `gz` is the only output-gradient slab, and conv1's was the last written)
