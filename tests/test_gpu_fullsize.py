@@ -130,6 +130,63 @@ def test_bn_pool_and_loss_invariants_at_full_size():
     assert abs((gfeat.view(M, C).double() * feat.double()).sum().item() - (dl * logits.view(M, K).double()).sum().item()) < 1e-6
 
 
+@pytest.mark.parametrize("C,P_out", [(256, 8), (64, 4)])
+def test_bn_pool_backward_every_element_at_full_size(C, P_out):
+    """The backward elementwise launches of a block at 128 x 64 x 64 -- pool backward + leaky-ReLU backward + the batch-norm-backward
+    sums (drs_bn_backward_reduce), the means (drs_stats_reduce_means) and gz = rstd * (g - mean_g - xhat * mean_gx) written into the
+    haloed slab the next convolution reads (drs_bn_backward_apply_means: the single-rank form the timed step runs; and the fp64-sums
+    form behind an all-reduce) -- against the same expressions in fp64 on the device, EVERY element (isprs:655-663, 745-746 backward):
+    pool winners are the device's own arg-max codes (the forward pass is checked bit-exactly above)."""
+    from drs_amd import _lib
+    alpha = 0.1
+    g0 = torch.Generator(device=DEV).manual_seed(11 + C)
+    z = torch.randn(M, C, device=DEV, generator=g0) * 1.5 + 0.3
+    ga = torch.randn(M, C, device=DEV, generator=g0)
+    st = stream()
+    z64 = z.double()
+    mu, var = z64.mean(0), z64.var(0, unbiased=False)
+    mr = torch.stack([mu, (var + 1e-3).rsqrt()], dim=1).float().contiguous()            # (mean, rstd) as the forward pass leaves them
+    out = torch.empty(M * C, device=DEV)
+    idx = torch.empty(M * C, dtype=torch.uint8, device=DEV)
+    _lib.call("drs_bn_act_pool_forward", z.data_ptr(), B, S, C, mr.data_ptr(), alpha, 1, out.data_ptr(), 0, C, 0, idx.data_ptr(), st)
+    rows_b = _lib.query("drs_bn_backward_rows", B, S, C, 1)
+    gxh = torch.empty(M * C, device=DEV)
+    pb = torch.empty(rows_b * C * 2, device=DEV)
+    _lib.call("drs_bn_backward_reduce", ga.data_ptr(), C, 0, z.data_ptr(), idx.data_ptr(), B, S, C, mr.data_ptr(), alpha, 1, gxh.data_ptr(),
+              pb.data_ptr(), st)
+    sums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    means = torch.zeros(2 * C, device=DEV)
+    _lib.call("drs_stats_reduce_means", pb.data_ptr(), rows_b, C, float(M), sums.data_ptr(), means.data_ptr(), st)
+    Sp = S + 2 * P_out
+    gz = torch.full((B, Sp, Sp, C), 7.0, device=DEV)                                   # junk in the halo: the launch must zero it
+    _lib.call("drs_bn_backward_apply_means", gxh.data_ptr(), z.data_ptr(), B, S, C, mr.data_ptr(), means.data_ptr(), gz.data_ptr(), P_out, C, 0, st)
+    gz2 = torch.full((B, Sp, Sp, C), 7.0, device=DEV)
+    _lib.call("drs_bn_backward_apply", gxh.data_ptr(), z.data_ptr(), B, S, C, mr.data_ptr(), sums.data_ptr(), float(M), gz2.data_ptr(), P_out, C, 0, st)
+    torch.cuda.synchronize()
+    # fp64 on the device: route ga to the pool's winners (arg-max code = dy * 3 + dx of the 3 x 3 window), activation slope, sums, apply
+    mr64 = mr.double()
+    xh = (z64 - mr64[:, 0]) * mr64[:, 1]
+    gp = torch.zeros(B, S + 2, S + 2, C, dtype=torch.float64, device=DEV)
+    g4, i4 = ga.view(B, S, S, C).double(), idx.view(B, S, S, C)
+    for code in range(9):
+        dy, dx = divmod(code, 3)
+        gp[:, dy:dy + S, dx:dx + S, :] += torch.where(i4 == code, g4, torch.zeros((), dtype=torch.float64, device=DEV))
+    gact = gp[:, 1:-1, 1:-1, :].reshape(M, C)
+    del gp
+    gx_ref = gact * torch.where(xh > 0, 1.0, alpha)
+    assert float((gxh.view(M, C).double() - gx_ref).abs().max()) <= 1e-6 * float(gx_ref.abs().max())
+    s1, s2 = gx_ref.sum(0), (gx_ref * xh).sum(0)
+    assert float((sums.view(C, 2)[:, 0] - s1).abs().max()) <= 1e-6 * float(gx_ref.abs().sum(0).max())
+    assert float((sums.view(C, 2)[:, 1] - s2).abs().max()) <= 1e-6 * float((gx_ref * xh).abs().sum(0).max())
+    gz_ref = mr64[:, 1] * (gx_ref - s1 / M - xh * (s2 / M))
+    for got in (gz, gz2):
+        inner = got[:, P_out:P_out + S, P_out:P_out + S, :].reshape(M, C).double()
+        assert float((inner - gz_ref).abs().max()) <= 1e-5 * float(gz_ref.abs().max())
+        assert float(got[:, :P_out].abs().max()) == 0 and float(got[:, -P_out:].abs().max()) == 0          # the halo the next convolution
+        assert float(got[:, :, :P_out].abs().max()) == 0 and float(got[:, :, -P_out:].abs().max()) == 0    # reads without bounds checks
+    assert torch.equal(gz, gz2)          # the two forms of the apply pass: the same bits (DESIGN 3)
+
+
 def test_crop_equals_direct_slicing_and_stitch_of_constant_logits():
     from drs_amd import _lib, patches as P
     from drs_amd.net import DilatedNet
