@@ -201,3 +201,57 @@ def test_dilated_conv_matches_tensorflows_space_to_batch_formulation(k, rate, H,
     ref = _atrous_conv2d_same_tf(x, w, rate)
     assert got.shape == ref.shape == (2, H, W, 4)
     np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)
+
+
+def test_known_answers_published_with_tensorflows_api():
+    """The reference holds no golden vectors for its graph half and TensorFlow cannot run here (parity of the graph half is
+    UNPINNED).  What TensorFlow itself PUBLISHES with the ops the reference calls is pinned here: the worked examples and the defining
+    formulas of its API documentation (restated, not copied code), as known answers for oracle/tf_ops.py.
+      * tf.nn.sparse_softmax_cross_entropy_with_logits (isprs:1093), the documented example: logits [[2, -5, .5, -.1], [0, 0, 1.9, 1.4],
+        [-100, 100, -100, -100]], labels [0, 3, 1] -> [0.29750752, 1.1448325, 0.]; and tf.nn.softmax_cross_entropy_with_logits' example
+        logits [[4, 2, 1], [0, 5, 1]] with the one-hot row [1, 0, 0] -> 0.16984604
+      * SAME padding at stride 1 (the convolution guide): pad_total = max(k_eff - 1, 0) with k_eff = k + (k - 1)(rate - 1) for
+        atrous_conv2d (isprs:710), pad_before = pad_total // 2, the odd pixel after
+      * tf.nn.l2_loss = sum(t ** 2) / 2 (isprs:648); tf.train.exponential_decay(staircase=True) = lr * rate ** floor(step / decay_steps)
+        (isprs:1686); MomentumOptimizer: accumulation = momentum * accumulation + gradient; variable -= lr * accumulation (isprs:1687)."""
+    lg = np.array([[2.0, -5.0, 0.5, -0.1], [0.0, 0.0, 1.9, 1.4], [-100.0, 100.0, -100.0, -100.0]])
+    want = np.array([0.29750752, 1.1448325, 0.0])
+    for i, lab in enumerate([0, 3, 1]):
+        ce, g = T.softmax_ce(lg[i:i + 1].reshape(1, 1, 1, 4), np.array([[[lab]]]))
+        assert abs(ce - want[i]) < 2e-7 * max(1.0, want[i]), (i, ce)
+        assert abs(g.sum()) < 1e-12                                   # softmax - onehot sums to zero
+    ce, _ = T.softmax_ce(lg.reshape(1, 3, 1, 4), np.array([0, 3, 1]).reshape(1, 3, 1))
+    assert abs(ce - want.mean()) < 1e-7                               # isprs:1095: reduce_mean over the pixels
+    ce, _ = T.softmax_ce(np.array([4.0, 2.0, 1.0]).reshape(1, 1, 1, 3), np.array([[[0]]]))
+    assert abs(ce - 0.16984604) < 1e-7                                # (the documentation prints float32 results)
+    for k in (1, 2, 3, 4, 5):
+        for rate in range(1, 9):
+            k_eff = k + (k - 1) * (rate - 1)
+            pad_total = max(k_eff - 1, 0)
+            assert nets.same_pad(k, rate) == (pad_total // 2, pad_total - pad_total // 2)
+            x = np.zeros((1, 9, 11, 1))
+            x[0, 4, 5, 0] = 1.0
+            w = np.arange(1.0, k * k + 1).reshape(k, k, 1, 1)
+            y = T.conv2d_same(x, w, rate)                             # an impulse: the filter, flipped, placed by the padding rule
+            assert y.shape == x.shape
+            pb = pad_total // 2
+            for u in range(k):
+                for v in range(k):
+                    yy, xx = 4 - (u * rate - pb), 5 - (v * rate - pb)
+                    if 0 <= yy < 9 and 0 <= xx < 11:
+                        assert y[0, yy, xx, 0] == w[u, v, 0, 0]
+    t = np.array([[1.0, -2.0], [3.0, 0.5]])
+    o = T.OracleNet("dilated_grsl", 5, 6, seed=1)
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(2, 6, 6, 5))
+    yl = rng.integers(0, 6, size=(2, 6, 6))
+    loss, _, grads, logits = o.loss_and_grads(x, yl, 0.01)
+    ce, _ = T.softmax_ce(logits, yl)
+    l2 = sum(0.5 * float((o.p[n] ** 2).sum()) for n in o.p if n.endswith("/weights"))
+    assert abs(loss - (ce + 0.01 * l2)) < 1e-12 and abs(0.5 * (t ** 2).sum() - 7.125) < 1e-15        # wd * l2_loss per kernel (isprs:646-651)
+    assert T.learning_rate(0.01, 49999, 0.5) == 0.01 and T.learning_rate(0.01, 50000, 0.5) == 0.005 and T.learning_rate(0.01, 149999, 0.1) == 0.01 * 0.1 ** 2
+    w0 = {n: o.p[n].copy() for n in grads}
+    o.apply_momentum(grads, 0.02)
+    o.apply_momentum(grads, 0.02)                                     # accumulation = 0.9 * g + g after the second call
+    for n in grads:
+        np.testing.assert_allclose(o.p[n], w0[n] - 0.02 * grads[n] - 0.02 * (0.9 * grads[n] + grads[n]), rtol=0, atol=1e-15 + 1e-13 * np.abs(w0[n]).max())
