@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """The population comparison of tests/test_gpu_accuracy_parity.py over MANY seeds (development aid: is a mean paired difference of
 the late training loss / held-out accuracy between the HIP path and the CPU oracle chance or bias?).
-    python tools/parity_population.py [seeds=24] [first=100]"""
+    python tests/fuzz/parity_population.py [seeds=24] [first=100]"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import conftest

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""is the same-sign difference of the late training loss / held-out accuracy between the HIP path and the CPU
+"""TEST INFRASTRUCTURE (imports oracle/; lives under tests/ for that reason).  VERDICT r05 item 2: is the same-sign difference of the late training loss / held-out accuracy between the HIP path and the CPU
 oracle chance (two correct fp32 implementations drifting apart through eight batch-normalised layers) or a bias of the HIP path?
 
 Three implementations of the run of tests/test_gpu_accuracy_parity.py (120 steps of 6 patches of 20 x 20, Dilated8Pooling, then the
@@ -10,9 +10,9 @@ held-out tile labelled by sliding window with each side's own trained variables)
                                                          fp32 rounding + chaos alone does to these statistics)
     hip    the product library (libdrs_hip.so)
 The sides are independent given the seed, so they run where their hardware is and are merged afterwards:
-    python tools/parity_threeway.py side=hip   first=1000 seeds=600 out=gpurun_out/r06/threeway_hip.npz          (GPU box)
-    python tools/parity_threeway.py side=cpu   first=1000 seeds=600 out=threeway_cpu_0.npz [threads=8] [order=desc]   (any host; no GPU; resumes from `out`)
-    python tools/parity_threeway.py merge hip.npz cpu_a.npz cpu_b.npz ...                                        (report)
+    python tests/fuzz/parity_threeway.py side=hip   first=1000 seeds=600 out=gpurun_out/r06/threeway_hip.npz          (GPU box)
+    python tests/fuzz/parity_threeway.py side=cpu   first=1000 seeds=600 out=threeway_cpu_0.npz [threads=8] [order=desc]   (any host; no GPU; resumes from `out`)
+    python tests/fuzz/parity_threeway.py merge hip.npz cpu_a.npz cpu_b.npz ...                                        (report)
 Per seed and side: loss of steps 0..7 (the trajectory before the chaos), mean loss of steps 20-59 and of steps 100-119, held-out accuracy.
 """
 import os
@@ -20,7 +20,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

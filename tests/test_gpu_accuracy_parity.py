@@ -13,7 +13,7 @@ drift apart after a few dozen steps, so one pair of runs says little.  The test 
     spread of those differences.  (r05: twelve seeds, paired -- the oracle's PyTorch-CPU side now runs with a thread per GRANTED
     core, tests/conftest.py, 4 s a seed instead of 60; the unpaired band of three seeds was 0.30 of accuracy wide -- a build that
     labelled at chance would have passed it -- this one is ~0.12.  r06: the band is 3.3 standard errors of the spread measured over 600
-    paired seeds, no floors; tools/parity_threeway.py: HIP, PyTorch-CPU fp32 and an fp64 run of the same seeds,
+    paired seeds, no floors; tests/fuzz/parity_threeway.py: HIP, PyTorch-CPU fp32 and an fp64 run of the same seeds,
     profiles/r06/accuracy_parity_threeway.txt.)
 """
 import numpy as np
@@ -30,7 +30,7 @@ from gpu_util import DEV   # noqa: E402
 
 NET, CH, K, B, S, STEPS, LR, WD = "dilated_grsl_rate8", 5, 6, 6, 20, 120, 0.01, 0.0005
 SEEDS = tuple(range(12))
-# per-seed standard deviation of (HIP - PyTorch-CPU fp32) over 600 paired seeds of this very run (tools/parity_threeway.py,
+# per-seed standard deviation of (HIP - PyTorch-CPU fp32) over 600 paired seeds of this very run (tests/fuzz/parity_threeway.py,
 # profiles/r06/accuracy_parity_threeway.txt): mean loss of steps 100-119, held-out pixel accuracy
 POP_SD_LATE_LOSS, POP_SD_ACCURACY = 0.074, 0.122
 
