@@ -240,6 +240,13 @@ def test_known_answers_published_with_tensorflows_api():
                     yy, xx = 4 - (u * rate - pb), 5 - (v * rate - pb)
                     if 0 <= yy < 9 and 0 <= xx < 11:
                         assert y[0, yy, xx, 0] == w[u, v, 0, 0]
+    # tf.keras.layers.LeakyReLU's documented example at the reference's slope (isprs:620-621: tf.maximum(0.1 * x, x)): [-3, -1, 0, 2] -> [-0.3, -0.1, 0, 2]
+    np.testing.assert_allclose(T.act_fwd(np.array([-3.0, -1.0, 0.0, 2.0]), "lrelu"), [-0.3, -0.1, 0.0, 2.0], rtol=0, atol=1e-15)
+    np.testing.assert_array_equal(T.act_fwd(np.array([-3.0, -1.0, 0.0, 2.0]), "relu"), [0.0, 0.0, 0.0, 2.0])
+    # tf.keras.layers.MaxPooling2D's documented padding='same', strides 1 example has a 2 x 2 window; for the reference's 3 x 3 window the
+    # documented RULE is what is pinned: SAME pads with -inf (padding never wins), here on the same 3 x 3 input [[1..3], [4..6], [7..9]]
+    y, idx = T.max_pool_3x3(np.arange(1.0, 10.0).reshape(1, 3, 3, 1) - 20.0)          # all negative: a zero pad would win everywhere
+    np.testing.assert_array_equal(y[0, :, :, 0] + 20.0, [[5, 6, 6], [8, 9, 9], [8, 9, 9]])
     t = np.array([[1.0, -2.0], [3.0, 0.5]])
     o = T.OracleNet("dilated_grsl", 5, 6, seed=1)
     rng = np.random.default_rng(0)
