@@ -85,13 +85,13 @@ def run_cpu(seed, dtype, data):
     return stats(losses, float((pred == held_lab).mean()))
 
 
-def run_hip(seed, data):
+def run_hip(seed, data, arith="f32"):
     from drs_amd import loops, patches as P
     from drs_amd.net import DilatedNet
     from drs_amd.synthetic import grid_instances
     tile, lab, held, held_lab, mean, std = data
     inst = grid_instances(tile.shape[0], tile.shape[1], S, 8, B * STEPS, seed=100 + seed)
-    d = DilatedNet(NET, CH, K, WD, b_max=B, s_max=S, device="cuda:0", seed=21 + seed)
+    d = DilatedNet(NET, CH, K, WD, b_max=B, s_max=S, device="cuda:0", seed=21 + seed, arith=arith)
     pool = P.TilePool([tile], [lab], "cuda:0")
     losses = []
     for i in range(STEPS):
@@ -136,7 +136,7 @@ def main():
         for f in argv[1:]:
             z = np.load(f)
             if "seeds" in z.files:           # the compact form committed under profiles/: seeds[n], <side>[n, 11]
-                for side in ("hip", "torch", "fp64"):
+                for side in ("hip", "torch", "fp64"):          # (hip_bf16x6, the opt-in split-kernel arm, is in the file for the record only)
                     for sd, row in zip(z["seeds"], z[side]):
                         rows.setdefault(int(sd), {})[side] = row
                 continue
@@ -161,9 +161,10 @@ def main():
     done = 0
     for seed in order:
         if side == "hip":
-            if "hip_%d" % seed in res:
+            key = ("hip" if kw.get("arith", "f32") == "f32" else kw["arith"]) + "_%d" % seed      # (arith=bf16x6: the opt-in three-term split kernels, op-level path)
+            if key in res:
                 continue
-            res["hip_%d" % seed] = run_hip(seed, data)
+            res[key] = run_hip(seed, data, kw.get("arith", "f32"))
         else:
             if "fp64_%d" % seed in res and "torch_%d" % seed in res:
                 continue
